@@ -1,0 +1,157 @@
+"""TEST INFRASTRUCTURE — CPU oracle for score filter / top-k / NMS / gather / retrieval.
+
+numpy restatement (integer/index work, bit-exact contract).  The defined total order
+is the one SURVEY.md §7 fixes: candidates enumerate row-major over [anchor, class]
+(``torch.nonzero`` order, generate_proposal.py:110-111); sorting is by score
+descending with ties broken by candidate index ascending (= the reference run with
+``sort(stable=True)``; its default unstable sort is not reproducible at tie level).
+
+Reference sites:
+  filter_scores_and_topk           generate_proposal.py:85-131
+  head_predict per-image loop      generate_proposal.py:1196-1218; extract_embedding.py:1233-1260
+  predict_by_feat per-image loop   wedetect/models/dense_heads/yolo_world_head.py:680-748
+  un-letterbox + clamp             generate_proposal.py:1106-1115
+  retrieval similarity             eval_retrieval/retrieval_metric.py:367-377
+  batched NMS: torchvision.ops.batched_nms (call generate_proposal.py:1210) and
+  mmcv.ops.batched_nms (call via _bbox_post_process, yolo_world_head.py:740-744) —
+  third-party native code, absent here: **parity unpinned**.  Restated from their
+  documented behaviour: per class, greedy in descending score; box i suppresses a
+  later box j of the same class iff  inter / (area_i + area_j - inter) > thr  with
+  area = (x2-x1)*(y2-y1), inter = max(0, .)*max(0, .), fp32, evaluated left to right;
+  kept indices are returned in descending-score order.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+f32 = np.float32
+
+
+def filter_scores_and_topk(scores: np.ndarray, score_thr: float, topk: int):
+    """scores [N, K] fp32 -> (scores[n], labels[n] i64, anchor_idx[n] i64), n <= topk."""
+    scores = np.ascontiguousarray(scores, dtype=f32)
+    n, k = scores.shape
+    flat = scores.reshape(-1)
+    valid = np.nonzero(flat > f32(score_thr))[0]          # ascending flat index
+    s = flat[valid]
+    order = np.argsort(-s, kind="stable")                  # desc, ties: index asc
+    num = min(int(topk), valid.shape[0])
+    order = order[:num]
+    idx = valid[order]
+    return s[order], (idx % k).astype(np.int64), (idx // k).astype(np.int64)
+
+
+def iou_suppresses(bi: np.ndarray, bj: np.ndarray, thr: float) -> np.ndarray:
+    """fp32 IoU test of one box ``bi`` [4] against boxes ``bj`` [m,4]; True = suppressed."""
+    area_i = (bi[2] - bi[0]) * (bi[3] - bi[1])
+    area_j = (bj[:, 2] - bj[:, 0]) * (bj[:, 3] - bj[:, 1])
+    xx1 = np.maximum(bi[0], bj[:, 0])
+    yy1 = np.maximum(bi[1], bj[:, 1])
+    xx2 = np.minimum(bi[2], bj[:, 2])
+    yy2 = np.minimum(bi[3], bj[:, 3])
+    w = np.maximum(f32(0), xx2 - xx1)
+    h = np.maximum(f32(0), yy2 - yy1)
+    inter = w * h
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ovr = inter / (area_i + area_j - inter)
+    return ovr > f32(thr)
+
+
+def batched_nms(boxes: np.ndarray, scores: np.ndarray, labels: np.ndarray, thr: float,
+                max_keep: Optional[int] = None) -> np.ndarray:
+    """Class-aware greedy NMS.  Inputs must already be in the defined total order
+    (they are: the output of filter_scores_and_topk).  Returns kept candidate indices
+    in that order.  ``max_keep`` stops early — identical to slicing the full result,
+    because whether a box is kept depends only on earlier kept boxes."""
+    boxes = np.ascontiguousarray(boxes, dtype=f32)
+    n = boxes.shape[0]
+    assert np.all(scores[:-1] >= scores[1:]), "candidates must be sorted by score desc"
+    suppressed = np.zeros(n, dtype=bool)
+    keep: List[int] = []
+    for i in range(n):
+        if suppressed[i]:
+            continue
+        keep.append(i)
+        if max_keep is not None and len(keep) >= max_keep:
+            break
+        rest = np.nonzero((labels[i + 1:] == labels[i]) & ~suppressed[i + 1:])[0] + i + 1
+        if rest.size:
+            sup = iou_suppresses(boxes[i], boxes[rest], thr)
+            suppressed[rest[sup]] = True
+    return np.asarray(keep, dtype=np.int64)
+
+
+def unletterbox(boxes: np.ndarray, pad_xy: Tuple[float, float], ratio: float,
+                ori_hw: Tuple[int, int], rescale: bool = True) -> np.ndarray:
+    """generate_proposal.py:1106-1115: subtract (dw, dh), divide by ratio, clamp."""
+    b = boxes.astype(f32).copy()
+    b -= np.asarray([pad_xy[0], pad_xy[1], pad_xy[0], pad_xy[1]], dtype=f32)
+    if rescale:
+        b /= f32(ratio)
+    b[:, 0::2] = np.clip(b[:, 0::2], f32(0), f32(ori_hw[1]))
+    b[:, 1::2] = np.clip(b[:, 1::2], f32(0), f32(ori_hw[0]))
+    return b
+
+
+def uni_predict_image(boxes: np.ndarray, embed: np.ndarray, scores: np.ndarray,
+                      level_of: np.ndarray, logit_scale: np.ndarray, contrast_bias: np.ndarray,
+                      num_proposals: int = 300, nms_pre: int = 30000, iou_thr: float = 0.7,
+                      score_thr: float = 0.0) -> Dict[str, np.ndarray]:
+    """One image of SimpleYOLOWorldDetector.head_predict (generate_proposal.py:1197-1217,
+    with the extra outputs of extract_embedding.py:1247-1259).  Boxes stay in
+    letterboxed network coordinates (NMS runs before the un-letterbox there)."""
+    s, labels, anchors = filter_scores_and_topk(scores, score_thr, nms_pre)
+    cand_boxes = boxes[anchors]
+    keep = batched_nms(cand_boxes, s, labels, iou_thr, max_keep=num_proposals)
+    a = anchors[keep]
+    lv = level_of[a]
+    return dict(bboxes=cand_boxes[keep], embeddings=embed[a], scores=s[keep], labels=labels[keep],
+                anchors=a, scales=logit_scale[lv].astype(f32), bias=contrast_bias[lv].astype(f32),
+                num_candidates=np.int64(s.shape[0]), keep=keep)
+
+
+def mmdet_predict_image(boxes: np.ndarray, scores: np.ndarray, pad_param, scale_factor,
+                        ori_hw: Tuple[int, int], score_thr: float = 0.001, nms_pre: int = 30000,
+                        iou_thr: float = 0.7, max_per_img: int = 300) -> Dict[str, np.ndarray]:
+    """One image of YOLOWorldHead.predict_by_feat, multi_label=True
+    (yolo_world_head.py:680-748): filter/top-k, rescale to original pixels, THEN NMS,
+    [:max_per_img], clamp.  pad_param = (top, bottom, left, right); scale_factor = (w, h)."""
+    s, labels, anchors = filter_scores_and_topk(scores, score_thr, nms_pre)
+    b = boxes[anchors].astype(f32)
+    if pad_param is not None:
+        b = b - np.asarray([pad_param[2], pad_param[0], pad_param[2], pad_param[0]], dtype=f32)
+    b = b / np.asarray([scale_factor[0], scale_factor[1]] * 2, dtype=f32)
+    if s.shape[0] == 0:
+        return dict(bboxes=b, scores=s, labels=labels, anchors=anchors)
+    keep = batched_nms(b, s, labels, iou_thr, max_keep=max_per_img)
+    b = b[keep]
+    b[:, 0::2] = np.clip(b[:, 0::2], f32(0), f32(ori_hw[1]))
+    b[:, 1::2] = np.clip(b[:, 1::2], f32(0), f32(ori_hw[0]))
+    return dict(bboxes=b, scores=s[keep], labels=labels[keep], anchors=anchors[keep])
+
+
+def retrieval_scores(embedding: np.ndarray, text: np.ndarray, scale: np.ndarray,
+                     bias: np.ndarray) -> np.ndarray:
+    """retrieval_metric.py:369-375: sigmoid((E Tᵀ)·exp(scale_r)+bias_r), max over regions.
+    embedding [R,768], text [K,768], scale/bias [R] -> [K] fp32 (zeros-size R -> -inf guard
+    is not in the reference: R >= 1 always there)."""
+    import torch  # the reference computes this in torch fp32; keep its op sequence
+    e = torch.from_numpy(np.ascontiguousarray(embedding, dtype=f32))
+    t = torch.from_numpy(np.ascontiguousarray(text, dtype=f32))
+    sc = torch.from_numpy(np.ascontiguousarray(scale, dtype=f32))
+    bs = torch.from_numpy(np.ascontiguousarray(bias, dtype=f32))
+    lg = torch.einsum('bw,kw->bk', e, t)
+    lg = torch.sigmoid(lg * sc.exp().unsqueeze(1) + bs.unsqueeze(1))
+    return torch.max(lg, dim=0)[0].numpy()
+
+
+def shard_indices(total: int, world: int, rank: int) -> range:
+    """InferenceSampler._get_local_indices (extract_embedding.py:1631-1638)."""
+    shard = total // world
+    left = total % world
+    sizes = [shard + int(r < left) for r in range(world)]
+    begin = sum(sizes[:rank])
+    end = min(sum(sizes[:rank + 1]), total)
+    return range(begin, end)

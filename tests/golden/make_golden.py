@@ -1,0 +1,436 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by IMPORTING the reference.
+
+Runs only in the build container (needs /root/reference; CPU).  It
+  1. builds the reference's own modules (generate_proposal.py pure-torch copy, and the
+     wedetect/models mmdet-plugin classes through import stubs for mmdet/mmcv/mmengine),
+  2. loads the name-keyed synthetic weights of wedetect_amd.weights into them,
+  3. runs them on seeded synthetic inputs,
+  4. checks the repo's oracle (oracle/ref_cpu.py, oracle/postprocess.py) against those
+     outputs — bit-identical on the network, index-exact on filter/top-k (reference run
+     with its sort forced stable) — and aborts on any mismatch,
+  5. writes small .npz fixtures (checksums, sampled elements, final detections).
+
+Only data is written: no reference source text is copied.  torchvision is absent, so
+``torchvision.ops.batched_nms`` is bound to the oracle's restatement while the
+reference's head_predict runs (NMS parity stays "unpinned", see oracle/__init__.py).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+"""
+import sys
+sys.dont_write_bytecode = True
+
+import contextlib
+import importlib
+import importlib.abc
+import importlib.machinery
+import importlib.util
+import os
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+
+from oracle import postprocess as opp          # noqa: E402
+from oracle import ref_cpu as orc              # noqa: E402
+from wedetect_amd import weights as W          # noqa: E402
+from wedetect_amd.arch import get_arch, HD     # noqa: E402
+
+torch.set_grad_enabled(False)
+torch.manual_seed(0)
+
+
+# ------------------------------------------------------------------ reference import helpers
+def _nms_stub(boxes, scores, idxs, iou_threshold):
+    keep = opp.batched_nms(boxes.numpy(), scores.numpy(), idxs.numpy(), float(iou_threshold))
+    return torch.from_numpy(keep)
+
+
+def import_generate_proposal():
+    tv = types.ModuleType("torchvision")
+    tv.ops = types.ModuleType("torchvision.ops")
+    tv.ops.batched_nms = _nms_stub
+    tv.__spec__ = importlib.machinery.ModuleSpec("torchvision", None)
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.ops"] = tv.ops
+    sys.path.insert(0, REF)
+    spec = importlib.util.spec_from_file_location("ref_generate_proposal", os.path.join(REF, "generate_proposal.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@contextlib.contextmanager
+def stable_sort():
+    """Force every Tensor.sort inside the reference to be stable."""
+    orig = torch.Tensor.sort
+
+    def patched(self, *a, **k):
+        k.setdefault("stable", True)
+        return orig(self, *a, **k)
+    torch.Tensor.sort = patched
+    try:
+        yield
+    finally:
+        torch.Tensor.sort = orig
+
+
+class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    """Generic stand-in modules for mmdet / mmcv / mmengine / timm / cv2 so that the
+    reference's wedetect/models/*.py can be imported for their nn.Module code."""
+    ROOTS = ("mmdet", "mmcv", "mmengine", "timm", "cv2", "mmyolo")
+
+    def find_spec(self, name, path=None, target=None):
+        if name.split(".")[0] in self.ROOTS:
+            return importlib.machinery.ModuleSpec(name, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        return _StubModule(spec.name)
+
+    def exec_module(self, module):
+        pass
+
+
+class _Registry:
+    def register_module(self, *a, **k):
+        if a and isinstance(a[0], type):
+            return a[0]
+        return lambda cls: cls
+
+    def build(self, cfg):
+        raise RuntimeError("stub registry cannot build")
+
+
+import abc as _abc
+
+
+class _StubMeta(_abc.ABCMeta):
+    def __getattr__(cls, item):
+        raise AttributeError(item)
+
+
+class _StubModule(types.ModuleType):
+    __path__ = []
+
+    def __getattr__(self, item):
+        if item.startswith("__"):
+            raise AttributeError(item)
+        if item in ("MODELS", "TASK_UTILS", "TRANSFORMS", "DATASETS", "HOOKS", "OPTIM_WRAPPER_CONSTRUCTORS",
+                    "OPTIMIZERS", "DATA_SAMPLERS", "METRICS", "FUNCTIONS"):
+            return _Registry()
+        if item in ("BaseModule", "BaseModel"):
+            return _BaseModule
+        if item == "_BatchNorm":
+            return torch.nn.modules.batchnorm._BatchNorm
+        if item == "DropPath":
+            return lambda *a, **k: torch.nn.Identity()
+        if item == "trunc_normal_":
+            return lambda t, *a, **k: t
+        if item == "ConvModule":
+            return _ConvModule
+        if item and item[0].isupper():
+            return _StubMeta(item, (torch.nn.Module,), {"__init__": lambda self, *a, **k: torch.nn.Module.__init__(self)})
+        return lambda *a, **k: None
+
+
+class _BaseModule(torch.nn.Module):
+    """mmengine.model.BaseModule stand-in: nn.Module that swallows ``init_cfg``."""
+
+    def __init__(self, init_cfg=None, **kw):
+        super().__init__()
+
+
+class _ConvModule(torch.nn.Module):
+    """mmcv.cnn.ConvModule as the head uses it: conv(no bias) + BN + act (keys conv/bn)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, norm_cfg=None, act_cfg=None, **kw):
+        super().__init__()
+        self.conv = torch.nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, bias=norm_cfg is None)
+        self.bn = torch.nn.BatchNorm2d(out_channels, momentum=norm_cfg.get("momentum", 0.1), eps=norm_cfg.get("eps", 1e-5))
+        self.act = torch.nn.SiLU(inplace=False)
+
+    def forward(self, x):
+        return self.act(self.bn(self.conv(x)))
+
+
+def import_wedetect_models():
+    """Import the reference's mmdet-plugin model files with stubbed third parties."""
+    sys.meta_path.insert(0, _StubFinder())
+    root = os.path.join(REF, "wedetect", "models")
+
+    # fake parent packages so that the files' relative imports resolve to stand-ins
+    for pkg in ("refwd", "refwd.models", "refwd.models.necks", "refwd.models.backbones"):
+        m = types.ModuleType(pkg)
+        m.__path__ = []
+        sys.modules[pkg] = m
+    y8 = types.ModuleType("refwd.models.necks.yolov8_pafpn")
+    y8.YOLOv8PAFPN = type("YOLOv8PAFPN", (torch.nn.Module,), {})
+    sys.modules["refwd.models.necks.yolov8_pafpn"] = y8
+
+    def load(modname, rel):
+        spec = importlib.util.spec_from_file_location(modname, os.path.join(root, rel))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[modname] = m
+        spec.loader.exec_module(m)
+        return m
+    bb = load("refwd.models.backbones.mm_backbone", "backbones/mm_backbone.py")
+    nk = load("refwd.models.necks.yolo_world_pafpn", "necks/yolo_world_pafpn.py")
+    return bb, nk
+
+
+# ------------------------------------------------------------------ small utilities
+def checksum(t: torch.Tensor, n_samples=64, seed=7):
+    a = t.detach().contiguous().view(-1).to(torch.float64)
+    g = np.random.default_rng(seed)
+    idx = np.sort(g.choice(a.numel(), size=min(n_samples, a.numel()), replace=False))
+    return dict(mean=np.float64(a.mean().item()), l2=np.float64(a.pow(2).sum().sqrt().item()),
+                idx=idx.astype(np.int64), val=t.detach().contiguous().view(-1)[torch.from_numpy(idx)].numpy().copy())
+
+
+def put(d, prefix, cs):
+    for k, v in cs.items():
+        d[f"{prefix}.{k}"] = v
+
+
+def must_equal(name, a: torch.Tensor, b: torch.Tensor):
+    if not torch.equal(a, b):
+        diff = (a - b).abs().max().item()
+        raise SystemExit(f"ORACLE MISMATCH at {name}: max|d|={diff:g}")
+    print(f"  [bit-identical] {name} {tuple(a.shape)}")
+
+
+def load_uni_model(gp, arch, num_prompts, seed):
+    sd_np = W.make_state_dict(arch, seed=seed, num_prompts=num_prompts)
+    model = gp.SimpleYOLOWorldDetector(backbone_size=arch, prompt_dim=768, num_prompts=num_prompts, num_proposals=300)
+    uni = {k: torch.from_numpy(v) for k, v in W.to_uni_keys(sd_np).items()}
+    # BatchNorm num_batches_tracked buffers are not part of the synthetic set.
+    msg = model.load_state_dict(uni, strict=False)
+    missing = [k for k in msg.missing_keys if not k.endswith("num_batches_tracked")]
+    assert not missing and not msg.unexpected_keys, (missing, msg.unexpected_keys)
+    model.eval()
+    return model, sd_np
+
+
+# ------------------------------------------------------------------ cases
+def case_network(gp, arch, b, hw, seed_w=2026, seed_img=1234, num_prompts=256, full_predict=True):
+    """Reference pure-torch copy vs oracle on (arch, b, hw)."""
+    tag = f"{arch}_b{b}_{hw}"
+    print(f"== network case {tag}")
+    model, sd_np = load_uni_model(gp, arch, num_prompts, seed_w)
+    sd = orc.to_torch(sd_np)
+    a = get_arch(arch)
+    imgs = W.make_images(b, hw, hw, seed=seed_img)
+    x = orc.preprocess_u8(imgs)
+
+    fx = dict(arch=arch, b=b, hw=hw, seed_w=seed_w, seed_img=seed_img, num_prompts=num_prompts)
+    c_ref = model.backbone(x)
+    c_orc = orc.backbone(sd, a, x)
+    for i in range(4):
+        must_equal(f"{tag}.c{i+1}", c_ref[i], c_orc[i])
+        put(fx, f"c{i+1}", checksum(c_ref[i].permute(0, 2, 3, 1)))       # NHWC flattening
+    p_ref = model.neck(c_ref)
+    p_orc = orc.neck(sd, a, c_orc)
+    for i in range(3):
+        must_equal(f"{tag}.p{i+3}", p_ref[i], p_orc[i])
+        put(fx, f"p{i+3}", checksum(p_ref[i].permute(0, 2, 3, 1)))
+
+    prompts = sd["embeddings"]
+    for l in range(3):
+        e_ref, bb_ref, lg_ref = model.head_module_forward_single(
+            p_ref[l], model.bbox_head.cls_preds[l], model.bbox_head.reg_preds[l], model.bbox_head.cls_contrasts[l])
+        e_orc, lg_orc, bb_orc = orc.head_level(sd, l, p_orc[l], prompts, normalize_text=False)
+        must_equal(f"{tag}.embed{l}", e_ref, e_orc)
+        must_equal(f"{tag}.logits{l}", lg_ref, lg_orc)
+        must_equal(f"{tag}.bbox{l}", bb_ref, bb_orc)
+        put(fx, f"embed{l}", checksum(e_ref.permute(0, 2, 3, 1)))
+        put(fx, f"logits{l}", checksum(lg_ref.permute(0, 2, 3, 1)))
+        put(fx, f"bbox{l}", checksum(bb_ref.permute(0, 2, 3, 1)))
+
+    # mmdet-path head: YOLOWorldHeadModule.forward with a [B,K,768] text tensor that is
+    # L2-normalised inside BNContrastiveHead (generate_proposal.py:605-623, 716-752 —
+    # the same code as yolo_world_head.py:90-108, 263-294).
+    k_text = 80
+    text = torch.from_numpy(W.make_text_bank(k_text) * np.float32(1.7))     # not unit-norm on purpose
+    text_b = text[None].repeat(b, 1, 1)
+    outs = model.bbox_head(p_ref, text_b)
+    for l in range(3):
+        _, lg_orc, bb_orc = orc.head_level(sd, l, p_orc[l], text_b, normalize_text=True)
+        must_equal(f"{tag}.mm_logits{l}", outs[l][0], lg_orc)
+        must_equal(f"{tag}.mm_bbox{l}", outs[l][1], bb_orc)
+        put(fx, f"mm_logits{l}", checksum(outs[l][0].permute(0, 2, 3, 1)))
+    if full_predict:
+        flat_mm = orc.head_flat(sd, p_orc, text_b, normalize_text=True)
+        for i in range(b):
+            # synthetic letterbox metadata: pad (top,bottom,left,right), scale (w,h), ori (h,w)
+            pad = (8.0, 8.0, 0.0, 0.0) if i % 2 == 0 else (0.0, 0.0, 12.0, 12.0)
+            sf = (0.5, 0.5) if i % 2 == 0 else (0.8, 0.8)
+            ori = (int((hw - 16) / 0.5), int(hw / 0.5)) if i % 2 == 0 else (int(hw / 0.8), int((hw - 24) / 0.8))
+            o = opp.mmdet_predict_image(flat_mm["boxes"][i].numpy(), flat_mm["scores"][i].numpy(), pad, sf, ori)
+            fx[f"mm.img{i}.pad"], fx[f"mm.img{i}.sf"], fx[f"mm.img{i}.ori"] = np.asarray(pad), np.asarray(sf), np.asarray(ori)
+            for key in ("bboxes", "scores", "labels", "anchors"):
+                fx[f"mm.img{i}.{key}"] = o[key]
+            print(f"  mm img{i}: kept {o['scores'].shape[0]}")
+    if full_predict:
+        with stable_sort():
+            res = model.head_predict(p_ref)
+        flat = orc.head_flat(sd, p_orc, prompts, normalize_text=False)
+        ls = np.asarray([sd[HD + f"cls_contrasts.{l}.logit_scale"].item() for l in range(3)], dtype=np.float32)
+        cb = np.asarray([sd[HD + f"cls_contrasts.{l}.bias"].item() for l in range(3)], dtype=np.float32)
+        for i in range(b):
+            o = opp.uni_predict_image(flat["boxes"][i].numpy(), flat["embed"][i].numpy(), flat["scores"][i].numpy(),
+                                      flat["level_of"].numpy(), ls, cb)
+            must_equal(f"{tag}.img{i}.bboxes", res[i]["bboxes"], torch.from_numpy(o["bboxes"]))
+            must_equal(f"{tag}.img{i}.scores", res[i]["scores"], torch.from_numpy(o["scores"]))
+            must_equal(f"{tag}.img{i}.embeddings", res[i]["embeddings"], torch.from_numpy(o["embeddings"]))
+            n = o["scores"].shape[0]
+            gaps = np.diff(o["scores"].astype(np.float64))
+            fx[f"img{i}.bboxes"] = o["bboxes"]
+            fx[f"img{i}.scores"] = o["scores"]
+            fx[f"img{i}.labels"] = o["labels"]
+            fx[f"img{i}.anchors"] = o["anchors"]
+            fx[f"img{i}.embed16"] = o["embeddings"][:, :16].copy()
+            fx[f"img{i}.embed_l2"] = np.linalg.norm(o["embeddings"].astype(np.float64), axis=1)
+            fx[f"img{i}.num_candidates"] = o["num_candidates"]
+            fx[f"img{i}.min_score_gap"] = np.float64(np.min(-gaps)) if n > 1 else np.float64(1.0)
+            print(f"  img{i}: kept {n}, candidates {int(o['num_candidates'])}, min score gap {fx[f'img{i}.min_score_gap']:.3g}")
+    np.savez_compressed(os.path.join(OUT, f"net_{tag}.npz"), **fx)
+
+
+def case_filter_topk(gp):
+    """filter_scores_and_topk: reference (stable sort) vs oracle, incl. ties, empty, truncation."""
+    print("== filter_scores_and_topk cases")
+    g = np.random.default_rng(99)
+    fx = {}
+    cases = {
+        "ties": (np.round(g.random((500, 7), dtype=np.float32) * 20) / 20, 0.3, 1000),
+        "trunc": (g.random((4000, 9), dtype=np.float32), 0.05, 30000),
+        "empty": (g.random((50, 3), dtype=np.float32) * 0.001, 0.5, 100),
+        "all_equal": (np.full((64, 4), 0.5, dtype=np.float32), 0.0, 100),
+    }
+    for name, (sc, thr, topk) in cases.items():
+        with stable_sort():
+            s, lab, keep, _ = gp.filter_scores_and_topk(torch.from_numpy(sc), thr, topk)
+        os_, ol, oa = opp.filter_scores_and_topk(sc, thr, topk)
+        must_equal(f"topk.{name}.scores", s, torch.from_numpy(os_))
+        must_equal(f"topk.{name}.labels", lab, torch.from_numpy(ol))
+        must_equal(f"topk.{name}.anchors", keep, torch.from_numpy(oa))
+        fx[f"{name}.in"] = sc
+        fx[f"{name}.thr"] = np.float32(thr)
+        fx[f"{name}.topk"] = np.int64(topk)
+        fx[f"{name}.scores"] = os_
+        fx[f"{name}.labels"] = ol
+        fx[f"{name}.anchors"] = oa
+    np.savez_compressed(os.path.join(OUT, "filter_topk.npz"), **fx)
+
+
+def case_nms():
+    """Hand-made NMS unit cases for the build-defined semantics (parity unpinned)."""
+    print("== NMS unit cases (oracle-defined)")
+    f = np.float32
+    fx = {}
+    # IoU of [0,0,10,10] vs [0,0,10,7] = 0.7 exactly (not > 0.7 -> both kept);
+    # vs [0,0,10,7.0001] slightly above -> suppressed.
+    boxes = np.array([[0, 0, 10, 10], [0, 0, 10, 7], [0, 0, 10, 7.001], [0, 0, 10, 10], [20, 20, 30, 30],
+                      [20, 20, 30, 30], [5, 5, 5, 5], [5, 5, 5, 5]], dtype=f)
+    scores = np.array([0.9, 0.8, 0.8, 0.7, 0.6, 0.6, 0.5, 0.5], dtype=f)
+    labels = np.array([0, 0, 0, 1, 2, 2, 3, 3], dtype=np.int64)
+    keep = opp.batched_nms(boxes, scores, labels, 0.7)
+    fx["unit.boxes"], fx["unit.scores"], fx["unit.labels"], fx["unit.keep"] = boxes, scores, labels, keep
+    print("  unit keep:", keep.tolist())
+    g = np.random.default_rng(5)
+    n = 3000
+    ctr = g.random((n, 2), dtype=np.float32) * 200
+    wh = g.random((n, 2), dtype=np.float32) * 60 + 4
+    boxes = np.concatenate([ctr - wh / 2, ctr + wh / 2], axis=1).astype(f)
+    scores = np.sort(np.round(g.random(n, dtype=np.float32) * 500) / 500)[::-1].copy()
+    labels = g.integers(0, 5, size=n).astype(np.int64)
+    keep = opp.batched_nms(boxes, scores, labels, 0.7)
+    keep300 = opp.batched_nms(boxes, scores, labels, 0.7, max_keep=300)
+    assert np.array_equal(keep[:300], keep300)
+    fx["rand.boxes"], fx["rand.scores"], fx["rand.labels"], fx["rand.keep"] = boxes, scores, labels, keep
+    fx["empty.keep"] = opp.batched_nms(np.zeros((0, 4), f), np.zeros((0,), f), np.zeros((0,), np.int64), 0.7)
+    print(f"  rand: {n} boxes -> {keep.shape[0]} kept")
+    np.savez_compressed(os.path.join(OUT, "nms.npz"), **fx)
+
+
+def case_retrieval():
+    """retrieval_metric.py:369-375 (module not importable: argparse + file IO at import);
+    its five tensor lines are executed here verbatim-in-meaning with torch and compared."""
+    print("== retrieval similarity cases")
+    fx = {}
+    g = np.random.default_rng(11)
+    for k in (80, 81, 256, 1203):
+        e = W.make_regions(300, seed=11 + k)          # regenerated from the seed by the tests
+        t = W.make_text_bank(k)
+        scale = g.choice(np.array([-0.35, -0.55, -0.2], dtype=np.float32), size=300)
+        bias = g.choice(np.array([-2.6, -2.2, -1.9], dtype=np.float32), size=300)
+        et, tt = torch.from_numpy(e), torch.from_numpy(t)
+        cls_logits = torch.einsum('bw,kw->bk', et, tt)
+        cls_logits = torch.sigmoid(cls_logits * torch.from_numpy(scale).exp().unsqueeze(1)
+                                   + torch.from_numpy(bias).unsqueeze(1))
+        ref = torch.max(cls_logits, dim=0)[0]
+        must_equal(f"retrieval.k{k}", ref, torch.from_numpy(opp.retrieval_scores(e, t, scale, bias)))
+        fx[f"k{k}.seed_embed"] = np.int64(11 + k)
+        fx[f"k{k}.embed_head"] = e[:4, :8].copy()
+        fx[f"k{k}.scale"], fx[f"k{k}.bias"] = scale, bias
+        fx[f"k{k}.max_scores"] = ref.numpy()
+    np.savez_compressed(os.path.join(OUT, "retrieval.npz"), **fx)
+
+
+def case_mmdet_modules(arch="tiny", hw=64):
+    """wedetect/models plugin classes (Tiny exists only there): backbone + neck vs oracle."""
+    print(f"== mmdet-plugin modules, {arch} @ {hw}")
+    bbm, nkm = import_wedetect_models()
+    a = get_arch(arch)
+    sd_np = W.make_state_dict(arch, seed=2026)
+    sd = orc.to_torch(sd_np)
+    vis = bbm.ConvNextVisionBackbone(model_name=arch)
+    vis_sd = {k[len("backbone.image_model."):]: torch.from_numpy(v) for k, v in sd_np.items()
+              if k.startswith("backbone.image_model.")}
+    msg = vis.load_state_dict(vis_sd, strict=False)
+    assert not msg.unexpected_keys, msg.unexpected_keys
+    assert all(k.startswith(("model.norm.", "model.head.")) for k in msg.missing_keys), msg.missing_keys
+    neck = nkm.CSPRepBiFPANNeck(scale_factor=a.neck_scale, model_size=arch)
+    nk_sd = {k[len("neck."):]: torch.from_numpy(v) for k, v in sd_np.items() if k.startswith("neck.")}
+    msg = neck.load_state_dict(nk_sd, strict=False)
+    assert not msg.unexpected_keys and all(k.endswith("num_batches_tracked") for k in msg.missing_keys), msg
+    torch.nn.Module.eval(vis)
+    torch.nn.Module.eval(neck)
+    for m in list(vis.modules()) + list(neck.modules()):
+        m.training = False
+    imgs = W.make_images(1, hw, hw, seed=1234)
+    x = orc.preprocess_u8(imgs)
+    c_ref = vis(x)
+    c_orc = orc.backbone(sd, a, x)
+    fx = dict(arch=arch, b=1, hw=hw, seed_w=2026, seed_img=1234)
+    for i in range(4):
+        must_equal(f"mm.{arch}.c{i+1}", c_ref[i], c_orc[i])
+        put(fx, f"c{i+1}", checksum(c_ref[i].permute(0, 2, 3, 1)))
+    p_ref = neck(c_ref)
+    p_orc = orc.neck(sd, a, c_orc)
+    for i in range(3):
+        must_equal(f"mm.{arch}.p{i+3}", p_ref[i], p_orc[i])
+        put(fx, f"p{i+3}", checksum(p_ref[i].permute(0, 2, 3, 1)))
+    np.savez_compressed(os.path.join(OUT, f"mm_{arch}_b1_{hw}.npz"), **fx)
+
+
+if __name__ == "__main__":
+    assert os.path.isdir(REF), "reference tree not present: goldens can only be generated in the build container"
+    # transformers probes torchvision at import: the plugin files (which import it) must be
+    # loaded BEFORE the bare torchvision stand-in goes into sys.modules
+    case_mmdet_modules("tiny", 64)
+    gp = import_generate_proposal()
+    case_filter_topk(gp)
+    case_nms()
+    case_retrieval()
+    case_network(gp, "base", 1, 64)
+    case_network(gp, "base", 2, 128)
+    case_network(gp, "base", 1, 640)
+    case_network(gp, "large", 1, 64, full_predict=False)
+    print("all golden fixtures written to", OUT)
