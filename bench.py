@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py — images/s of the WeDetect hot path on MI355X (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched under torch.distributed.run, one rank per GPU, RCCL backend)
+
+One step = one pass of the hot path over one batch of synthetic images already resident in
+HBM as uint8 NHWC: ConvNeXt-Base tower + CSPRepBiFPAN neck + YOLO-World head (region
+embeddings, DFL boxes) -> L2-normalised 80-class text bank similarity GEMM (+ per-level
+scale/bias + sigmoid) -> score filter (> 0.001) / top-30000 / sort -> class-aware NMS (0.7)
+-> <= 300 detections + their 768-d embeddings per image, all on device.  At N > 1 every
+rank runs that on its own batch (images shard with no data-path collective) and the
+kept-region embeddings are exchanged with one all_gather_into_tensor per step (the
+retrieval gather, extract_embedding.py:1753-1756).  Weights/images/text are seeded
+synthetic (no checkpoints or datasets offline).
+
+Prints ONE JSON line (rank 0) with the driver's contract plus:
+  roofline      — the dominant kernel (128x128 fp32-MFMA GEMM that runs the ConvNeXt MLPs),
+                  algorithmic flops / HIP-event time of its launches inside the timed steps
+  sim_gemm      — the judged region x text similarity GEMM, same accounting
+  cpu_baseline  — the CPU oracle (port of the reference's PyTorch-CPU path) on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--arch", default="base")
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--classes", type=int, default=80)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-images", type=int, default=2)
+    return ap.parse_args()
+
+
+class GemmTimer:
+    """HIP-event brackets around selected wd_conv_gemm launches on the launch stream."""
+
+    def __init__(self, lib):
+        self.lib = lib
+        self.rec = {}          # tag -> list of (start, end, flops)
+        self.on = False
+        self._orig = lib.conv_gemm
+
+    def install(self):
+        orig, rec, lib = self._orig, self.rec, self.lib
+
+        def wrapped(a, w, bias, c, **kw):
+            if not self.on:
+                return orig(a, w, bias, c, **kw)
+            kh, kw_ = kw.get("kh", 1), kw.get("kw", 1)
+            hin, win, stride, pad = kw["hin"], kw["win"], kw.get("stride", 1), kw.get("pad", 0)
+            hout = (hin + 2 * pad - kh) // stride + 1
+            wout = (win + 2 * pad - kw_) // stride + 1
+            m, n, k = kw["batch"] * hout * wout, kw["n"], kh * kw_ * kw["cin"]
+            plain = kh == 1 and kw_ == 1 and stride == 1 and pad == 0
+            tag = lib.gemm_config(m, n, k) + ("/plain" if plain else "/conv")
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            orig(a, w, bias, c, **kw)
+            e.record()
+            rec.setdefault(tag, []).append((s, e, 2.0 * m * n * k))
+        lib.conv_gemm = wrapped
+
+    def summary(self):
+        out = {}
+        for tag, lst in self.rec.items():
+            ms = sum(s.elapsed_time(e) for s, e, _ in lst)
+            fl = sum(f for _, _, f in lst)
+            out[tag] = dict(launches=len(lst), ms_total=ms, flops_total=fl,
+                            avg_us=1e3 * ms / len(lst), tflops=fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0)
+        return out
+
+
+def cpu_baseline(arch, size, classes, n_images):
+    """The oracle (CPU port of the reference's PyTorch path) on a bounded sample: n_images
+    single-image passes of the same workload, all host cores."""
+    from oracle import postprocess as opp
+    from oracle import ref_cpu as orc
+    from wedetect_amd import weights as W
+    from wedetect_amd.arch import get_arch
+    torch.set_num_threads(os.cpu_count() or 1)
+    a = get_arch(arch)
+    sd = orc.to_torch(W.make_state_dict(arch))
+    text = torch.from_numpy(W.make_text_bank(classes))
+    imgs = W.make_images(n_images + 1, size, size)
+    times = []
+    with torch.no_grad():
+        for i in range(n_images + 1):
+            t0 = time.perf_counter()
+            _, p = orc.forward_features(sd, a, imgs[i:i + 1])
+            flat = orc.head_flat(sd, p, text, normalize_text=True)
+            opp.mmdet_predict_image(flat["boxes"][0].numpy(), flat["scores"][0].numpy(), None, (1.0, 1.0), (size, size))
+            times.append(time.perf_counter() - t0)
+    t = float(np.mean(times[1:]))      # first pass = warm-up
+    return dict(value=round(1.0 / t, 4), unit="images/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n_images} single-image passes of the same {arch}@{size} K={classes} path "
+                       f"(oracle/ref_cpu.py + oracle/postprocess.py, fp32, torch {torch.__version__}) after 1 warm-up")
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE {world}")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+
+    from wedetect_amd import lib as L
+    from wedetect_amd import weights as W
+    from wedetect_amd.engine import ImageTower
+    from wedetect_amd.pack import pack
+    from wedetect_amd.parallel import gather_regions
+
+    B, S, K = args.batch, args.size, args.classes
+    tower = ImageTower(args.arch, pack(W.make_state_dict(args.arch), args.arch), B, S, S, max_classes=K)
+    images = torch.from_numpy(W.make_images(B, S, S, seed=1234 + rank)).cuda()
+    text = torch.from_numpy(W.make_text_bank(K)).cuda()
+    meta = tower.identity_meta()
+    meta[:, 7] = 1.0                        # mmdet order: rescale before NMS
+    timer = GemmTimer(L)
+    timer.install()
+
+    def step():
+        res = tower.detect(images, text, meta, normalize_text=True, score_thr=0.001, with_embed=True)
+        if world > 1:
+            gather_regions(res["embeddings"], res["count"])
+        return res
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    timer.on = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    sync()
+    dt = time.perf_counter() - t0
+    timer.on = False
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kept = int(res["count"].sum().item())
+
+    if rank == 0:
+        summ = timer.summary()
+        dom_tag = max(summ, key=lambda k: summ[k]["flops_total"])
+        dom = summ[dom_tag]
+        sim_tag = L.gemm_config(B * tower.ntot, K, 768) + "/plain"
+        sim = summ.get(sim_tag)
+        flops_img = sum(v["flops_total"] for v in summ.values()) / (args.steps * B)
+        out = {
+            "metric": "images/s at 640x640 (WeDetect-Base image tower + 80-class similarity + top-k/NMS)",
+            "value": round(world * B * args.steps / dt, 3),
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"WeDetect-{args.arch.capitalize()}, batch {B}x{S}x{S} per GPU, {K}-class similarity, "
+                                   f"thr 0.001 / nms_pre 30000 / NMS 0.7 / 300 per image (BASELINE.json configs[1])",
+                       "global_batch": world * B, "per_gpu_batch": B, "image": [S, S], "classes": K,
+                       "parallelism": f"image-shard x{world}" + (" + all-gather of kept-region embeddings" if world > 1 else ""),
+                       "kept_regions_last_step_rank0": kept,
+                       "gemm_gflop_per_image": round(flops_img / 1e9, 2)},
+            "roofline": {"kernel": f"conv_gemm_kernel<{dom_tag}> (fp32 MFMA 16x16x4)", "bound": "mfma",
+                         "achieved": round(dom["tflops"], 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(dom["tflops"] / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "launches_per_step": dom["launches"] // args.steps, "avg_launch_us": round(dom["avg_us"], 2),
+                         "algorithmic_gflop_per_launch": round(dom["flops_total"] / dom["launches"] / 1e9, 3)},
+            "gemm_kernels": {k: {"launches_per_step": v["launches"] // args.steps, "avg_us": round(v["avg_us"], 2),
+                                 "tflops": round(v["tflops"], 2)} for k, v in sorted(summ.items())},
+        }
+        if sim is not None:
+            out["sim_gemm"] = {"kernel": f"conv_gemm_kernel<{sim_tag}>", "m": B * tower.ntot, "n": K, "k": 768,
+                               "achieved": round(sim["tflops"], 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(sim["tflops"] / F32_MFMA_PEAK_TFLOPS, 4), "avg_launch_us": round(sim["avg_us"], 2)}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.arch, S, K, args.cpu_images)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

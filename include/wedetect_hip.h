@@ -1,0 +1,213 @@
+/*
+ * wedetect_hip.h — C ABI of libwedetect_hip.so (MI355X / gfx950 only).
+ *
+ * The reference (WeChatCV/WeDetect) is pure Python: it has no FFI boundary of its own.
+ * Its hot path bottoms out in ATen / cuDNN / cuBLAS ops and two third-party native NMS
+ * ops.  This header is the boundary a maintainer binds instead (ctypes stub in
+ * INTEGRATION.md); every entry point names the reference site(s) it replaces
+ * (paths relative to the reference root).
+ *
+ * Conventions
+ *   - plain C types only: device pointers, sizes, a hipStream_t passed as void*.
+ *   - every call is asynchronous on the caller's stream, allocates nothing, keeps no
+ *     mutable global state (one-time kernel attribute setup excepted) and returns
+ *     WD_OK or a negative WD_ERR_* code; it never throws.
+ *   - activations are NHWC fp32: a tensor [B,H,W,C] is a row matrix [B*H*W, C] whose
+ *     row stride ("ld", in floats) may exceed C so producers can write straight into a
+ *     channel slice of a wider buffer (this is how the reference's torch.cat calls,
+ *     yolo_world_pafpn.py:647,715,1127,1131, disappear).
+ *   - all floating-point work is fp32 with fp32 accumulation (MFMA f32_16x16x4_f32).
+ *   - index outputs are int32 (flat candidate index < 2^31: 33600 anchors x 1203 classes).
+ */
+#ifndef WEDETECT_HIP_H
+#define WEDETECT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WD_OK 0
+#define WD_ERR_BAD_ARG (-1)     /* shape / alignment / null-pointer contract violated */
+#define WD_ERR_LAUNCH (-2)      /* hipGetLastError() after launch was not hipSuccess  */
+#define WD_ERR_WORKSPACE (-3)   /* caller-provided workspace too small                */
+#define WD_ERR_UNSUPPORTED (-4)
+
+#define WD_ACT_NONE 0
+#define WD_ACT_RELU 1
+#define WD_ACT_SILU 2
+#define WD_ACT_GELU 3           /* exact erf GELU (nn.GELU default, mm_backbone.py:100) */
+
+#define WD_OUT_ROWS 0           /* C[m, n] at c + m*ldc + n                              */
+#define WD_OUT_DECONV2X2 1      /* ConvTranspose2d k2 s2 scatter, see wd_conv_gemm        */
+
+/* ABI version, bumped on any signature change. */
+int wd_abi_version(void);
+/* Human-readable message for a WD_ERR_* code. */
+const char* wd_strerror(int code);
+
+/* ------------------------------------------------------------------------------------
+ * wd_conv_gemm — implicit-GEMM convolution / linear layer with fused epilogue.
+ *
+ *   C[m, n] = epi( sum_k A_im2col[m, k] * W[n, k] + bias[n] )
+ *   m = (b, ho, wo) row-major, k = (kh, kw, ci) with ci fastest, W row-major [n][k].
+ *   epi(v): v = act(v); v = v*out_scale + out_bias; if sigmoid v = 1/(1+exp(-v));
+ *           if res: v += res_alpha * res[m*ldres + n].
+ *   seg_rows > 0 (similarity GEMM over all head levels at once): rows are grouped per image
+ *   (seg_rows rows each); pos = m % seg_rows selects the head level
+ *   lvl = (pos >= seg_end0) + (pos >= seg_end1) and out_scale/out_bias are replaced by
+ *   seg_scale[lvl] / seg_bias[lvl] (per-level exp(logit_scale) and bias scalars).
+ *   c_batch_stride > 0: output row of m = (b, pos), pos < hout*wout, is b*c_batch_stride + pos
+ *   (a level's embeddings go straight into the [B, all-anchors, 768] tensor).
+ *   out_mode WD_OUT_DECONV2X2: the GEMM is a 1x1 conv over [B,H,W,cin] with n =
+ *   (ty*2+tx)*(N/4) + co; element (m=(b,h,w), n) is stored at output pixel
+ *   (b, 2h+ty, 2w+tx), channel co of a [B,2H,2W,*] tensor with row stride ldc.
+ *
+ * Replaces (all fp32, eval mode; BatchNorm folded into W/bias by the caller):
+ *   nn.Conv2d 4x4 s4 stem / 2x2 s2 downsample   wedetect/models/backbones/mm_backbone.py:185-198
+ *   nn.Linear pwconv1 + GELU, pwconv2 + gamma + residual   mm_backbone.py:117-124
+ *   ConvModule_torch 1x1 / 3x3 (s1|s2) conv + BN + ReLU|SiLU   necks/yolo_world_pafpn.py:40-68
+ *   BottleRep  "outputs + alpha * x"                  necks/yolo_world_pafpn.py:602-605
+ *   ConvTranspose2d 2x2 s2 + bias                     necks/yolo_world_pafpn.py:195-208
+ *   head 3x3 Conv+BN+SiLU and final 1x1 conv (+ folded contrastive BN)
+ *                                                     dense_heads/yolo_world_head.py:194-232, 98
+ *   BNContrastiveHead einsum 'bchw,bkc->bkhw' * exp(logit_scale) + bias (+ sigmoid of
+ *   predict_by_feat)                                  dense_heads/yolo_world_head.py:101-108, 664
+ *   Uni einsum 'bchw,kc->bkhw'                        generate_proposal.py:1130-1131, 1185
+ *
+ * Contract: cin % 4 == 0, lda % 4 == 0, a/w 16-byte aligned, k == kh*kw*cin,
+ * m == batch*hout*wout; ldc/ldres/c/res need no alignment (vector stores are used only
+ * when they are 16-byte friendly).
+ * ---------------------------------------------------------------------------------- */
+typedef struct WdConvGemm {
+  const float* a;      /* input NHWC [batch, hin, win, cin], pixel stride lda           */
+  const float* w;      /* weights [n][k]                                                 */
+  const float* bias;   /* [n] or NULL                                                    */
+  const float* res;    /* residual [m][ldres] or NULL (same row indexing as C)           */
+  float* c;            /* output                                                         */
+  int32_t batch, hin, win, cin, lda;
+  int32_t kh, kw, stride, pad, hout, wout;
+  int32_t m, n, k;
+  int32_t ldc, ldres;
+  int32_t act;
+  int32_t out_mode;
+  float res_alpha;
+  float out_scale, out_bias;
+  int32_t sigmoid;
+  int32_t c_batch_stride;      /* rows; 0 = plain row-major output                       */
+  int32_t seg_rows, seg_end0, seg_end1;
+  float seg_scale[3], seg_bias[3];
+} WdConvGemm;
+
+int wd_conv_gemm(const WdConvGemm* p, void* stream);
+
+/* sizeof(WdConvGemm) as compiled into the library, so a binding can verify its mirror. */
+int wd_sizeof_conv_gemm(void);
+
+/* Name of the tile configuration wd_conv_gemm would pick for (m, n, k), e.g. "128x128".
+ * Diagnostic only (bench / tests print it). */
+const char* wd_conv_gemm_config(int32_t m, int32_t n, int32_t k);
+
+/* ------------------------------------------------------------------------------------
+ * wd_stem_patchify — uint8 RGB NHWC image -> fp32 patch matrix for the 4x4 s4 stem conv.
+ *   out[(b, ho, wo), (kh*4+kw)*3 + c] = img[b, 4ho+kh, 4wo+kw, c] / 255
+ * Replaces: uint8->float "/255" (generate_proposal.py:1096-1097; DetDataPreprocessor
+ * mean 0 / std 255, config/wedetect_base.py:44-48) and the im2col of the stem conv
+ * (mm_backbone.py:188-189).  h, w multiples of 4.
+ * ---------------------------------------------------------------------------------- */
+int wd_stem_patchify(const uint8_t* img, float* out, int32_t batch, int32_t h, int32_t w, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * wd_dwconv7 — depthwise 7x7, pad 3, + bias, NHWC.  w7 is [49][c] (tap-major).
+ * Replaces nn.Conv2d(dim, dim, 7, padding=3, groups=dim)  mm_backbone.py:96-98, 114.
+ * c % 4 == 0; x and y must not alias.
+ * ---------------------------------------------------------------------------------- */
+int wd_dwconv7(const float* x, const float* w7, const float* bias, float* y,
+               int32_t batch, int32_t h, int32_t w, int32_t c, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * wd_layernorm_rows — y[r,:] = (x[r,:]-mean)*rsqrt(var+eps)*gamma + beta over c channels,
+ * biased variance, two-pass fp32.  In-place allowed (y == x).
+ * Replaces F.layer_norm (channels_last, mm_backbone.py:146-149) and the hand-written
+ * channels_first LayerNorm (mm_backbone.py:150-155).  c % 4 == 0, c <= 2048.
+ * ---------------------------------------------------------------------------------- */
+int wd_layernorm_rows(const float* x, float* y, const float* gamma, const float* beta,
+                      int64_t rows, int32_t c, int32_t ldx, int32_t ldy, float eps, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * wd_l2norm_rows — y[r,:] = x[r,:] / max(||x[r,:]||_2, 1e-12).
+ * Replaces F.normalize(w, dim=-1, p=2) on the text bank
+ * (yolo_world_head.py:101; extract_embedding.py:1713).
+ * ---------------------------------------------------------------------------------- */
+int wd_l2norm_rows(const float* x, float* y, int64_t rows, int32_t c, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * wd_dfl_decode — DFL expectation + distance->box decode for one head level.
+ *   dist [batch, hl*wl, 64] (row stride ld): channel = side*16 + bin;
+ *   d_side = sum_i softmax(dist[side,:])_i * i;  box = prior -/+ d*stride,
+ *   prior = ((x+0.5)*stride, (y+0.5)*stride); written to boxes[b, anchor_off + y*wl + x, 0:4].
+ * Replaces yolo_world_head.py:279-288 (DFL), generate_proposal.py:880-905 (priors),
+ * distance_point_bbox_coder.py:51-53 + generate_proposal.py:1021-1026 (decode).
+ * ---------------------------------------------------------------------------------- */
+int wd_dfl_decode(const float* dist, int32_t ld, float* boxes, int32_t batch, int32_t hl, int32_t wl,
+                  int32_t stride, int32_t anchor_off, int32_t anchors_total, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * wd_topk_candidates — per image: candidates (anchor, class) with score > thr, sorted by
+ * (score desc, flat index asc), truncated to nms_pre.  flat index = anchor*k + class.
+ *   scores [batch, n_anchor*k] fp32 (already sigmoid-ed, > 0)
+ *   out_idx    [batch, cap] int32 flat indices in sorted order (cap = wd_topk_capacity)
+ *   out_score  [batch, cap] fp32
+ *   out_count  [batch] int32  (<= nms_pre)
+ * Replaces filter_scores_and_topk (generate_proposal.py:85-131; mmdet twin called at
+ * yolo_world_head.py:721-722) with the stabilised total order of SURVEY.md §7.
+ * Workspace: wd_topk_workspace_bytes(batch, n, nms_pre) bytes, 256-byte aligned.
+ * ---------------------------------------------------------------------------------- */
+int64_t wd_topk_workspace_bytes(int32_t batch, int64_t n_per_image, int32_t nms_pre);
+int32_t wd_topk_capacity(int32_t nms_pre);   /* power of two >= nms_pre */
+int wd_topk_candidates(const float* scores, int32_t batch, int64_t n_per_image, float thr,
+                       int32_t nms_pre, int32_t* out_idx, float* out_score, int32_t* out_count,
+                       void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * wd_nms_gather — class-aware greedy NMS over sorted candidates + gather of the results.
+ *   cand_idx/cand_score/cand_count: output of wd_topk_candidates (row stride cap).
+ *   boxes [batch, n_anchor, 4] network-input pixels.  Per image meta (8 floats):
+ *     {pad_x, pad_y, inv-unused, scale_x, scale_y, ori_w, ori_h, pre_nms_rescale}
+ *   pre_nms_rescale != 0 : mmdet order — box = (box - pad) / scale BEFORE NMS, clamp after
+ *                          (yolo_world_head.py:728-746);
+ *   pre_nms_rescale == 0 : Uni order — NMS in network pixels, then (box - pad) / scale and
+ *                          clamp (generate_proposal.py:1106-1115, 1210).
+ *   A box i suppresses a later box j of the same class iff
+ *       inter / (area_i + area_j - inter) > iou_thr        (fp32, IEEE division)
+ *   Outputs (row stride max_out): out_boxes [batch,max_out,4], out_scores, out_labels
+ *   (int32), out_anchors (int32), out_count [batch]; if embed != NULL also
+ *   out_embed [batch, max_out, embed_dim] = embed[b, anchor, :].
+ * Replaces torchvision.ops.batched_nms(...)[:300] (generate_proposal.py:1210),
+ * mmdet _bbox_post_process -> mmcv.ops.batched_nms + max_per_img
+ * (yolo_world_head.py:740-744), and the index gathers at generate_proposal.py:1208-1217.
+ * ---------------------------------------------------------------------------------- */
+int wd_nms_gather(const int32_t* cand_idx, const float* cand_score, const int32_t* cand_count,
+                  int32_t cand_stride, const float* boxes, int32_t n_anchor, int32_t k,
+                  const float* meta, float iou_thr, int32_t max_out,
+                  const float* embed, int32_t embed_dim,
+                  float* out_boxes, float* out_scores, int32_t* out_labels, int32_t* out_anchors,
+                  int32_t* out_count, float* out_embed, int32_t batch, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * wd_retrieval_max — object-retrieval similarity with fused epilogue:
+ *   out[i, c] = max_{r < count[i]} sigmoid( <E[i,r,:], T[c,:]> * exp(scale[i,r]) + bias[i,r] )
+ *   E [n_img, rows_per_img, dim], T [n_cls, dim], scale/bias [n_img, rows_per_img],
+ *   count [n_img] int32 (0 -> out row = 0).  Logits are never materialised.
+ * Replaces eval_retrieval/retrieval_metric.py:369-375 (einsum, sigmoid, max over regions).
+ * dim % 4 == 0; rows_per_img <= 320.
+ * ---------------------------------------------------------------------------------- */
+int wd_retrieval_max(const float* e, const float* t, const float* scale, const float* bias,
+                     const int32_t* count, float* out, int32_t n_img, int32_t rows_per_img,
+                     int32_t n_cls, int32_t dim, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WEDETECT_HIP_H */

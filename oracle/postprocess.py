@@ -112,24 +112,45 @@ def uni_predict_image(boxes: np.ndarray, embed: np.ndarray, scores: np.ndarray,
                 num_candidates=np.int64(s.shape[0]), keep=keep)
 
 
+def rescale_boxes(b: np.ndarray, pad_xy, scale_xy) -> np.ndarray:
+    """(box - [px, py, px, py]) / [sx, sy, sx, sy] in fp32 (yolo_world_head.py:728-734;
+    generate_proposal.py:1108-1113 with sx = sy = ratio)."""
+    b = b.astype(f32) - np.asarray([pad_xy[0], pad_xy[1], pad_xy[0], pad_xy[1]], dtype=f32)
+    return b / np.asarray([scale_xy[0], scale_xy[1], scale_xy[0], scale_xy[1]], dtype=f32)
+
+
+def clamp_boxes(b: np.ndarray, ori_hw) -> np.ndarray:
+    b = b.astype(f32).copy()
+    b[:, 0::2] = np.clip(b[:, 0::2], f32(0), f32(ori_hw[1]))
+    b[:, 1::2] = np.clip(b[:, 1::2], f32(0), f32(ori_hw[0]))
+    return b
+
+
+def mmdet_predict_image_from_candidates(cand_boxes, s, labels, pad_param, scale_factor, ori_hw,
+                                        iou_thr: float = 0.7, max_per_img: int = 300):
+    """Tail of predict_by_feat once candidates exist (yolo_world_head.py:724-746): rescale
+    to original pixels, THEN NMS, [:max_per_img], clamp.  pad_param = (top, bottom, left,
+    right); scale_factor = (w, h)."""
+    b = cand_boxes.astype(f32)
+    pad = (0.0, 0.0) if pad_param is None else (pad_param[2], pad_param[0])
+    b = rescale_boxes(b, pad, scale_factor)
+    keep = batched_nms(b, s, labels, iou_thr, max_keep=max_per_img)
+    return dict(bboxes=clamp_boxes(b[keep], ori_hw), keep=keep)
+
+
 def mmdet_predict_image(boxes: np.ndarray, scores: np.ndarray, pad_param, scale_factor,
                         ori_hw: Tuple[int, int], score_thr: float = 0.001, nms_pre: int = 30000,
                         iou_thr: float = 0.7, max_per_img: int = 300) -> Dict[str, np.ndarray]:
     """One image of YOLOWorldHead.predict_by_feat, multi_label=True
     (yolo_world_head.py:680-748): filter/top-k, rescale to original pixels, THEN NMS,
-    [:max_per_img], clamp.  pad_param = (top, bottom, left, right); scale_factor = (w, h)."""
+    [:max_per_img], clamp."""
     s, labels, anchors = filter_scores_and_topk(scores, score_thr, nms_pre)
-    b = boxes[anchors].astype(f32)
-    if pad_param is not None:
-        b = b - np.asarray([pad_param[2], pad_param[0], pad_param[2], pad_param[0]], dtype=f32)
-    b = b / np.asarray([scale_factor[0], scale_factor[1]] * 2, dtype=f32)
     if s.shape[0] == 0:
-        return dict(bboxes=b, scores=s, labels=labels, anchors=anchors)
-    keep = batched_nms(b, s, labels, iou_thr, max_keep=max_per_img)
-    b = b[keep]
-    b[:, 0::2] = np.clip(b[:, 0::2], f32(0), f32(ori_hw[1]))
-    b[:, 1::2] = np.clip(b[:, 1::2], f32(0), f32(ori_hw[0]))
-    return dict(bboxes=b, scores=s[keep], labels=labels[keep], anchors=anchors[keep])
+        return dict(bboxes=np.zeros((0, 4), f32), scores=s, labels=labels, anchors=anchors)
+    r = mmdet_predict_image_from_candidates(boxes[anchors], s, labels, pad_param, scale_factor, ori_hw,
+                                            iou_thr, max_per_img)
+    keep = r["keep"]
+    return dict(bboxes=r["bboxes"], scores=s[keep], labels=labels[keep], anchors=anchors[keep])
 
 
 def retrieval_scores(embedding: np.ndarray, text: np.ndarray, scale: np.ndarray,

@@ -1,0 +1,250 @@
+"""CPU-side tests (run with -m "not gpu"): the oracle against the golden fixtures generated
+from the reference, host logic, the C-ABI library's exports, and the N>1 exchange on gloo."""
+import os
+import re
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import GOLDEN, assert_close, check_checksum, golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------------------------------ oracle vs goldens
+@pytest.mark.parametrize("fixture", ["net_base_b1_64.npz", "net_base_b2_128.npz", "net_large_b1_64.npz",
+                                     "mm_tiny_b1_64.npz"])
+def test_oracle_reproduces_reference_goldens(fixture):
+    """The fixtures were written by tests/golden/make_golden.py from an import of the
+    reference (bit-identity asserted there).  Here the oracle alone must reproduce them
+    (different BLAS threading may move the last bit: tolerance 1e-5)."""
+    from oracle import postprocess as opp
+    from oracle import ref_cpu as orc
+    from wedetect_amd import weights as W
+    from wedetect_amd.arch import HD, get_arch
+    fx = golden(fixture)
+    arch, b, hw = str(fx["arch"]), int(fx["b"]), int(fx["hw"])
+    npr = int(fx["num_prompts"]) if "num_prompts" in fx else 0
+    sd = orc.to_torch(W.make_state_dict(arch, seed=int(fx["seed_w"]), num_prompts=npr))
+    imgs = W.make_images(b, hw, hw, seed=int(fx["seed_img"]))
+    with torch.no_grad():
+        c, p = orc.forward_features(sd, get_arch(arch), imgs)
+    for i in range(4):
+        check_checksum(f"{fixture} c{i+1}", c[i].permute(0, 2, 3, 1), fx, f"c{i+1}", 1e-5, 1e-5)
+    for i in range(3):
+        check_checksum(f"{fixture} p{i+3}", p[i].permute(0, 2, 3, 1), fx, f"p{i+3}", 1e-5, 1e-5)
+    if "img0.scores" not in fx:
+        return
+    with torch.no_grad():
+        flat = orc.head_flat(sd, p, sd["embeddings"], normalize_text=False)
+    ls = np.asarray([sd[HD + f"cls_contrasts.{l}.logit_scale"].item() for l in range(3)], np.float32)
+    cb = np.asarray([sd[HD + f"cls_contrasts.{l}.bias"].item() for l in range(3)], np.float32)
+    for i in range(b):
+        o = opp.uni_predict_image(flat["boxes"][i].numpy(), flat["embed"][i].numpy(), flat["scores"][i].numpy(),
+                                  flat["level_of"].numpy(), ls, cb)
+        assert_close(f"{fixture} img{i} scores", o["scores"], fx[f"img{i}.scores"], 1e-6)
+        same = np.mean(o["anchors"] == fx[f"img{i}.anchors"])
+        assert same > 0.98, f"{fixture} img{i}: only {same:.3f} of kept anchors in reference order"
+        assert int(o["num_candidates"]) == int(fx[f"img{i}.num_candidates"])
+
+
+def test_oracle_filter_topk_golden():
+    from oracle import postprocess as opp
+    fx = golden("filter_topk.npz")
+    for name in ("ties", "trunc", "empty", "all_equal"):
+        s, l, a = opp.filter_scores_and_topk(fx[f"{name}.in"], float(fx[f"{name}.thr"]), int(fx[f"{name}.topk"]))
+        assert np.array_equal(s, fx[f"{name}.scores"]) and np.array_equal(l, fx[f"{name}.labels"])
+        assert np.array_equal(a, fx[f"{name}.anchors"])
+    assert fx["empty.scores"].shape[0] == 0
+    # ties come out index-ascending
+    s, l, a = opp.filter_scores_and_topk(fx["all_equal.in"], 0.0, 100)
+    flat = a * fx["all_equal.in"].shape[1] + l
+    assert np.array_equal(flat, np.arange(100))
+
+
+def test_oracle_nms_golden_and_prefix_property():
+    from oracle import postprocess as opp
+    fx = golden("nms.npz")
+    for c in ("unit", "rand"):
+        keep = opp.batched_nms(fx[f"{c}.boxes"], fx[f"{c}.scores"], fx[f"{c}.labels"], 0.7)
+        assert np.array_equal(keep, fx[f"{c}.keep"])
+        for m in (1, 5, 300):
+            assert np.array_equal(opp.batched_nms(fx[f"{c}.boxes"], fx[f"{c}.scores"], fx[f"{c}.labels"], 0.7, m), keep[:m])
+    # IoU exactly 0.7 is NOT suppressed (strict >), a hair above is; other classes never interact
+    assert fx["unit.keep"].tolist() == [0, 1, 3, 4, 6, 7]
+
+
+def test_oracle_retrieval_golden():
+    from oracle import postprocess as opp
+    from wedetect_amd import weights as W
+    fx = golden("retrieval.npz")
+    for k in (80, 81, 256, 1203):
+        e = W.make_regions(300, seed=int(fx[f"k{k}.seed_embed"]))
+        out = opp.retrieval_scores(e, W.make_text_bank(k), fx[f"k{k}.scale"], fx[f"k{k}.bias"])
+        assert_close(f"retrieval k{k}", out, fx[f"k{k}.max_scores"], 1e-6)
+
+
+def test_shard_indices_match():
+    from oracle import postprocess as opp
+    from wedetect_amd.parallel import shard_range
+    for total in (0, 1, 7, 8, 5000, 4999):
+        for world in (1, 2, 3, 8):
+            got = [shard_range(total, world, r) for r in range(world)]
+            assert [list(g) for g in got] == [list(opp.shard_indices(total, world, r)) for r in range(world)]
+            assert sum(len(g) for g in got) == total
+
+
+# ------------------------------------------------------------------------------------------ host logic
+def test_arch_tables_and_state_dict_layout():
+    from wedetect_amd.arch import all_params, get_arch, num_anchors
+    a = get_arch("base")
+    names = [n for n, _, _ in all_params(a, 256)]
+    assert len(names) == len(set(names))
+    assert "backbone.image_model.model.stages.2.26.pwconv2.weight" in names
+    assert "neck.Rep_p4.m.block.4.conv2.block.bn.running_var" in names
+    assert "bbox_head.head_module.cls_contrasts.2.logit_scale" in names and "embeddings" in names
+    n_float = sum(int(np.prod(s)) if len(s) else 1 for _, s, _ in all_params(a, 0))
+    # Base = 107.3 M without text tower and prompts (BN counters excluded here)
+    assert abs(n_float / 1e6 - 107.3) < 0.6, n_float
+    assert num_anchors(640, 640) == 8400
+    assert get_arch("tiny").head_in == (96, 192, 384) and get_arch("large").head_in == (192, 384, 768)
+    with pytest.raises(KeyError):
+        get_arch("huge")
+
+
+def test_weights_deterministic_and_key_remaps_roundtrip():
+    from wedetect_amd import weights as W
+    from wedetect_amd.detector import from_uni_keys
+    a = W.make_state_dict("nano", seed=5, num_prompts=8)
+    b = W.make_state_dict("nano", seed=5, num_prompts=8)
+    c = W.make_state_dict("nano", seed=6, num_prompts=8)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    assert any(not np.array_equal(a[k], c[k]) for k in a)
+    uni = W.to_uni_keys(a)
+    assert "backbone.stages.0.0.dwconv.weight" in uni and "bbox_head.cls_preds.1.4.running_mean" in uni
+    assert "bbox_head.reg_preds.2.6.bias" in uni and "bbox_head.cls_contrasts.0.norm.weight" in uni
+    back = from_uni_keys(uni)
+    assert set(back) == set(a) and all(np.array_equal(back[k], a[k]) for k in a)
+    assert np.allclose(np.linalg.norm(a["embeddings"], axis=1), 1.0, atol=1e-6)
+
+
+def test_pack_folds_match_unfolded_math():
+    """BN / layer-scale folding done by pack() is algebraically the reference's op order."""
+    from wedetect_amd import weights as W
+    from wedetect_amd.arch import NK
+    from wedetect_amd.pack import pack
+    sd = W.make_state_dict("nano", num_prompts=4)
+    P = pack(sd, "nano", device="cpu")
+    x = torch.randn(2, 256, 5, 5)
+    p = NK + "reduce_layer0.block."
+    y = torch.nn.functional.conv2d(x, torch.from_numpy(sd[p + "conv.weight"]))
+    y = torch.nn.functional.batch_norm(y, torch.from_numpy(sd[p + "bn.running_mean"]), torch.from_numpy(sd[p + "bn.running_var"]),
+                                       torch.from_numpy(sd[p + "bn.weight"]), torch.from_numpy(sd[p + "bn.bias"]), False, 0.1, 1e-5)
+    w = P["reduce_layer0.w"]                                   # [cout, cin]
+    z = torch.einsum("bchw,oc->bohw", x, w) + P["reduce_layer0.b"][None, :, None, None]
+    assert_close("folded conv+bn", z, y, 1e-5, 1e-5)
+    q = "backbone.image_model.model.stages.0.0."
+    h = torch.randn(7, 4 * 32)
+    ref = torch.from_numpy(sd[q + "gamma"]) * torch.nn.functional.linear(h, torch.from_numpy(sd[q + "pwconv2.weight"]),
+                                                                         torch.from_numpy(sd[q + "pwconv2.bias"]))
+    assert_close("gamma folded into pwconv2", torch.nn.functional.linear(h, P["s0.0.w2"], P["s0.0.b2"]), ref, 1e-5, 1e-5)
+    assert P["s0.0.dw_w"].shape == (49, 32) and P["Bifusion0.up.w"].shape == (4 * 64, 64)
+
+
+def test_letterbox_matches_reference_arithmetic():
+    from PIL import Image
+    from wedetect_amd.detector import letterbox
+    img = Image.fromarray(np.random.default_rng(0).integers(0, 255, (72, 128, 3), dtype=np.uint8))
+    out, r, (dw, dh) = letterbox(img, (64, 64))
+    assert out.size == (64, 64) and r == 0.5 and (dw, dh) == (0.0, 14.0)
+    a = np.asarray(out)
+    assert np.all(a[:14] == 114) and np.all(a[50:] == 114) and not np.all(a[14:50] == 114)
+
+
+def test_instance_data_surface():
+    from wedetect_amd.detector import InstanceData
+    d = InstanceData(bboxes=torch.arange(12.).view(3, 4), scores=torch.tensor([0.9, 0.2, 0.5]), labels=torch.tensor([1, 2, 3]))
+    m = d[d.scores > 0.3]
+    assert len(m) == 2 and m["labels"].tolist() == [1, 3]
+    n = m.cpu().numpy()
+    assert isinstance(n["bboxes"], np.ndarray) and "scores" in n
+
+
+def test_detectors_refuse_to_run_without_gpu_or_weights():
+    from wedetect_amd.detector import SimpleYOLOWorldDetector, YOLOWorldDetector
+    from wedetect_amd import weights as W
+    m = SimpleYOLOWorldDetector("nano", num_prompts=8)
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({}, strict=False)                     # missing tensors are an error, never random-init
+    msg = m.load_state_dict(W.to_uni_keys(W.make_state_dict("nano", num_prompts=8)), strict=True)
+    assert not msg.missing_keys and not msg.unexpected_keys
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            m.cuda()
+    d = YOLOWorldDetector("nano")
+    with pytest.raises(NotImplementedError):
+        d.reparameterize([["cat"], ["dog"]])
+
+
+# ------------------------------------------------------------------------------------------ C ABI
+def test_library_loads_and_exports_every_declared_symbol():
+    import ctypes
+    from wedetect_amd import build as wb
+    wb.build(verbose=False)
+    hdr = open(os.path.join(ROOT, "include", "wedetect_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(wd_[a-z0-9_]+)\s*\(", hdr))
+    assert {"wd_conv_gemm", "wd_topk_candidates", "wd_nms_gather", "wd_retrieval_max", "wd_dwconv7"} <= declared
+    lib = ctypes.CDLL(wb.LIB)
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, f"declared in include/wedetect_hip.h but not exported: {missing}"
+    from wedetect_amd import lib as L
+    assert set(L.EXPORTS) == declared
+    assert L.LIB.wd_abi_version() == L.ABI_VERSION
+    assert ctypes.sizeof(L.ConvGemm) == L.LIB.wd_sizeof_conv_gemm() == 168
+    assert L.topk_capacity(30000) == 32768 and L.topk_workspace_bytes(2, 8400 * 80, 30000) > 2 * 32768 * 8
+    assert L.gemm_config(1000, 80, 768).startswith("256x80") and L.gemm_config(1000, 2048, 512).startswith("128x128")
+
+
+# ------------------------------------------------------------------------------------------ N > 1 on gloo
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _gather_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from wedetect_amd.parallel import gather_regions, gather_results, shard_range
+    ids = list(shard_range(6, world, rank))
+    emb = torch.stack([torch.full((5, 8), float(i)) for i in ids])
+    cnt = torch.tensor([i % 5 + 1 for i in ids], dtype=torch.int32)
+    g = gather_regions(emb, cnt)
+    r = gather_results(dict(image_id=torch.tensor(ids, dtype=torch.int64)))
+    q.put((rank, g["embeddings"][:, 0, 0].tolist(), g["count"].tolist(), r["image_id"].tolist()))
+    dist.destroy_process_group()
+
+
+def test_region_gather_world2_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, e0, cnt, ids in outs:
+        assert ids == [0, 1, 2, 3, 4, 5], (rank, ids)                # global image order on every rank
+        assert e0 == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0]
+        assert cnt == [i % 5 + 1 for i in range(6)]

@@ -1,0 +1,357 @@
+"""Kernel-level parity tests (GPU): every C-ABI entry point against a CPU reference on the
+same seeded inputs.  Floating-point kernels: fp64/fp32 torch-CPU references, tolerance
+written per test.  Index kernels (top-k, NMS): bit-exact against oracle/postprocess.py
+and the committed golden fixtures."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import assert_close, golden, to_np
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from wedetect_amd import lib
+    return lib
+
+
+def dev(a, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(dtype).cuda()
+
+
+def rnd(seed, *shape, scale=1.0):
+    return (np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("m,n,k", [(1, 48, 48), (100, 64, 64), (300, 80, 768), (257, 81, 100), (1000, 96, 256),
+                                   (513, 128, 512), (130, 256, 36), (77, 1203, 768), (4096, 512, 2048),
+                                   (300, 192, 32), (64, 16, 4)])
+def test_gemm_plain(L, m, n, k):
+    a, w, b = rnd(1, m, k), rnd(2, n, k, scale=k ** -0.5), rnd(3, n)
+    c = torch.full((m, n), 7.0, device="cuda")
+    L.conv_gemm(dev(a), dev(w), dev(b), c, batch=1, hin=1, win=m, cin=k, lda=k, n=n, ldc=n)
+    ref = a.astype(np.float64) @ w.astype(np.float64).T + b
+    assert_close(f"gemm {m}x{n}x{k} [{L.gemm_config(m, n, k)}]", c, ref, atol=2e-5, rtol=2e-5)
+
+
+@pytest.mark.parametrize("act", ["none", "relu", "silu", "gelu"])
+def test_gemm_activation_residual_slice(L, act):
+    m, n, k, ldc, off = 333, 64, 128, 200, 24
+    a, w, b, r = rnd(4, m, k), rnd(5, n, k, scale=k ** -0.5), rnd(6, n), rnd(7, m, n)
+    full = torch.full((m, ldc), -3.0, device="cuda")
+    code = dict(none=L.ACT_NONE, relu=L.ACT_RELU, silu=L.ACT_SILU, gelu=L.ACT_GELU)[act]
+    L.conv_gemm(dev(a), dev(w), dev(b), full[:, off:], batch=1, hin=1, win=m, cin=k, lda=k, n=n, ldc=ldc, act=code,
+                res=dev(r), ldres=n, res_alpha=0.625)
+    v = torch.from_numpy(a.astype(np.float64) @ w.astype(np.float64).T + b)
+    v = dict(none=lambda x: x, relu=F.relu, silu=F.silu, gelu=F.gelu)[act](v)
+    ref = v.numpy() + 0.625 * r
+    out = to_np(full)
+    assert_close(f"gemm+{act}+res slice", out[:, off:off + n], ref, atol=3e-5, rtol=3e-5)
+    assert np.all(out[:, :off] == -3.0) and np.all(out[:, off + n:] == -3.0), "wrote outside its channel slice"
+
+
+def test_gemm_inplace_residual(L):
+    m, n, k = 640, 128, 512
+    a, w, b, x = rnd(8, m, k), rnd(9, n, k, scale=k ** -0.5), rnd(10, n), rnd(11, m, n)
+    xd = dev(x)
+    L.conv_gemm(dev(a), dev(w), dev(b), xd, batch=1, hin=1, win=m, cin=k, lda=k, n=n, ldc=n, res=xd, ldres=n)
+    assert_close("x += a w^T + b (in place)", xd, a.astype(np.float64) @ w.astype(np.float64).T + b + x, 3e-5, 3e-5)
+
+
+def test_gemm_similarity_epilogue(L):
+    """Per-level exp(logit_scale)/bias + sigmoid over rows grouped per image (seg mode), unaligned N."""
+    b_, ntot, k, kcls = 3, 84, 768, 81
+    e, t = rnd(12, b_ * ntot, k), rnd(13, kcls, k)
+    t /= np.linalg.norm(t, axis=1, keepdims=True)
+    sc, bs = (0.7, 0.58, 0.82), (-2.6, -2.2, -1.9)
+    out = torch.empty(b_, ntot, kcls, device="cuda")
+    L.conv_gemm(dev(e), dev(t), None, out, batch=1, hin=1, win=b_ * ntot, cin=k, lda=k, n=kcls, ldc=kcls,
+                sigmoid=True, seg=(ntot, 64, 80, sc, bs))
+    lvl = (np.arange(ntot) >= 64).astype(int) + (np.arange(ntot) >= 80).astype(int)
+    lg = (e.astype(np.float64) @ t.astype(np.float64).T).reshape(b_, ntot, kcls)
+    lg = lg * np.asarray(sc)[lvl][None, :, None] + np.asarray(bs)[lvl][None, :, None]
+    assert_close("sim sigmoid seg", out, 1 / (1 + np.exp(-lg)), atol=2e-6, rtol=1e-5)
+
+
+def test_gemm_batch_stride_rows(L):
+    """A level's rows land at b*stride + pos inside a taller [B, Ntot, C] tensor."""
+    b_, hw, ntot, off, k, n = 3, 16, 21, 4, 64, 96
+    a, w = rnd(14, b_ * hw, k), rnd(15, n, k)
+    big = torch.full((b_, ntot, n), 9.0, device="cuda")
+    L.conv_gemm(dev(a), dev(w), None, big.view(-1, n)[off:], batch=b_, hin=4, win=4, cin=k, lda=k, n=n, ldc=n,
+                c_batch_stride=ntot)
+    ref = (a.astype(np.float64) @ w.astype(np.float64).T).reshape(b_, hw, n)
+    out = to_np(big)
+    assert_close("batch-stride rows", out[:, off:off + hw], ref, 2e-5, 2e-5)
+    assert np.all(out[:, :off] == 9.0) and np.all(out[:, off + hw:] == 9.0)
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,h,w", [(32, 64, 3, 1, 9, 7), (48, 48, 3, 1, 16, 16), (64, 96, 3, 2, 16, 12),
+                                                   (128, 256, 2, 2, 8, 8), (96, 80, 1, 1, 5, 6), (256, 256, 3, 1, 20, 20),
+                                                   (64, 64, 3, 2, 7, 9)])
+def test_conv_nhwc(L, cin, cout, k, stride, h, w):
+    b_ = 2
+    pad = 1 if k == 3 else 0
+    x, wt, bias = rnd(16, b_, cin, h, w), rnd(17, cout, cin, k, k, scale=(cin * k * k) ** -0.5), rnd(18, cout)
+    ref = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(), torch.from_numpy(bias).double(),
+                   stride=stride, padding=pad)
+    ho, wo = ref.shape[2:]
+    lda = cin + 8                                   # input lives in a channel slice of a wider buffer
+    xin = torch.zeros(b_, h, w, lda, device="cuda")
+    xin[..., 4:4 + cin] = dev(np.transpose(x, (0, 2, 3, 1)))
+    wrows = np.transpose(wt, (0, 2, 3, 1)).reshape(cout, -1)
+    out = torch.empty(b_ * ho * wo, cout, device="cuda")
+    L.conv_gemm(xin[..., 4:], dev(wrows), dev(bias), out, batch=b_, hin=h, win=w, cin=cin, lda=lda, kh=k, kw=k,
+                stride=stride, pad=pad, n=cout, ldc=cout)
+    assert_close(f"conv{k}x{k}s{stride} {cin}->{cout} @{h}x{w}", out.view(b_, ho, wo, cout),
+                 ref.permute(0, 2, 3, 1).numpy(), 3e-5, 3e-5)
+
+
+def test_deconv2x2(L):
+    b_, ci, co, h, w = 2, 64, 32, 5, 6
+    x, wt, bias = rnd(19, b_, ci, h, w), rnd(20, ci, co, 2, 2, scale=ci ** -0.5), rnd(21, co)
+    ref = F.conv_transpose2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(),
+                             torch.from_numpy(bias).double(), stride=2)
+    ldc = 3 * co
+    out = torch.full((b_, 2 * h, 2 * w, ldc), 5.0, device="cuda")
+    wrows = np.transpose(wt, (2, 3, 1, 0)).reshape(4 * co, ci)
+    L.conv_gemm(dev(np.transpose(x, (0, 2, 3, 1))), dev(wrows), dev(np.tile(bias, 4)), out, batch=b_, hin=h, win=w,
+                cin=ci, lda=ci, n=4 * co, ldc=ldc, out_mode=L.OUT_DECONV2X2)
+    o = to_np(out)
+    assert_close("deconv2x2", o[..., :co], ref.permute(0, 2, 3, 1).numpy(), 3e-5, 3e-5)
+    assert np.all(o[..., co:] == 5.0)
+
+
+def test_gemm_rejects_bad_args(L):
+    a = torch.zeros(8, 6, device="cuda")
+    with pytest.raises(L.WedetectHipError):
+        L.conv_gemm(a, a, None, a, batch=1, hin=1, win=8, cin=6, lda=6, n=8, ldc=8)       # cin % 4 != 0
+
+
+# ------------------------------------------------------------------------------------------ elementwise
+def test_stem_patchify(L):
+    img = np.random.default_rng(22).integers(0, 256, size=(2, 32, 24, 3), dtype=np.uint8)
+    out = torch.empty(2 * 8 * 6, 48, device="cuda")
+    L.stem_patchify(torch.from_numpy(img).cuda(), out)
+    x = torch.from_numpy(img).float() / 255.0                                        # [B,H,W,3]
+    ref = x.view(2, 8, 4, 6, 4, 3).permute(0, 1, 3, 2, 4, 5).reshape(2 * 8 * 6, 48)
+    assert torch.equal(out.cpu(), ref), "patchify must be bit-exact (uint8 -> float, one division)"
+
+
+@pytest.mark.parametrize("c,h,w", [(32, 16, 16), (96, 9, 11), (128, 20, 20), (192, 5, 3), (512, 8, 8), (1536, 2, 2)])
+def test_dwconv7(L, c, h, w):
+    b_ = 2
+    x, wt, bias = rnd(23, b_, c, h, w), rnd(24, c, 1, 7, 7, scale=1 / 7), rnd(25, c)
+    ref = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(), torch.from_numpy(bias).double(),
+                   padding=3, groups=c)
+    y = torch.empty(b_, h, w, c, device="cuda")
+    L.dwconv7(dev(np.transpose(x, (0, 2, 3, 1))), dev(wt.reshape(c, 49).T), dev(bias), y, b_, h, w, c)
+    assert_close(f"dwconv7 c{c} {h}x{w}", y, ref.permute(0, 2, 3, 1).numpy(), 1e-5, 1e-5)
+
+
+@pytest.mark.parametrize("c", [32, 64, 96, 128, 192, 256, 384, 512, 768, 1024, 1536])
+def test_layernorm_rows(L, c):
+    rows = 77
+    x, g, b = rnd(26, rows, c, scale=2.0) + 0.5, rnd(27, c) * 0.2 + 1.0, rnd(28, c) * 0.1
+    ref = F.layer_norm(torch.from_numpy(x), (c,), torch.from_numpy(g), torch.from_numpy(b), 1e-6)
+    xd = dev(x)
+    y = torch.empty_like(xd)
+    L.layernorm_rows(xd, y, dev(g), dev(b), rows, c)
+    assert_close(f"layernorm c{c}", y, ref, 5e-6, 5e-6)
+    L.layernorm_rows(xd, xd, dev(g), dev(b), rows, c)        # in place
+    assert torch.equal(xd, y)
+
+
+def test_l2norm_rows(L):
+    x = rnd(29, 81, 768) * 3
+    y = torch.empty(81, 768, device="cuda")
+    L.l2norm_rows(dev(x), y)
+    assert_close("l2norm", y, F.normalize(torch.from_numpy(x), dim=-1), 1e-6, 1e-6)
+
+
+def test_dfl_decode(L):
+    from oracle import ref_cpu as orc
+    b_, sizes = 2, [(8, 6), (4, 3), (2, 2)]
+    ntot = sum(h * w for h, w in sizes)
+    boxes = torch.zeros(b_, ntot, 4, device="cuda")
+    pri, stride = orc.grid_priors(sizes)
+    off, ref = 0, []
+    for l, (h, w) in enumerate(sizes):
+        d = rnd(30 + l, b_, h * w, 64, scale=2.0)
+        L.dfl_decode(dev(d), 64, boxes, b_, h, w, (8, 16, 32)[l], off, ntot)
+        dd = torch.from_numpy(d).view(b_, h * w, 4, 16).softmax(3).matmul(torch.arange(16.).view(-1, 1)).squeeze(-1)
+        dd = dd * (8, 16, 32)[l]
+        p = pri[off:off + h * w][None]
+        ref.append(torch.stack([p[..., 0] - dd[..., 0], p[..., 1] - dd[..., 1], p[..., 0] + dd[..., 2],
+                                p[..., 1] + dd[..., 3]], -1))
+        off += h * w
+    assert_close("dfl decode", boxes, torch.cat(ref, 1), 2e-4, 1e-6)
+
+
+# ------------------------------------------------------------------------------------------ top-k
+def run_topk(L, scores_list, thr, nms_pre):
+    b_ = len(scores_list)
+    n = scores_list[0].size
+    s = dev(np.stack([x.reshape(-1) for x in scores_list]))
+    cap = L.topk_capacity(nms_pre)
+    ws = torch.empty(L.topk_workspace_bytes(b_, n, nms_pre) + 256, dtype=torch.uint8, device="cuda")
+    o = (-ws.data_ptr()) % 256
+    ws = ws[o:]
+    idx = torch.empty(b_, cap, dtype=torch.int32, device="cuda")
+    sc = torch.empty(b_, cap, device="cuda")
+    cnt = torch.empty(b_, dtype=torch.int32, device="cuda")
+    L.topk_candidates(s, b_, n, thr, nms_pre, idx, sc, cnt, ws)
+    torch.cuda.synchronize()
+    return to_np(idx), to_np(sc), to_np(cnt)
+
+
+def check_topk(L, scores_list, thr, nms_pre, name):
+    from oracle import postprocess as opp
+    idx, sc, cnt = run_topk(L, scores_list, np.float32(thr), nms_pre)
+    for i, s in enumerate(scores_list):
+        rs, rl, ra = opp.filter_scores_and_topk(s, thr, nms_pre)
+        k = s.shape[1]
+        assert cnt[i] == rs.shape[0], f"{name}[{i}]: count {cnt[i]} vs oracle {rs.shape[0]}"
+        n = int(cnt[i])
+        ref_flat = ra * k + rl
+        bad = np.nonzero(idx[i, :n] != ref_flat)[0]
+        assert bad.size == 0, (f"{name}[{i}]: {bad.size}/{n} candidate indices differ, first at rank {bad[0]}: "
+                               f"got {idx[i, bad[0]]} (score {sc[i, bad[0]]}) want {ref_flat[bad[0]]} (score {rs[bad[0]]})")
+        assert np.array_equal(sc[i, :n], rs), f"{name}[{i}]: candidate scores differ"
+        assert np.all(idx[i, n:] == -1)
+
+
+def test_topk_against_oracle(L):
+    g = np.random.default_rng(31)
+    a = g.random((700, 9), dtype=np.float32)
+    ties = (np.round(g.random((700, 9), dtype=np.float32) * 16) / 16).astype(np.float32)
+    low = (g.random((700, 9), dtype=np.float32) * 1e-4).astype(np.float32)
+    const = np.full((700, 9), 0.5, dtype=np.float32)
+    check_topk(L, [a, ties, low, const], 0.001, 1000, "mixed batch, truncating")
+    check_topk(L, [a, ties, low, const], 0.001, 30000, "mixed batch, everything kept")
+    check_topk(L, [ties], 0.3, 50, "ties at the cut")
+    check_topk(L, [low], 0.5, 100, "empty")
+
+
+def test_topk_large_sigmoid_map(L):
+    g = np.random.default_rng(32)
+    maps = [(1 / (1 + np.exp(-(g.standard_normal((8400, 256)) - 2.5)))).astype(np.float32) for _ in range(2)]
+    check_topk(L, maps, 0.0, 30000, "8400x256 sigmoid")
+
+
+def test_topk_golden(L):
+    fx = golden("filter_topk.npz")
+    for name in ("ties", "trunc", "empty", "all_equal"):
+        s = fx[f"{name}.in"]
+        idx, sc, cnt = run_topk(L, [s], np.float32(fx[f"{name}.thr"]), int(fx[f"{name}.topk"]))
+        n = int(cnt[0])
+        assert n == fx[f"{name}.scores"].shape[0], name
+        assert np.array_equal(idx[0, :n], fx[f"{name}.anchors"] * s.shape[1] + fx[f"{name}.labels"]), name
+        assert np.array_equal(sc[0, :n], fx[f"{name}.scores"]), name
+
+
+# ------------------------------------------------------------------------------------------ NMS
+def run_nms(L, boxes_list, scores_list, labels_list, k, thr, max_out, meta_rows, embed=None):
+    """Candidates are fed pre-sorted, one candidate per anchor (flat = anchor*k + label)."""
+    b_ = len(boxes_list)
+    nmax = max(1, max(b.shape[0] for b in boxes_list))
+    boxes = np.zeros((b_, nmax, 4), np.float32)
+    cidx = np.full((b_, nmax), -1, np.int32)
+    csc = np.zeros((b_, nmax), np.float32)
+    cnt = np.zeros(b_, np.int32)
+    for i, (bx, sc, lb) in enumerate(zip(boxes_list, scores_list, labels_list)):
+        n = bx.shape[0]
+        boxes[i, :n] = bx
+        cidx[i, :n] = np.arange(n) * k + lb
+        csc[i, :n] = sc
+        cnt[i] = n
+    ob = torch.empty(b_, max_out, 4, device="cuda")
+    os_ = torch.empty(b_, max_out, device="cuda")
+    ol = torch.empty(b_, max_out, dtype=torch.int32, device="cuda")
+    oa = torch.empty(b_, max_out, dtype=torch.int32, device="cuda")
+    oc = torch.empty(b_, dtype=torch.int32, device="cuda")
+    oe = None
+    ed = None
+    if embed is not None:
+        ed = dev(embed)
+        oe = torch.empty(b_, max_out, embed.shape[-1], device="cuda")
+    L.nms_gather(dev(cidx, torch.int32), dev(csc), dev(cnt, torch.int32), nmax, dev(boxes), nmax, k,
+                 dev(np.asarray(meta_rows, np.float32)), float(np.float32(thr)), max_out, ed,
+                 0 if embed is None else embed.shape[-1], ob, os_, ol, oa, oc, oe, b_)
+    torch.cuda.synchronize()
+    return to_np(ob), to_np(os_), to_np(ol), to_np(oa), to_np(oc), None if oe is None else to_np(oe)
+
+
+IDENT = [0, 0, 0, 1, 1, 1e9, 1e9, 0]
+
+
+def test_nms_golden_and_random(L):
+    from oracle import postprocess as opp
+    fx = golden("nms.npz")
+    cases = [(fx["unit.boxes"], fx["unit.scores"], fx["unit.labels"], fx["unit.keep"]),
+             (fx["rand.boxes"], fx["rand.scores"], fx["rand.labels"], fx["rand.keep"]),
+             (np.zeros((0, 4), np.float32), np.zeros(0, np.float32), np.zeros(0, np.int64), fx["empty.keep"])]
+    max_out = 300
+    ob, os_, ol, oa, oc, _ = run_nms(L, [c[0] for c in cases], [c[1] for c in cases], [c[2] for c in cases], 7, 0.7,
+                                     max_out, [IDENT] * 3)
+    for i, (bx, sc, lb, keep) in enumerate(cases):
+        keep = keep[:max_out]
+        assert oc[i] == keep.shape[0], f"nms case {i}: kept {oc[i]} vs oracle {keep.shape[0]}"
+        assert np.array_equal(oa[i, :oc[i]], keep), f"nms case {i}: kept indices differ"
+        assert np.array_equal(ol[i, :oc[i]], lb[keep])
+        assert np.array_equal(os_[i, :oc[i]], sc[keep])
+        assert np.array_equal(ob[i, :oc[i]], bx[keep]) or oc[i] == 0
+        assert np.all(oa[i, oc[i]:] == -1)
+    # dense overlaps, many classes, more than max_out survivors, both rescale orders
+    g = np.random.default_rng(33)
+    n = 5000
+    ctr = g.random((n, 2), dtype=np.float32) * 300 + 20
+    wh = g.random((n, 2), dtype=np.float32) * 80 + 2
+    bx = np.concatenate([ctr - wh / 2, ctr + wh / 2], 1).astype(np.float32)
+    sc = np.sort(g.random(n, dtype=np.float32))[::-1].copy()
+    lb = g.integers(0, 3, n).astype(np.int64)
+    emb = g.standard_normal((1, n, 32)).astype(np.float32)
+    meta_pre = [6.0, 4.0, 0, 0.5, 0.8, 500.0, 380.0, 1.0]
+    meta_post = [6.0, 4.0, 0, 0.5, 0.8, 500.0, 380.0, 0.0]
+    for meta in (meta_pre, meta_post):
+        ob, os_, ol, oa, oc, oe = run_nms(L, [bx], [sc], [lb], 3, 0.7, 300, [meta], embed=emb)
+        if meta[7]:
+            r = opp.mmdet_predict_image_from_candidates(bx, sc, lb, (meta[1], 0, meta[0], 0), (meta[3], meta[4]),
+                                                        (meta[6], meta[5]), 0.7, 300)
+            keep, rb = r["keep"], r["bboxes"]
+        else:
+            keep = opp.batched_nms(bx, sc, lb, 0.7, max_keep=300)
+            rb = opp.clamp_boxes(opp.rescale_boxes(bx[keep], (meta[0], meta[1]), (meta[3], meta[4])),
+                                 (meta[6], meta[5]))
+        assert oc[0] == keep.shape[0]
+        assert np.array_equal(oa[0, :oc[0]], keep), f"pre={meta[7]}: kept set/order differs"
+        assert np.array_equal(ob[0, :oc[0]], rb), f"pre={meta[7]}: output boxes differ"
+        assert np.array_equal(oe[0, :oc[0]], emb[0, keep])
+        assert np.all(oe[0, oc[0]:] == 0)
+
+
+# ------------------------------------------------------------------------------------------ retrieval
+@pytest.mark.parametrize("k", [80, 81, 256, 1203])
+def test_retrieval_max_golden(L, k):
+    from oracle import postprocess as opp
+    from wedetect_amd import weights as W
+    fx = golden("retrieval.npz")
+    e = W.make_regions(300, seed=int(fx[f"k{k}.seed_embed"]))
+    assert np.array_equal(e[:4, :8], fx[f"k{k}.embed_head"]), "region generator drifted from the golden fixture"
+    t = W.make_text_bank(k)
+    scale, bias = fx[f"k{k}.scale"], fx[f"k{k}.bias"]
+    n_img, rows = 3, 300
+    counts = np.asarray([300, 0, 137], np.int32)
+    ed = dev(np.stack([e, e, e]))
+    out = torch.full((n_img, k), -1.0, device="cuda")
+    L.retrieval_max(ed, dev(t), dev(np.stack([scale] * 3)), dev(np.stack([bias] * 3)), dev(counts, torch.int32), out,
+                    n_img, rows, k, 768)
+    o = to_np(out)
+    assert_close(f"retrieval max k{k} (golden from the reference's lines)", o[0], fx[f"k{k}.max_scores"], 2e-6, 1e-5)
+    assert np.all(o[1] == 0.0), "image without regions must give zeros"
+    assert_close("partial count", o[2], opp.retrieval_scores(e[:137], t, scale[:137], bias[:137]), 2e-6, 1e-5)

@@ -1,0 +1,273 @@
+// elementwise.hip — HBM-bound kernels of the image tower: stem patchify, depthwise 7x7,
+// LayerNorm over channels, L2 row normalisation, DFL + box decode.  NHWC fp32, 16-byte
+// per-lane accesses with lanes running along the channel axis (coalesced 1 KiB per wave
+// instruction whenever C >= 256).
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------
+// stem patchify: uint8 RGB NHWC -> [B*(H/4)*(W/4), 48] fp32, /255
+// One thread = one (patch, kh) segment = 12 contiguous bytes in, 12 floats out.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) stem_patchify_kernel(const uint8_t* __restrict__ img, float* __restrict__ out,
+                                                            int h, int w, long long total) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int kh = (int)(idx & 3);
+  const long long patch = idx >> 2;
+  const int wo_n = w >> 2, ho_n = h >> 2;
+  const int wo = (int)(patch % wo_n);
+  const long long q = patch / wo_n;
+  const int ho = (int)(q % ho_n);
+  const long long b = q / ho_n;
+  const uint8_t* src = img + ((b * h + (ho * 4 + kh)) * (long long)w + wo * 4) * 3;   // 4-byte aligned (w%4==0)
+  const uint32_t* s4 = reinterpret_cast<const uint32_t*>(src);
+  const uint32_t u0 = s4[0], u1 = s4[1], u2 = s4[2];
+  float* dst = out + patch * 48 + kh * 12;
+  float v[12];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[i] = (float)((u0 >> (8 * i)) & 255u);
+    v[4 + i] = (float)((u1 >> (8 * i)) & 255u);
+    v[8 + i] = (float)((u2 >> (8 * i)) & 255u);
+  }
+  // the reference divides by 255 (x / 255.0), it does not multiply by a reciprocal
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    *reinterpret_cast<f32x4*>(dst + 4 * i) =
+        f32x4{v[4 * i] / 255.0f, v[4 * i + 1] / 255.0f, v[4 * i + 2] / 255.0f, v[4 * i + 3] / 255.0f};
+}
+
+// ---------------------------------------------------------------------------------------
+// depthwise 7x7 pad 3 + bias.  One thread = 4 channels x DW_TW consecutive output pixels of
+// one row; lanes run along channel quads.  Inputs are re-read through L1/L2 (each input
+// float4 is used by up to 49 outputs, 7 of them inside this thread).
+// ---------------------------------------------------------------------------------------
+constexpr int DW_TW = 8;
+
+__global__ void __launch_bounds__(256) dwconv7_kernel(const float* __restrict__ x, const float* __restrict__ w7,
+                                                      const float* __restrict__ bias, float* __restrict__ y,
+                                                      int h, int w, int c, int nstrip_w, long long total) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int cq_n = c >> 2;
+  const int cq = (int)(idx % cq_n);
+  long long s = idx / cq_n;
+  const int ws = (int)(s % nstrip_w);
+  s /= nstrip_w;
+  const int ho = (int)(s % h);
+  const long long b = s / h;
+  const int w0 = ws * DW_TW;
+  const int c0 = cq * 4;
+
+  f32x4 acc[DW_TW];
+  const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c0);
+#pragma unroll
+  for (int j = 0; j < DW_TW; ++j) acc[j] = bv;
+
+  const float* xb = x + (b * h) * (long long)w * c + c0;
+#pragma unroll 1
+  for (int kh = 0; kh < 7; ++kh) {
+    const int hi = ho + kh - 3;
+    if ((unsigned)hi >= (unsigned)h) continue;
+    const float* xr = xb + (long long)hi * w * c;
+    f32x4 in[DW_TW + 6];
+#pragma unroll
+    for (int j = 0; j < DW_TW + 6; ++j) {
+      const int wi = w0 + j - 3;
+      in[j] = ((unsigned)wi < (unsigned)w) ? *reinterpret_cast<const f32x4*>(xr + (long long)wi * c)
+                                           : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float* wr = w7 + (kh * 7) * c + c0;
+#pragma unroll
+    for (int kw = 0; kw < 7; ++kw) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + kw * c);
+#pragma unroll
+      for (int j = 0; j < DW_TW; ++j) acc[j] += in[j + kw] * wv;
+    }
+  }
+  float* yr = y + ((b * h + ho) * (long long)w) * c + c0;
+#pragma unroll
+  for (int j = 0; j < DW_TW; ++j)
+    if (w0 + j < w) *reinterpret_cast<f32x4*>(yr + (long long)(w0 + j) * c) = acc[j];
+}
+
+// ---------------------------------------------------------------------------------------
+// LayerNorm over the channel axis of each row.  A group of G lanes (power of two, 8..64)
+// owns one row; each lane holds NV float4.  Two-pass (mean, then centred variance), fp32.
+// ---------------------------------------------------------------------------------------
+template <int NV>
+__global__ void __launch_bounds__(256) layernorm_rows_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, long long rows, int c,
+                                                             int ldx, int ldy, float eps, int g) {
+  const int t = threadIdx.x;
+  const int rows_per_block = 256 / g;
+  const long long row = (long long)blockIdx.x * rows_per_block + t / g;
+  const int gl = t % g;
+  const bool row_ok = row < rows;      // keep every lane alive for the shuffles
+  const int nq = c >> 2;
+  f32x4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int q = gl + i * g;
+    v[i] = (row_ok && q < nq) ? *reinterpret_cast<const f32x4*>(x + row * ldx + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  }
+  s = wd_group_sum(s, g);
+  const float mean = s / (float)c;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int q = gl + i * g;
+    if (q < nq) {
+      const f32x4 d = v[i] - mean;
+      sq += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+    }
+  }
+  sq = wd_group_sum(sq, g);
+  const float rstd = 1.0f / sqrtf(sq / (float)c + eps);
+  if (!row_ok) return;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int q = gl + i * g;
+    if (q < nq) {
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + q * 4);
+      const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + q * 4);
+      *reinterpret_cast<f32x4*>(y + row * ldy + q * 4) = (v[i] - mean) * rstd * gm + bt;
+    }
+  }
+}
+
+// L2 row normalisation, one wave per row (rows are few: the text bank).
+__global__ void __launch_bounds__(256) l2norm_rows_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          long long rows, int c) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const bool ok = row < rows;
+  float s = 0.f;
+  if (ok)
+    for (int i = lane; i < c; i += 64) { const float v = x[row * c + i]; s += v * v; }
+  s = wd_group_sum(s, 64);
+  const float d = fmaxf(sqrtf(s), 1e-12f);
+  if (ok)
+    for (int i = lane; i < c; i += 64) y[row * c + i] = x[row * c + i] / d;
+}
+
+// ---------------------------------------------------------------------------------------
+// DFL + decode: one thread per (anchor, side); 4 lanes share one anchor.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) dfl_decode_kernel(const float* __restrict__ dist, int ld,
+                                                         float* __restrict__ boxes, int hl, int wl, int stride,
+                                                         int anchor_off, int anchors_total, long long total) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int side = (int)(idx & 3);
+  const long long a = idx >> 2;                 // (b, y, x) flattened over this level
+  const int per = hl * wl;
+  const long long b = a / per;
+  const int pos = (int)(a - b * per);
+  const int yy = pos / wl, xx = pos - yy * wl;
+  const float* d = dist + a * ld + side * 16;
+  f32x4 q[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) q[i] = *reinterpret_cast<const f32x4*>(d + 4 * i);
+  float mx = q[0][0];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, q[i][r]);
+  float den = 0.f, num = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float e = expf(q[i][r] - mx);
+      den += e;
+      num += e * (float)(4 * i + r);
+    }
+  const float dd = (num / den) * (float)stride;
+  const float px = ((float)xx + 0.5f) * (float)stride;
+  const float py = ((float)yy + 0.5f) * (float)stride;
+  float v;
+  if (side == 0) v = px - dd;
+  else if (side == 1) v = py - dd;
+  else if (side == 2) v = px + dd;
+  else v = py + dd;
+  boxes[(b * anchors_total + anchor_off + pos) * 4 + side] = v;
+}
+
+}  // namespace
+
+extern "C" int wd_stem_patchify(const uint8_t* img, float* out, int32_t batch, int32_t h, int32_t w, void* stream) {
+  if (!img || !out || batch <= 0 || h <= 0 || w <= 0 || (h & 3) || (w & 3)) return WD_ERR_BAD_ARG;
+  if ((reinterpret_cast<uintptr_t>(img) & 3u) || !wd_aligned16(out)) return WD_ERR_BAD_ARG;
+  const long long total = (long long)batch * (h / 4) * (w / 4) * 4;
+  const unsigned grid = (unsigned)((total + 255) / 256);
+  hipLaunchKernelGGL(stem_patchify_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), img, out, h, w,
+                     total);
+  return wd_launch_status();
+}
+
+extern "C" int wd_dwconv7(const float* x, const float* w7, const float* bias, float* y, int32_t batch, int32_t h,
+                          int32_t w, int32_t c, void* stream) {
+  if (!x || !w7 || !bias || !y || x == y) return WD_ERR_BAD_ARG;
+  if (batch <= 0 || h <= 0 || w <= 0 || c <= 0 || (c & 3)) return WD_ERR_BAD_ARG;
+  if (!wd_aligned16(x) || !wd_aligned16(w7) || !wd_aligned16(bias) || !wd_aligned16(y)) return WD_ERR_BAD_ARG;
+  const int nstrip = (w + DW_TW - 1) / DW_TW;
+  const long long total = (long long)batch * h * nstrip * (c / 4);
+  const long long grid = (total + 255) / 256;
+  if (grid > 0x7fffffffLL) return WD_ERR_BAD_ARG;
+  hipLaunchKernelGGL(dwconv7_kernel, dim3((unsigned)grid), dim3(256), 0, static_cast<hipStream_t>(stream), x, w7, bias,
+                     y, h, w, c, nstrip, total);
+  return wd_launch_status();
+}
+
+extern "C" int wd_layernorm_rows(const float* x, float* y, const float* gamma, const float* beta, int64_t rows,
+                                 int32_t c, int32_t ldx, int32_t ldy, float eps, void* stream) {
+  if (!x || !y || !gamma || !beta || rows <= 0 || c <= 0 || (c & 3) || c > 2048) return WD_ERR_BAD_ARG;
+  if (ldx < c || ldy < c || (ldx & 3) || (ldy & 3)) return WD_ERR_BAD_ARG;
+  if (!wd_aligned16(x) || !wd_aligned16(y) || !wd_aligned16(gamma) || !wd_aligned16(beta)) return WD_ERR_BAD_ARG;
+  const int nq = c / 4;
+  int g = 8;
+  while (g < 64 && g < nq) g <<= 1;
+  const int nv = (nq + g - 1) / g;
+  const int rpb = 256 / g;
+  const long long grid = (rows + rpb - 1) / rpb;
+  if (grid > 0x7fffffffLL) return WD_ERR_BAD_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+#define WD_LN_CASE(NV)                                                                                              \
+  case NV:                                                                                                          \
+    hipLaunchKernelGGL(layernorm_rows_kernel<NV>, dim3((unsigned)grid), dim3(256), 0, st, x, y, gamma, beta,        \
+                       (long long)rows, c, ldx, ldy, eps, g);                                                       \
+    break;
+  switch (nv) {
+    WD_LN_CASE(1) WD_LN_CASE(2) WD_LN_CASE(3) WD_LN_CASE(4) WD_LN_CASE(5) WD_LN_CASE(6) WD_LN_CASE(7) WD_LN_CASE(8)
+    default: return WD_ERR_UNSUPPORTED;
+  }
+#undef WD_LN_CASE
+  return wd_launch_status();
+}
+
+extern "C" int wd_l2norm_rows(const float* x, float* y, int64_t rows, int32_t c, void* stream) {
+  if (!x || !y || rows <= 0 || c <= 0) return WD_ERR_BAD_ARG;
+  const long long grid = (rows + 3) / 4;
+  if (grid > 0x7fffffffLL) return WD_ERR_BAD_ARG;
+  hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)grid), dim3(256), 0, static_cast<hipStream_t>(stream), x, y,
+                     (long long)rows, c);
+  return wd_launch_status();
+}
+
+extern "C" int wd_dfl_decode(const float* dist, int32_t ld, float* boxes, int32_t batch, int32_t hl, int32_t wl,
+                             int32_t stride, int32_t anchor_off, int32_t anchors_total, void* stream) {
+  if (!dist || !boxes || batch <= 0 || hl <= 0 || wl <= 0 || stride <= 0) return WD_ERR_BAD_ARG;
+  if (ld < 64 || (ld & 3) || !wd_aligned16(dist)) return WD_ERR_BAD_ARG;
+  if (anchor_off < 0 || anchor_off + hl * wl > anchors_total) return WD_ERR_BAD_ARG;
+  const long long total = (long long)batch * hl * wl * 4;
+  const long long grid = (total + 255) / 256;
+  hipLaunchKernelGGL(dfl_decode_kernel, dim3((unsigned)grid), dim3(256), 0, static_cast<hipStream_t>(stream), dist, ld,
+                     boxes, hl, wl, stride, anchor_off, anchors_total, total);
+  return wd_launch_status();
+}

@@ -1,0 +1,295 @@
+"""The image-tower execution plan: a fixed sequence of C-ABI kernel launches over
+pre-allocated NHWC fp32 buffers resident in HBM.
+
+One ``ImageTower`` = (architecture, batch, input H x W) on one GPU.  Nothing is
+allocated per step; every ``torch.cat`` of the reference is replaced by producers writing
+into channel slices of a wider buffer (row stride ``ld`` > C).  All arithmetic happens in
+libwedetect_hip.so — this module only sequences launches on the current HIP stream.
+
+Reference call stack being replaced:
+  ConvNeXt.forward                  mm_backbone.py:233-255
+  CSPRepBiFPANNeck.forward          yolo_world_pafpn.py:1114-1137
+  YOLOWorldHeadModule.forward       yolo_world_head.py:263-294
+  head_predict / predict_by_feat    generate_proposal.py:1150-1218 / yolo_world_head.py:578-749
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import lib as L
+from .arch import ArchSpec, CLS_MID, EMBED_DIM, REG_MID, STRIDES, get_arch, level_sizes
+from .pack import Packed
+
+
+class ImageTower:
+    def __init__(self, arch, packed: Packed, batch: int, height: int, width: int, device="cuda",
+                 max_classes: int = 256, nms_pre: int = 30000, max_out: int = 300):
+        self.a: ArchSpec = get_arch(arch) if isinstance(arch, str) else arch
+        self.P = packed
+        self.B, self.H, self.W = batch, height, width
+        self.dev = torch.device(device)
+        if height % 32 or width % 32:
+            raise ValueError("input size must be a multiple of 32")
+        a, B = self.a, batch
+        f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=self.dev)
+        # ---- backbone buffers
+        self.hw = [(height // (4 << i), width // (4 << i)) for i in range(4)]
+        self.M = [B * h * w for h, w in self.hw]
+        self.patches = f(self.M[0], 48)
+        self.x = [f(self.M[i], a.dims[i]) for i in range(4)]            # c1..c4 (residual streams)
+        self.tmp = f(max(self.M[i] * a.dims[i] for i in range(4)))
+        self.hid = f(max(self.M[i] * 4 * a.dims[i] for i in range(4)))
+        # ---- neck buffers
+        nc = a.neck_channels
+        (h3, w3), (h4, w4), (h5, w5) = self.hw[1], self.hw[2], self.hw[3]
+        M2, M3, M4, M5 = self.M
+        self.cat_n4 = f(M5, nc["d1"] + nc["p5r"])
+        self.cat_b0 = f(M4, 3 * nc["p5r"])
+        self.b0_t = f(M3, nc["p5r"])
+        self.f0 = f(M4, nc["p5r"])
+        self.f_out0 = f(M4, nc["p5r"])
+        self.cat_n3 = f(M4, nc["d2"] + nc["p4r"])
+        self.cat_b1 = f(M3, 3 * nc["p4r"])
+        self.b1_t = f(M2, nc["p4r"])
+        self.f1 = f(M3, nc["p4r"])
+        self.p3 = f(M3, nc["p4r"])
+        self.p4 = f(M4, nc["n3"])
+        self.p5 = f(M5, nc["n4"])
+        self._bep = {}
+        for name, m, cout in (("Rep_p4", M4, nc["p5r"]), ("Rep_p3", M3, nc["p4r"]),
+                              ("Rep_n3", M4, nc["n3"]), ("Rep_n4", M5, nc["n4"])):
+            c_ = cout // 2
+            self._bep[name] = dict(cat=f(m, 2 * c_), u0=f(m, c_), u1=f(m, c_), t=f(m, c_), c_=c_)
+        # ---- head buffers
+        self.lv = level_sizes(height, width)
+        self.nl = [h * w for h, w in self.lv]
+        self.ntot = sum(self.nl)
+        self.off = [0, self.nl[0], self.nl[0] + self.nl[1]]
+        self.embed = f(B, self.ntot, EMBED_DIM)
+        self.boxes = f(B, self.ntot, 4)
+        self.hc = [(f(B * n, CLS_MID), f(B * n, CLS_MID)) for n in self.nl]
+        self.hr = [(f(B * n, REG_MID), f(B * n, REG_MID), f(B * n, 4 * 16)) for n in self.nl]
+        # ---- similarity / post-process buffers (sized for max_classes; grown on demand)
+        self.nms_pre, self.max_out = nms_pre, max_out
+        self.cap = L.topk_capacity(nms_pre)
+        self._alloc_post(max_classes)
+        self.cand_idx = torch.empty(B, self.cap, dtype=torch.int32, device=self.dev)
+        self.cand_score = f(B, self.cap)
+        self.cand_count = torch.empty(B, dtype=torch.int32, device=self.dev)
+        self.out_boxes = f(B, max_out, 4)
+        self.out_scores = f(B, max_out)
+        self.out_labels = torch.empty(B, max_out, dtype=torch.int32, device=self.dev)
+        self.out_anchors = torch.empty(B, max_out, dtype=torch.int32, device=self.dev)
+        self.out_count = torch.empty(B, dtype=torch.int32, device=self.dev)
+        self.out_embed = f(B, max_out, EMBED_DIM)
+        self.text_norm = f(max_classes, EMBED_DIM)
+        # per-level exp(logit_scale) in fp32 like ``logit_scale.exp()`` on a float32 parameter
+        self.lvl_scale = [float(np.exp(np.float32(self.P.s[f"head{l}.logit_scale"]))) for l in range(3)]
+        self.lvl_bias = [float(np.float32(self.P.s[f"head{l}.bias"])) for l in range(3)]
+        self.lvl_logit_scale = [float(np.float32(self.P.s[f"head{l}.logit_scale"])) for l in range(3)]
+
+    def _alloc_post(self, k: int) -> None:
+        self.max_classes = k
+        self.scores = torch.empty(self.B, self.ntot, k, dtype=torch.float32, device=self.dev)
+        nbytes = L.topk_workspace_bytes(self.B, self.ntot * k, self.nms_pre)
+        self.topk_ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.dev)
+        off = (-self.topk_ws.data_ptr()) % 256
+        self.topk_ws = self.topk_ws[off:off + nbytes]
+
+    # ------------------------------------------------------------------ helpers
+    def _conv(self, a, w, b, c, *, hin, win, cin, lda, n, ldc, k=1, stride=1, act=L.ACT_NONE, res=None, ldres=0,
+              res_alpha=1.0, **kw):
+        L.conv_gemm(a, self.P[w], self.P[b] if b else None, c, batch=self.B, hin=hin, win=win, cin=cin, lda=lda,
+                    kh=k, kw=k, stride=stride, pad=(k // 2 if k == 3 else 0), n=n, ldc=ldc, act=act, res=res,
+                    ldres=ldres, res_alpha=res_alpha, **kw)
+
+    # ------------------------------------------------------------------ backbone
+    def backbone(self, images_u8: torch.Tensor) -> List[torch.Tensor]:
+        a, B = self.a, self.B
+        if images_u8.dtype != torch.uint8 or tuple(images_u8.shape) != (B, self.H, self.W, 3):
+            raise L.WedetectHipError(f"images must be uint8 [{B},{self.H},{self.W},3] (RGB, NHWC)")
+        if not images_u8.is_contiguous():
+            images_u8 = images_u8.contiguous()
+        L.stem_patchify(images_u8, self.patches)
+        h0, w0 = self.hw[0]
+        self._conv(self.patches, "stem.w", "stem.b", self.x[0], hin=h0, win=w0, cin=48, lda=48, n=a.dims[0],
+                   ldc=a.dims[0])
+        L.layernorm_rows(self.x[0], self.x[0], self.P["stem.ln_w"], self.P["stem.ln_b"], self.M[0], a.dims[0])
+        for i in range(4):
+            c = a.dims[i]
+            h, w = self.hw[i]
+            if i > 0:
+                cp = a.dims[i - 1]
+                hp, wp = self.hw[i - 1]
+                L.layernorm_rows(self.x[i - 1], self.tmp, self.P[f"down{i}.ln_w"], self.P[f"down{i}.ln_b"],
+                                 self.M[i - 1], cp)
+                L.conv_gemm(self.tmp, self.P[f"down{i}.w"], self.P[f"down{i}.b"], self.x[i], batch=B, hin=hp, win=wp,
+                            cin=cp, lda=cp, kh=2, kw=2, stride=2, pad=0, n=c, ldc=c)
+            for j in range(a.depths[i]):
+                q = f"s{i}.{j}."
+                L.dwconv7(self.x[i], self.P[q + "dw_w"], self.P[q + "dw_b"], self.tmp, B, h, w, c)
+                L.layernorm_rows(self.tmp, self.tmp, self.P[q + "ln_w"], self.P[q + "ln_b"], self.M[i], c)
+                self._conv(self.tmp, q + "w1", q + "b1", self.hid, hin=h, win=w, cin=c, lda=c, n=4 * c, ldc=4 * c,
+                           act=L.ACT_GELU)
+                # x <- x + (gamma*W2) hid + gamma*b2   (in place: each element is read then written by one lane)
+                self._conv(self.hid, q + "w2", q + "b2", self.x[i], hin=h, win=w, cin=4 * c, lda=4 * c, n=c, ldc=c,
+                           res=self.x[i], ldres=c)
+        return self.x
+
+    # ------------------------------------------------------------------ neck
+    def _bepc3(self, name: str, x, ldx: int, cin: int, hw: Tuple[int, int], out, cout: int):
+        bf = self._bep[name]
+        c_ = bf["c_"]
+        h, w = hw
+        nb = self.a.neck_repeats // 2
+        cat = bf["cat"]
+        self._conv(x, f"{name}.cv1.w", f"{name}.cv1.b", bf["u0"], hin=h, win=w, cin=cin, lda=ldx, n=c_, ldc=c_,
+                   act=L.ACT_SILU)
+        cur, nxt = bf["u0"], bf["u1"]
+        for j in range(nb):
+            s = f"{name}.m{j}"
+            self._conv(cur, s + ".c1.w", s + ".c1.b", bf["t"], hin=h, win=w, cin=c_, lda=c_, n=c_, ldc=c_, k=3,
+                       act=L.ACT_SILU)
+            last = j == nb - 1
+            dst, ldd = (cat, 2 * c_) if last else (nxt, c_)
+            self._conv(bf["t"], s + ".c2.w", s + ".c2.b", dst, hin=h, win=w, cin=c_, lda=c_, n=c_, ldc=ldd, k=3,
+                       act=L.ACT_SILU, res=cur, ldres=c_, res_alpha=self.P.s[s + ".alpha"])
+            cur, nxt = nxt, cur
+        self._conv(x, f"{name}.cv2.w", f"{name}.cv2.b", cat[:, c_:], hin=h, win=w, cin=cin, lda=ldx, n=c_,
+                   ldc=2 * c_, act=L.ACT_SILU)
+        self._conv(cat, f"{name}.cv3.w", f"{name}.cv3.b", out, hin=h, win=w, cin=2 * c_, lda=2 * c_, n=cout,
+                   ldc=cout, act=L.ACT_SILU)
+
+    def _bifusion(self, name: str, top, ld_top: int, hw_top, mid, c_mid: int, hw_mid, low, c_low: int, hw_low,
+                  cat, tbuf, out, cout: int):
+        """cat = [upsample(top) | cv1(mid) | downsample(cv2(low))] -> cv3 -> out  (yolo_world_pafpn.py:711-715)."""
+        B = self.B
+        ht, wt = hw_top
+        hm, wm = hw_mid
+        hl, wl = hw_low
+        L.conv_gemm(top, self.P[name + ".up.w"], self.P[name + ".up.b"], cat, batch=B, hin=ht, win=wt, cin=cout,
+                    lda=ld_top, n=4 * cout, ldc=3 * cout, out_mode=L.OUT_DECONV2X2)
+        self._conv(mid, name + ".cv1.w", name + ".cv1.b", cat[:, cout:], hin=hm, win=wm, cin=c_mid, lda=c_mid, n=cout,
+                   ldc=3 * cout, act=L.ACT_RELU)
+        self._conv(low, name + ".cv2.w", name + ".cv2.b", tbuf, hin=hl, win=wl, cin=c_low, lda=c_low, n=cout, ldc=cout,
+                   act=L.ACT_RELU)
+        self._conv(tbuf, name + ".downsample.w", name + ".downsample.b", cat[:, 2 * cout:], hin=hl, win=wl, cin=cout,
+                   lda=cout, n=cout, ldc=3 * cout, k=3, stride=2, act=L.ACT_RELU)
+        self._conv(cat, name + ".cv3.w", name + ".cv3.b", out, hin=hm, win=wm, cin=3 * cout, lda=3 * cout, n=cout,
+                   ldc=cout, act=L.ACT_RELU)
+
+    def neck(self) -> List[torch.Tensor]:
+        a = self.a
+        nc = a.neck_channels
+        c1, c2, c3, c4 = self.x
+        hw2, hw3, hw4, hw5 = self.hw
+        ld4 = nc["d1"] + nc["p5r"]
+        ld3 = nc["d2"] + nc["p4r"]
+        fpn_out0 = self.cat_n4[:, nc["d1"]:]
+        self._conv(c4, "reduce_layer0.w", "reduce_layer0.b", fpn_out0, hin=hw5[0], win=hw5[1], cin=nc["c4"],
+                   lda=nc["c4"], n=nc["p5r"], ldc=ld4, act=L.ACT_RELU)
+        self._bifusion("Bifusion0", fpn_out0, ld4, hw5, c3, nc["c3"], hw4, c2, nc["c2"], hw3, self.cat_b0, self.b0_t,
+                       self.f0, nc["p5r"])
+        self._bepc3("Rep_p4", self.f0, nc["p5r"], nc["p5r"], hw4, self.f_out0, nc["p5r"])
+        fpn_out1 = self.cat_n3[:, nc["d2"]:]
+        self._conv(self.f_out0, "reduce_layer1.w", "reduce_layer1.b", fpn_out1, hin=hw4[0], win=hw4[1], cin=nc["p5r"],
+                   lda=nc["p5r"], n=nc["p4r"], ldc=ld3, act=L.ACT_RELU)
+        self._bifusion("Bifusion1", fpn_out1, ld3, hw4, c2, nc["c2"], hw3, c1, nc["c1"], hw2, self.cat_b1, self.b1_t,
+                       self.f1, nc["p4r"])
+        self._bepc3("Rep_p3", self.f1, nc["p4r"], nc["p4r"], hw3, self.p3, nc["p4r"])
+        self._conv(self.p3, "downsample2.w", "downsample2.b", self.cat_n3, hin=hw3[0], win=hw3[1], cin=nc["p4r"],
+                   lda=nc["p4r"], n=nc["d2"], ldc=ld3, k=3, stride=2, act=L.ACT_RELU)
+        self._bepc3("Rep_n3", self.cat_n3, ld3, ld3, hw4, self.p4, nc["n3"])
+        self._conv(self.p4, "downsample1.w", "downsample1.b", self.cat_n4, hin=hw4[0], win=hw4[1], cin=nc["n3"],
+                   lda=nc["n3"], n=nc["d1"], ldc=ld4, k=3, stride=2, act=L.ACT_RELU)
+        self._bepc3("Rep_n4", self.cat_n4, ld4, ld4, hw5, self.p5, nc["n4"])
+        return [self.p3, self.p4, self.p5]
+
+    # ------------------------------------------------------------------ head
+    def head(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Region embeddings (post contrastive-BN) [B, N, 768] and decoded boxes [B, N, 4]."""
+        feats = [self.p3, self.p4, self.p5]
+        for l, (feat, cin) in enumerate(zip(feats, self.a.head_in)):
+            h, w = self.lv[l]
+            c1, c2 = self.hc[l]
+            self._conv(feat, f"head{l}.cls0.w", f"head{l}.cls0.b", c1, hin=h, win=w, cin=cin, lda=cin, n=CLS_MID,
+                       ldc=CLS_MID, k=3, act=L.ACT_SILU)
+            self._conv(c1, f"head{l}.cls1.w", f"head{l}.cls1.b", c2, hin=h, win=w, cin=CLS_MID, lda=CLS_MID, n=CLS_MID,
+                       ldc=CLS_MID, k=3, act=L.ACT_SILU)
+            dst = self.embed.view(-1, EMBED_DIM)[self.off[l]:]
+            self._conv(c2, f"head{l}.embed.w", f"head{l}.embed.b", dst, hin=h, win=w, cin=CLS_MID, lda=CLS_MID,
+                       n=EMBED_DIM, ldc=EMBED_DIM, c_batch_stride=self.ntot)
+            r1, r2, dist = self.hr[l]
+            self._conv(feat, f"head{l}.reg0.w", f"head{l}.reg0.b", r1, hin=h, win=w, cin=cin, lda=cin, n=REG_MID,
+                       ldc=REG_MID, k=3, act=L.ACT_SILU)
+            self._conv(r1, f"head{l}.reg1.w", f"head{l}.reg1.b", r2, hin=h, win=w, cin=REG_MID, lda=REG_MID, n=REG_MID,
+                       ldc=REG_MID, k=3, act=L.ACT_SILU)
+            self._conv(r2, f"head{l}.dist.w", f"head{l}.dist.b", dist, hin=h, win=w, cin=REG_MID, lda=REG_MID, n=64,
+                       ldc=64)
+            L.dfl_decode(dist, 64, self.boxes, self.B, h, w, STRIDES[l], self.off[l], self.ntot)
+        return self.embed, self.boxes
+
+    # ------------------------------------------------------------------ similarity
+    def similarity(self, text: torch.Tensor, normalize: bool, sigmoid: bool = True) -> torch.Tensor:
+        """scores[b, n, k] = sigmoid(<embed[b,n], t_k> * exp(logit_scale_lvl) + bias_lvl).
+        ``normalize``: L2-normalise the text rows first (BNContrastiveHead, yolo_world_head.py:101);
+        the Uni path uses its prompt rows as stored (generate_proposal.py:1130)."""
+        k = text.shape[0]
+        if text.dtype != torch.float32 or text.shape[1] != EMBED_DIM or not text.is_cuda:
+            raise L.WedetectHipError("text bank must be a device float32 [K, 768] tensor")
+        if k > self.max_classes:
+            self._alloc_post(k)
+        if k > self.text_norm.shape[0]:
+            self.text_norm = torch.empty(k, EMBED_DIM, dtype=torch.float32, device=self.dev)
+        t = text.contiguous()
+        if normalize:
+            L.l2norm_rows(t, self.text_norm[:k])
+            t = self.text_norm[:k]
+        out = self.scores.view(-1)[: self.B * self.ntot * k].view(self.B, self.ntot, k)
+        seg = (self.ntot, self.off[1], self.off[2], self.lvl_scale, self.lvl_bias)
+        L.conv_gemm(self.embed, t, None, out, batch=1, hin=1, win=self.B * self.ntot, cin=EMBED_DIM, lda=EMBED_DIM,
+                    n=k, ldc=k, sigmoid=sigmoid, seg=seg)
+        return out
+
+    # ------------------------------------------------------------------ post-process
+    def postprocess(self, scores: torch.Tensor, score_thr: float, meta: torch.Tensor, iou_thr: float = 0.7,
+                    with_embed: bool = True) -> Dict[str, torch.Tensor]:
+        """scores [B, N, K] -> candidates (score desc, index asc, <= nms_pre) -> class-aware NMS
+        -> <= max_out rows per image.  ``meta`` [B, 8] fp32 device tensor, see wd_nms_gather."""
+        B, n, k = scores.shape
+        L.topk_candidates(scores, B, n * k, float(np.float32(score_thr)), self.nms_pre, self.cand_idx,
+                          self.cand_score, self.cand_count, self.topk_ws)
+        L.nms_gather(self.cand_idx, self.cand_score, self.cand_count, self.cap, self.boxes, n, k, meta,
+                     float(np.float32(iou_thr)), self.max_out, self.embed if with_embed else None, EMBED_DIM,
+                     self.out_boxes, self.out_scores, self.out_labels, self.out_anchors, self.out_count,
+                     self.out_embed if with_embed else None, B)
+        res = dict(bboxes=self.out_boxes, scores=self.out_scores, labels=self.out_labels, anchors=self.out_anchors,
+                   count=self.out_count)
+        if with_embed:
+            res["embeddings"] = self.out_embed
+        return res
+
+    def identity_meta(self) -> torch.Tensor:
+        """Letterbox metadata of a network-sized image: pad 0, scale 1, clamp to H x W."""
+        m = torch.tensor([0.0, 0.0, 0.0, 1.0, 1.0, float(self.W), float(self.H), 0.0], dtype=torch.float32)
+        return m.repeat(self.B, 1).to(self.dev)
+
+    def level_of(self, anchors: torch.Tensor) -> torch.Tensor:
+        a = anchors.clamp_min(0)
+        return (a >= self.off[1]).to(torch.int64) + (a >= self.off[2]).to(torch.int64)
+
+    # ------------------------------------------------------------------ whole steps
+    def features(self, images_u8: torch.Tensor):
+        self.backbone(images_u8)
+        self.neck()
+        return self.head()
+
+    def detect(self, images_u8, text, meta, *, normalize_text: bool, score_thr: float, iou_thr: float = 0.7,
+               with_embed: bool = False):
+        self.features(images_u8)
+        scores = self.similarity(text, normalize=normalize_text)
+        return self.postprocess(scores, score_thr, meta, iou_thr, with_embed)

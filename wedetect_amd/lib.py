@@ -1,0 +1,185 @@
+"""ctypes binding of libwedetect_hip.so (declared in include/wedetect_hip.h).
+
+There is NO fallback: if the library is not built, importing this module raises
+``WedetectHipMissing``; every non-zero status raises ``WedetectHipError``.  Tensors are
+passed as raw device pointers (``tensor.data_ptr()``) and the caller's current HIP
+stream; torch is used only for memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwedetect_hip.so")
+
+ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU = 0, 1, 2, 3
+OUT_ROWS, OUT_DECONV2X2 = 0, 1
+ABI_VERSION = 1
+
+EXPORTS = (
+    "wd_abi_version", "wd_strerror", "wd_sizeof_conv_gemm", "wd_conv_gemm", "wd_conv_gemm_config", "wd_stem_patchify", "wd_dwconv7",
+    "wd_layernorm_rows", "wd_l2norm_rows", "wd_dfl_decode", "wd_topk_workspace_bytes", "wd_topk_capacity",
+    "wd_topk_candidates", "wd_nms_gather", "wd_retrieval_max",
+)
+
+
+class WedetectHipMissing(ImportError):
+    pass
+
+
+class WedetectHipError(RuntimeError):
+    pass
+
+
+class ConvGemm(C.Structure):
+    """Mirror of ``struct WdConvGemm``."""
+    _fields_ = [
+        ("a", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p), ("c", C.c_void_p),
+        ("batch", C.c_int32), ("hin", C.c_int32), ("win", C.c_int32), ("cin", C.c_int32), ("lda", C.c_int32),
+        ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("hout", C.c_int32), ("wout", C.c_int32),
+        ("m", C.c_int32), ("n", C.c_int32), ("k", C.c_int32),
+        ("ldc", C.c_int32), ("ldres", C.c_int32),
+        ("act", C.c_int32), ("out_mode", C.c_int32),
+        ("res_alpha", C.c_float), ("out_scale", C.c_float), ("out_bias", C.c_float),
+        ("sigmoid", C.c_int32),
+        ("c_batch_stride", C.c_int32),
+        ("seg_rows", C.c_int32), ("seg_end0", C.c_int32), ("seg_end1", C.c_int32),
+        ("seg_scale", C.c_float * 3), ("seg_bias", C.c_float * 3),
+    ]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise WedetectHipMissing(
+            f"{LIB_PATH} not found: build it with `python -m wedetect_amd.build` (hipcc, gfx950). "
+            "wedetect_amd has no CPU or PyTorch fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise WedetectHipMissing(f"{LIB_PATH} does not export {name}")
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    lib.wd_abi_version.restype = C.c_int
+    lib.wd_strerror.restype = C.c_char_p
+    lib.wd_strerror.argtypes = [C.c_int]
+    lib.wd_conv_gemm.argtypes = [C.POINTER(ConvGemm), vp]
+    lib.wd_conv_gemm_config.restype = C.c_char_p
+    lib.wd_conv_gemm_config.argtypes = [i32, i32, i32]
+    lib.wd_stem_patchify.argtypes = [vp, vp, i32, i32, i32, vp]
+    lib.wd_dwconv7.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.wd_layernorm_rows.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, f32, vp]
+    lib.wd_l2norm_rows.argtypes = [vp, vp, i64, i32, vp]
+    lib.wd_dfl_decode.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]
+    lib.wd_topk_workspace_bytes.restype = i64
+    lib.wd_topk_workspace_bytes.argtypes = [i32, i64, i32]
+    lib.wd_topk_capacity.restype = i32
+    lib.wd_topk_capacity.argtypes = [i32]
+    lib.wd_topk_candidates.argtypes = [vp, i32, i64, f32, i32, vp, vp, vp, vp, i64, vp]
+    lib.wd_nms_gather.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp, f32, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp]
+    lib.wd_retrieval_max.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    if lib.wd_sizeof_conv_gemm() != C.sizeof(ConvGemm):
+        raise WedetectHipMissing("struct WdConvGemm layout differs between the library and lib.ConvGemm; rebuild")
+    if lib.wd_abi_version() != ABI_VERSION:
+        raise WedetectHipMissing(f"ABI mismatch: library {lib.wd_abi_version()} vs binding {ABI_VERSION}; rebuild")
+    return lib
+
+
+LIB = _load()
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        raise WedetectHipError(f"{what} failed: {LIB.wd_strerror(status).decode()} ({status})")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise WedetectHipError(f"{name}: expected a CUDA/HIP float32 tensor, got {t.dtype} on {t.device}")
+    return t
+
+
+# ------------------------------------------------------------------------------------------
+# thin typed wrappers (pointer plumbing only)
+# ------------------------------------------------------------------------------------------
+def conv_gemm(a, w, bias, c, *, batch, hin, win, cin, lda, kh=1, kw=1, stride=1, pad=0, hout=None, wout=None,
+              n, ldc, act=ACT_NONE, res=None, ldres=0, res_alpha=1.0, out_mode=OUT_ROWS,
+              out_scale=1.0, out_bias=0.0, sigmoid=False, c_batch_stride=0, seg=None) -> None:
+    """``seg`` = (seg_rows, seg_end0, seg_end1, (s0, s1, s2), (b0, b1, b2)) or None."""
+    hout = (hin + 2 * pad - kh) // stride + 1 if hout is None else hout
+    wout = (win + 2 * pad - kw) // stride + 1 if wout is None else wout
+    p = ConvGemm(a=_p(a), w=_p(w), bias=_p(bias), res=_p(res), c=_p(c), batch=batch, hin=hin, win=win, cin=cin,
+                 lda=lda, kh=kh, kw=kw, stride=stride, pad=pad, hout=hout, wout=wout,
+                 m=batch * hout * wout, n=n, k=kh * kw * cin, ldc=ldc, ldres=ldres, act=act, out_mode=out_mode,
+                 res_alpha=res_alpha, out_scale=out_scale, out_bias=out_bias, sigmoid=int(bool(sigmoid)),
+                 c_batch_stride=c_batch_stride)
+    if seg is not None:
+        p.seg_rows, p.seg_end0, p.seg_end1 = int(seg[0]), int(seg[1]), int(seg[2])
+        p.seg_scale = (C.c_float * 3)(*[float(v) for v in seg[3]])
+        p.seg_bias = (C.c_float * 3)(*[float(v) for v in seg[4]])
+    check(LIB.wd_conv_gemm(C.byref(p), stream_ptr()), "wd_conv_gemm")
+
+
+def gemm_config(m: int, n: int, k: int) -> str:
+    return LIB.wd_conv_gemm_config(m, n, k).decode()
+
+
+def stem_patchify(img_u8: torch.Tensor, out: torch.Tensor) -> None:
+    b, h, w, _ = img_u8.shape
+    check(LIB.wd_stem_patchify(_p(img_u8), _p(out), b, h, w, stream_ptr()), "wd_stem_patchify")
+
+
+def dwconv7(x, w7, bias, y, batch, h, w, c) -> None:
+    check(LIB.wd_dwconv7(_p(x), _p(w7), _p(bias), _p(y), batch, h, w, c, stream_ptr()), "wd_dwconv7")
+
+
+def layernorm_rows(x, y, gamma, beta, rows, c, ldx=None, ldy=None, eps=1e-6) -> None:
+    check(LIB.wd_layernorm_rows(_p(x), _p(y), _p(gamma), _p(beta), rows, c, ldx or c, ldy or c, eps, stream_ptr()),
+          "wd_layernorm_rows")
+
+
+def l2norm_rows(x, y) -> None:
+    rows, c = x.shape
+    check(LIB.wd_l2norm_rows(_p(x), _p(y), rows, c, stream_ptr()), "wd_l2norm_rows")
+
+
+def dfl_decode(dist, ld, boxes, batch, hl, wl, stride, anchor_off, anchors_total) -> None:
+    check(LIB.wd_dfl_decode(_p(dist), ld, _p(boxes), batch, hl, wl, stride, anchor_off, anchors_total, stream_ptr()),
+          "wd_dfl_decode")
+
+
+def topk_capacity(nms_pre: int) -> int:
+    return LIB.wd_topk_capacity(nms_pre)
+
+
+def topk_workspace_bytes(batch: int, n: int, nms_pre: int) -> int:
+    return LIB.wd_topk_workspace_bytes(batch, n, nms_pre)
+
+
+def topk_candidates(scores, batch, n, thr, nms_pre, out_idx, out_score, out_count, workspace) -> None:
+    check(LIB.wd_topk_candidates(_p(scores), batch, n, thr, nms_pre, _p(out_idx), _p(out_score), _p(out_count),
+                                 _p(workspace), workspace.numel() * workspace.element_size(), stream_ptr()),
+          "wd_topk_candidates")
+
+
+def nms_gather(cand_idx, cand_score, cand_count, cand_stride, boxes, n_anchor, k, meta, iou_thr, max_out,
+               embed, embed_dim, out_boxes, out_scores, out_labels, out_anchors, out_count, out_embed, batch) -> None:
+    check(LIB.wd_nms_gather(_p(cand_idx), _p(cand_score), _p(cand_count), cand_stride, _p(boxes), n_anchor, k,
+                            _p(meta), iou_thr, max_out, _p(embed), embed_dim, _p(out_boxes), _p(out_scores),
+                            _p(out_labels), _p(out_anchors), _p(out_count), _p(out_embed), batch, stream_ptr()),
+          "wd_nms_gather")
+
+
+def retrieval_max(e, t, scale, bias, count, out, n_img, rows_per_img, n_cls, dim) -> None:
+    check(LIB.wd_retrieval_max(_p(e), _p(t), _p(scale), _p(bias), _p(count), _p(out), n_img, rows_per_img, n_cls, dim,
+                               stream_ptr()), "wd_retrieval_max")

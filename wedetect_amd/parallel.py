@@ -1,0 +1,62 @@
+"""Multi-GPU plumbing: one process per GPU, images sharded, one exchange step.
+
+The reference shards the image list contiguously per rank (InferenceSampler,
+eval_retrieval/extract_embedding.py:1620-1644) and, at the very end, pickles four Python
+lists of CPU tensors through ``all_gather_object`` (1753-1756).  Here the per-image results
+live in fixed-shape device tensors, so the exchange is ``all_gather_into_tensor`` on
+[B_local, 300, 768] (+ counts, scales, bias, ids) over RCCL (backend "nccl" on ROCm; "gloo"
+in the CPU tests).  The detector forward itself needs no communication (eval-mode BN).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total: int, world: int, rank: int) -> range:
+    """Contiguous shard of ``range(total)`` for ``rank`` — the same split as
+    InferenceSampler._get_local_indices (extract_embedding.py:1631-1638): the first
+    ``total % world`` ranks get one extra item."""
+    if world <= 0 or not (0 <= rank < world) or total < 0:
+        raise ValueError(f"bad shard request total={total} world={world} rank={rank}")
+    base, left = divmod(total, world)
+    begin = rank * base + min(rank, left)
+    return range(begin, begin + base + (1 if rank < left else 0))
+
+
+def gather_regions(embeddings: torch.Tensor, count: torch.Tensor, group=None) -> Dict[str, torch.Tensor]:
+    """All-gather the kept-region embeddings [B_local, R, D] and counts [B_local] of every
+    rank -> [world * B_local, R, D], [world * B_local]; rank-major order, i.e. the global
+    image order when images were sharded with ``shard_range`` and equal per-rank batches."""
+    if not dist.is_available() or not dist.is_initialized():
+        return dict(embeddings=embeddings, count=count)
+    world = dist.get_world_size(group)
+    out_e = torch.empty((world * embeddings.shape[0],) + tuple(embeddings.shape[1:]), dtype=embeddings.dtype,
+                        device=embeddings.device)
+    out_c = torch.empty(world * count.shape[0], dtype=count.dtype, device=count.device)
+    dist.all_gather_into_tensor(out_e, embeddings.contiguous(), group=group)
+    dist.all_gather_into_tensor(out_c, count.contiguous(), group=group)
+    return dict(embeddings=out_e, count=out_c)
+
+
+def gather_results(fields: Dict[str, torch.Tensor], group=None) -> Dict[str, torch.Tensor]:
+    """Same exchange for any dict of per-image tensors with a leading B_local axis (image ids,
+    scales, bias ... — the four lists of extract_embedding.py:1753-1756 in one place)."""
+    if not dist.is_available() or not dist.is_initialized():
+        return dict(fields)
+    world = dist.get_world_size(group)
+    out = {}
+    for k, v in fields.items():
+        o = torch.empty((world * v.shape[0],) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+        dist.all_gather_into_tensor(o, v.contiguous(), group=group)
+        out[k] = o
+    return out
+
+
+def shard_bank_by_class(bank: torch.Tensor, world: int, rank: int) -> torch.Tensor:
+    """Class-shard of a [K, D] text bank for the 1M-class retrieval configuration
+    (SURVEY.md §8e): every rank scores ALL gathered regions against its K/world classes."""
+    r = shard_range(bank.shape[0], world, rank)
+    return bank[r.start:r.stop]
