@@ -102,6 +102,10 @@ typedef struct WdConvGemm {
 
 int wd_conv_gemm(const WdConvGemm* p, void* stream);
 
+/* Tuning hook: launch a specific experimental tile configuration (see conv_gemm.hip).
+ * No argument validation beyond the config id; used by scripts/gemm_bench.py only. */
+int wd_conv_gemm_tuned(const WdConvGemm* p, int32_t cfg, void* stream);
+
 /* sizeof(WdConvGemm) as compiled into the library, so a binding can verify its mirror. */
 int wd_sizeof_conv_gemm(void);
 

@@ -1,0 +1,55 @@
+"""On-device A/B of wd_conv_gemm tile configurations (wd_conv_gemm_tuned) on the shapes
+that dominate WeDetect-Base B=32 @640.  Prints TFLOP/s per (shape, config) and checks every
+config against config 0's output."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from wedetect_amd import lib as L
+
+torch.manual_seed(0)
+dev = "cuda"
+SHAPES = {
+    "s3_pw1 51200x2048x512 gelu": dict(m=51200, n=2048, k=512, act=L.ACT_GELU),
+    "s3_pw2 51200x512x2048 res": dict(m=51200, n=512, k=2048, res=True),
+    "s1_pw1 819200x512x128 gelu": dict(m=819200, n=512, k=128, act=L.ACT_GELU),
+    "s2_pw2 204800x256x1024 res": dict(m=204800, n=256, k=1024, res=True),
+    "sim 268800x80x768 sigm": dict(m=268800, n=80, k=768, sim=True),
+}
+GROUPS = {"big": [0, 1, 2, 3, 4, 5, 6, 7, 8, 15], "sim": [9, 10, 11, 12, 13, 14]}
+reps = int(os.environ.get("REPS", "8"))
+only = os.environ.get("ONLY")
+for name, sh in SHAPES.items():
+    if only and only not in name:
+        continue
+    m, n, k = sh["m"], sh["n"], sh["k"]
+    a = torch.randn(m, k, device=dev)
+    w = torch.randn(n, k, device=dev) * k ** -0.5
+    b = torch.randn(n, device=dev)
+    r = torch.randn(m, n, device=dev) if sh.get("res") else None
+    ref = None
+    kw = dict(batch=1, hin=1, win=m, cin=k, lda=k, n=n, ldc=n, act=sh.get("act", L.ACT_NONE))
+    if r is not None:
+        kw.update(res=r, ldres=n)
+    if sh.get("sim"):
+        kw.update(sigmoid=True, seg=(8400, 6400, 8000, (0.7, 0.58, 0.82), (-2.6, -2.2, -1.9)))
+    for cfg in GROUPS["sim" if sh.get("sim") else "big"]:
+        c = torch.empty(m, n, device=dev)
+        try:
+            L.conv_gemm(a, w, b, c, tuned_cfg=cfg, **kw)
+            torch.cuda.synchronize()
+        except Exception as e:
+            print(f"{name:32s} cfg {cfg:2d}: FAILED {e}")
+            continue
+        if ref is None:
+            ref = c.clone()
+            err = 0.0
+        else:
+            err = float((c - ref).abs().max())
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            L.conv_gemm(a, w, b, c, tuned_cfg=cfg, **kw)
+        e.record()
+        torch.cuda.synchronize()
+        us = 1e3 * s.elapsed_time(e) / reps
+        print(f"{name:32s} cfg {cfg:2d}: {us:9.1f} us  {2.0*m*n*k/us/1e6:7.1f} TF   max|d vs first| {err:.2e}", flush=True)

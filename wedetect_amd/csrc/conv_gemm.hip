@@ -26,24 +26,32 @@
 
 namespace {
 
-constexpr int BK = 32;
-constexpr int LDS_LD = BK + 4;   // floats; 144-byte rows keep every float4 16-byte aligned
+// tuning variants (template int VAR): bit 0 = raise wave priority over the MFMA cluster,
+// bit 1 = pin an MFMA / LDS-read interleave with sched_group_barrier.
+constexpr int VAR_PRIO = 1, VAR_SGB = 2;
 
-template <int TM, int TN, int WM, int WN>
+template <int TM, int TN, int WM, int WN, int BK_ = 32>
 struct Tile {
+  static constexpr int BK = BK_;
+  static constexpr int LD = BK + 4;                      // floats; rows stay 16-byte aligned
+  static constexpr int KCH = BK / 4;                     // float4 chunks per row per K step
   static constexpr int BM = 16 * TM * WM;
   static constexpr int BN = 16 * TN * WN;
   static constexpr int NT = 64 * WM * WN;
-  static constexpr int A_PT = (BM * 8) / NT;             // float4 chunks of A per thread per K step
-  static constexpr int B_PT = (BN * 8 + NT - 1) / NT;
-  static constexpr int RSTEP = NT / 8;
-  static constexpr int LDS_BYTES = 2 * (BM + BN) * LDS_LD * 4;
-  static_assert((BM * 8) % NT == 0, "A tile must split evenly over the threads");
+  static constexpr int A_PT = (BM * KCH) / NT;           // float4 chunks of A per thread per K step
+  static constexpr int B_PT = (BN * KCH + NT - 1) / NT;
+  static constexpr int RSTEP = NT / KCH;
+  static constexpr int BN_LDS = B_PT * RSTEP;            // >= BN: every thread stores unconditionally
+  static constexpr int LDS_BYTES = 2 * (BM + BN_LDS) * LD * 4;
+  static_assert((BM * KCH) % NT == 0, "A tile must split evenly over the threads");
+  static_assert(NT % KCH == 0, "threads must tile the K chunks");
 };
 
 // ---------------------------------------------------------------------------------------
-// A-operand gather.  CONV=false: plain row-major [m][k] with row stride lda.
-// CONV=true: NHWC implicit im2col, k = (kh, kw, ci).
+// A-operand gather, branch-free: an out-of-range chunk reads the (always valid, 16-byte
+// aligned) tensor base and is zeroed by a select, so the K loop stays one basic block.
+// CONV=false: plain row-major [m][k] with row stride lda.
+// CONV=true : NHWC implicit im2col, k = (kh, kw, ci).
 // ---------------------------------------------------------------------------------------
 template <int A_PT, int RSTEP, bool CONV>
 struct ALoader {
@@ -69,14 +77,14 @@ struct ALoader {
         wi0[i] = wo * p.stride - p.pad;
         pix[i] = b * p.hin * p.win;
       } else {
-        pix[i] = m; hi0[i] = 0; wi0[i] = 0;
+        pix[i] = ok[i] ? m : 0; hi0[i] = 0; wi0[i] = 0;
       }
     }
   }
 
   __device__ __forceinline__ void load(int k, f32x4 (&reg)[A_PT]) const {
     const bool kok = k < K;
-    int kh = 0, kw = 0, ci = k;
+    int kh = 0, kw = 0, ci = kok ? k : 0;
     if (CONV) {
       const int tap = k / cin;
       ci = k - tap * cin;
@@ -85,15 +93,18 @@ struct ALoader {
     }
 #pragma unroll
     for (int i = 0; i < A_PT; ++i) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      bool valid;
+      size_t off;
       if (CONV) {
         const int hi = hi0[i] + kh, wi = wi0[i] + kw;
-        if (ok[i] && kok && (unsigned)hi < (unsigned)hin && (unsigned)wi < (unsigned)win)
-          v = *reinterpret_cast<const f32x4*>(a + (size_t)(pix[i] + hi * win + wi) * lda + ci);
+        valid = ok[i] && kok && (unsigned)hi < (unsigned)hin && (unsigned)wi < (unsigned)win;
+        off = valid ? (size_t)(pix[i] + hi * win + wi) * lda + ci : 0;
       } else {
-        if (ok[i] && kok) v = *reinterpret_cast<const f32x4*>(a + (size_t)pix[i] * lda + k);
+        valid = ok[i] && kok;
+        off = (size_t)pix[i] * lda + ci;
       }
-      reg[i] = v;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(a + off);
+      reg[i] = valid ? v : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
 };
@@ -113,9 +124,9 @@ struct RegionLoader {
   __device__ __forceinline__ void load(int k, f32x4 (&reg)[A_PT]) const {
 #pragma unroll
     for (int i = 0; i < A_PT; ++i) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (row[i] < rows && k < dim) v = *reinterpret_cast<const f32x4*>(base + (size_t)row[i] * dim + k);
-      reg[i] = v;
+      const bool valid = row[i] < rows && k < dim;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(base + (valid ? (size_t)row[i] * dim + k : 0));
+      reg[i] = valid ? v : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
 };
@@ -123,42 +134,74 @@ struct RegionLoader {
 // ---------------------------------------------------------------------------------------
 // Main loop shared by all kernels: acc[tm][tn] (+)= X[m, :] . W[n, :]
 // ---------------------------------------------------------------------------------------
-template <int TM, int TN, int WM, int WN, class AL>
+template <class T, int TM, int TN, int WN, int VAR, class AL>
 __device__ __forceinline__ void gemm_mainloop(const AL& al, const float* __restrict__ w, int n0, int N, int K,
                                               f32x4 (&acc)[TM][TN], float* smem) {
-  using T = Tile<TM, TN, WM, WN>;
-  constexpr int BM = T::BM, BN = T::BN, NT = T::NT, A_PT = T::A_PT, B_PT = T::B_PT, RSTEP = T::RSTEP;
+  constexpr int BK = T::BK, LD = T::LD, KCH = T::KCH;
+  constexpr int BM = T::BM, NT = T::NT, A_PT = T::A_PT, B_PT = T::B_PT, RSTEP = T::RSTEP, BN_LDS = T::BN_LDS;
   float* As = smem;
-  float* Bs = smem + 2 * BM * LDS_LD;
+  float* Bs = smem + 2 * BM * LD;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int kc = t & 7, r0 = t >> 3;
+  const int kc = t % KCH, r0 = t / KCH;
   const int nk = (K + BK - 1) / BK;
 
   f32x4 areg[A_PT], breg[B_PT];
+  size_t boff[B_PT];
+  bool bok[B_PT];
+#pragma unroll
+  for (int j = 0; j < B_PT; ++j) {
+    const int n = n0 + r0 + j * RSTEP;
+    bok[j] = (r0 + j * RSTEP) < T::BN && n < N;
+    boff[j] = bok[j] ? (size_t)n * K : 0;
+  }
 
   auto load_b = [&](int k) {
     const bool kok = k < K;
+    const int kk = kok ? k : 0;
 #pragma unroll
     for (int j = 0; j < B_PT; ++j) {
-      const int c = t + j * NT;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (c < BN * 8) {
-        const int n = n0 + (c >> 3);
-        if (n < N && kok) v = *reinterpret_cast<const f32x4*>(w + (size_t)n * K + k);
-      }
-      breg[j] = v;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(w + boff[j] + kk);
+      breg[j] = (bok[j] && kok) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
   auto store = [&](int buf) {
-    float* ad = As + buf * BM * LDS_LD + r0 * LDS_LD + kc * 4;
+    float* ad = As + buf * BM * LD + r0 * LD + kc * 4;
 #pragma unroll
-    for (int i = 0; i < A_PT; ++i) *reinterpret_cast<f32x4*>(ad + i * RSTEP * LDS_LD) = areg[i];
-    float* bd = Bs + buf * BN * LDS_LD;
+    for (int i = 0; i < A_PT; ++i) *reinterpret_cast<f32x4*>(ad + i * RSTEP * LD) = areg[i];
+    float* bd = Bs + buf * BN_LDS * LD + r0 * LD + kc * 4;
 #pragma unroll
-    for (int j = 0; j < B_PT; ++j) {
-      const int c = t + j * NT;
-      if (c < BN * 8) *reinterpret_cast<f32x4*>(bd + (c >> 3) * LDS_LD + (c & 7) * 4) = breg[j];
+    for (int j = 0; j < B_PT; ++j) *reinterpret_cast<f32x4*>(bd + j * RSTEP * LD) = breg[j];
+  };
+  auto compute = [&](int buf) {
+    const float* as = As + buf * BM * LD + (wm * TM * 16 + (lane & 15)) * LD + 4 * (lane >> 4);
+    const float* bs = Bs + buf * BN_LDS * LD + (wn * TN * 16 + (lane & 15)) * LD + 4 * (lane >> 4);
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      f32x4 xf[TM], wf[TN];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) xf[tm] = *reinterpret_cast<const f32x4*>(as + tm * 16 * LD + ks * 16);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) wf[tn] = *reinterpret_cast<const f32x4*>(bs + tn * 16 * LD + ks * 16);
+      if (VAR & VAR_PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[tn][r], xf[tm][r], acc[tm][tn], 0, 0, 0);
+      if (VAR & VAR_PRIO) __builtin_amdgcn_s_setprio(0);
+    }
+    if (VAR & VAR_SGB) {
+      // per 16-k half: the TM+TN fragment reads first, then the MFMAs with the next half's
+      // reads / the next tile's global loads slotted in between them
+#pragma unroll
+      for (int g = 0; g < (BK / 16) * 4 * TM * TN / 8; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);   // 8 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+      }
     }
   };
 
@@ -172,42 +215,25 @@ __device__ __forceinline__ void gemm_mainloop(const AL& al, const float* __restr
   store(0);
   __syncthreads();
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    const bool more = kt + 1 < nk;
-    if (more) {
-      const int k = (kt + 1) * BK + kc * 4;
-      al.load(k, areg);
-      load_b(k);
-    }
-    const float* as = As + cur * BM * LDS_LD + (wm * TM * 16 + (lane & 15)) * LDS_LD + 4 * (lane >> 4);
-    const float* bs = Bs + cur * BN * LDS_LD + (wn * TN * 16 + (lane & 15)) * LDS_LD + 4 * (lane >> 4);
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      f32x4 xf[TM], wf[TN];
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm) xf[tm] = *reinterpret_cast<const f32x4*>(as + tm * 16 * LDS_LD + ks * 16);
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) wf[tn] = *reinterpret_cast<const f32x4*>(bs + tn * 16 * LDS_LD + ks * 16);
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn)
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[tn][r], xf[tm][r], acc[tm][tn], 0, 0, 0);
-    }
-    if (more) store(cur ^ 1);
+  int cur = 0;
+  for (int kt = 1; kt < nk; ++kt) {
+    const int k = kt * BK + kc * 4;
+    al.load(k, areg);              // tile kt: global -> VGPR, in flight during the MFMAs of tile kt-1
+    load_b(k);
+    compute(cur);
+    store(cur ^ 1);
     __syncthreads();
+    cur ^= 1;
   }
+  compute(cur);
 }
 
 // ---------------------------------------------------------------------------------------
 // conv / linear / similarity kernel
 // ---------------------------------------------------------------------------------------
-template <int TM, int TN, int WM, int WN, bool CONV>
+template <int TM, int TN, int WM, int WN, bool CONV, int BKT = 32, int VAR = 0>
 __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const WdConvGemm p, int nbn, int vec_c, int vec_res) {
-  using T = Tile<TM, TN, WM, WN>;
+  using T = Tile<TM, TN, WM, WN, BKT>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -215,9 +241,9 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const WdConvGem
   const int m0 = bm * T::BM, n0 = bn * T::BN;
 
   ALoader<T::A_PT, T::RSTEP, CONV> al;
-  al.init(p, m0, t >> 3);
+  al.init(p, m0, t / T::KCH);
   f32x4 acc[TM][TN];
-  gemm_mainloop<TM, TN, WM, WN>(al, p.w, n0, p.n, p.k, acc, smem);
+  gemm_mainloop<T, TM, TN, WN, VAR>(al, p.w, n0, p.n, p.k, acc, smem);
 
   // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + 4*(lane>>4) + 0..3] per tile
   const int ncq = p.n >> 2;   // deconv: channels per tap
@@ -313,9 +339,9 @@ __global__ void __launch_bounds__(256) retrieval_max_kernel(const float* __restr
   const int n0 = blockIdx.x * T::BN;
 
   RegionLoader<T::A_PT, T::RSTEP> al;
-  al.init(e, img, rows_per_img, dim, t >> 3);
+  al.init(e, img, rows_per_img, dim, t / T::KCH);
   f32x4 acc[RT_TM][RT_TN];
-  gemm_mainloop<RT_TM, RT_TN, RT_WM, RT_WN>(al, tb, n0, n_cls, dim, acc, smem);
+  gemm_mainloop<T, RT_TM, RT_TN, RT_WN, 0>(al, tb, n0, n_cls, dim, acc, smem);
 
   const int cnt = count[img];
   float cmax[RT_TN][4];
@@ -368,9 +394,9 @@ __global__ void __launch_bounds__(256) retrieval_max_kernel(const float* __restr
 // ---------------------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------------------
-template <int TM, int TN, int WM, int WN>
+template <int TM, int TN, int WM, int WN, int BKT = 32, int VAR = 0>
 int launch_cfg(const WdConvGemm& p, hipStream_t st) {
-  using T = Tile<TM, TN, WM, WN>;
+  using T = Tile<TM, TN, WM, WN, BKT>;
   const bool conv = !(p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0);
   const int nbm = (p.m + T::BM - 1) / T::BM, nbn = (p.n + T::BN - 1) / T::BN;
   const long long nblk = (long long)nbm * nbn;
@@ -379,7 +405,7 @@ int launch_cfg(const WdConvGemm& p, hipStream_t st) {
   const int vec_res = p.res ? ((p.ldres % 4 == 0) && wd_aligned16(p.res)) : 0;
   static bool attr_plain = false, attr_conv = false;
   if (conv) {
-    auto k = conv_gemm_kernel<TM, TN, WM, WN, true>;
+    auto k = conv_gemm_kernel<TM, TN, WM, WN, true, BKT, VAR>;
     if (!attr_conv) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                               T::LDS_BYTES) != hipSuccess) return WD_ERR_LAUNCH;
@@ -387,7 +413,7 @@ int launch_cfg(const WdConvGemm& p, hipStream_t st) {
     }
     hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(T::NT), T::LDS_BYTES, st, p, nbn, vec_c, vec_res);
   } else {
-    auto k = conv_gemm_kernel<TM, TN, WM, WN, false>;
+    auto k = conv_gemm_kernel<TM, TN, WM, WN, false, BKT, VAR>;
     if (!attr_plain) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                               T::LDS_BYTES) != hipSuccess) return WD_ERR_LAUNCH;
@@ -456,6 +482,33 @@ extern "C" int wd_conv_gemm(const WdConvGemm* pp, void* stream) {
     case 80: return launch_cfg<4, 5, 4, 1>(p, st);
     case 64: return launch_cfg<4, 4, 4, 1>(p, st);
     default: return launch_cfg<4, 3, 4, 1>(p, st);
+  }
+}
+
+// Experimental tile configurations for on-device A/B runs (scripts/gemm_bench.py); not used
+// by the product path until a winner is promoted into wd_conv_gemm's table.
+extern "C" int wd_conv_gemm_tuned(const WdConvGemm* pp, int32_t cfg, void* stream) {
+  if (!pp) return WD_ERR_BAD_ARG;
+  const WdConvGemm& p = *pp;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (cfg) {
+    case 0: return launch_cfg<4, 4, 2, 2, 32, 0>(p, st);            // 128x128x32, 4 waves
+    case 1: return launch_cfg<4, 4, 2, 2, 32, VAR_PRIO>(p, st);
+    case 2: return launch_cfg<4, 4, 2, 2, 32, VAR_SGB>(p, st);
+    case 3: return launch_cfg<4, 4, 2, 2, 32, VAR_PRIO | VAR_SGB>(p, st);
+    case 4: return launch_cfg<4, 4, 4, 2, 32, 0>(p, st);            // 256x128x32, 8 waves
+    case 5: return launch_cfg<4, 4, 4, 2, 32, VAR_PRIO>(p, st);
+    case 6: return launch_cfg<4, 4, 2, 2, 16, 0>(p, st);            // 128x128x16, 4 waves (3-4 blocks/CU)
+    case 7: return launch_cfg<4, 4, 2, 4, 32, 0>(p, st);            // 128x256x32, 8 waves
+    case 8: return launch_cfg<2, 4, 4, 2, 32, 0>(p, st);            // 128x128x32, 8 waves (32x64 wave tiles)
+    case 9: return launch_cfg<4, 5, 4, 1, 32, 0>(p, st);            // 256x80x32, 4 waves
+    case 10: return launch_cfg<2, 5, 8, 1, 32, 0>(p, st);           // 256x80x32, 8 waves
+    case 11: return launch_cfg<3, 5, 4, 1, 32, 0>(p, st);           // 192x80x32, 4 waves
+    case 12: return launch_cfg<2, 5, 4, 1, 32, 0>(p, st);           // 128x80x32, 4 waves
+    case 13: return launch_cfg<4, 5, 4, 1, 16, 0>(p, st);           // 256x80x16, 4 waves
+    case 14: return launch_cfg<3, 5, 4, 1, 32, VAR_PRIO>(p, st);
+    case 15: return launch_cfg<4, 4, 2, 2, 64, 0>(p, st);            // 128x128x64, 4 waves (1 block/CU)
+    default: return WD_ERR_UNSUPPORTED;
   }
 }
 

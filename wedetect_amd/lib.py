@@ -20,7 +20,7 @@ OUT_ROWS, OUT_DECONV2X2 = 0, 1
 ABI_VERSION = 1
 
 EXPORTS = (
-    "wd_abi_version", "wd_strerror", "wd_sizeof_conv_gemm", "wd_conv_gemm", "wd_conv_gemm_config", "wd_stem_patchify", "wd_dwconv7",
+    "wd_abi_version", "wd_strerror", "wd_sizeof_conv_gemm", "wd_conv_gemm", "wd_conv_gemm_tuned", "wd_conv_gemm_config", "wd_stem_patchify", "wd_dwconv7",
     "wd_layernorm_rows", "wd_l2norm_rows", "wd_dfl_decode", "wd_topk_workspace_bytes", "wd_topk_capacity",
     "wd_topk_candidates", "wd_nms_gather", "wd_retrieval_max",
 )
@@ -66,6 +66,7 @@ def _load():
     lib.wd_strerror.restype = C.c_char_p
     lib.wd_strerror.argtypes = [C.c_int]
     lib.wd_conv_gemm.argtypes = [C.POINTER(ConvGemm), vp]
+    lib.wd_conv_gemm_tuned.argtypes = [C.POINTER(ConvGemm), i32, vp]
     lib.wd_conv_gemm_config.restype = C.c_char_p
     lib.wd_conv_gemm_config.argtypes = [i32, i32, i32]
     lib.wd_stem_patchify.argtypes = [vp, vp, i32, i32, i32, vp]
@@ -114,7 +115,7 @@ def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------
 def conv_gemm(a, w, bias, c, *, batch, hin, win, cin, lda, kh=1, kw=1, stride=1, pad=0, hout=None, wout=None,
               n, ldc, act=ACT_NONE, res=None, ldres=0, res_alpha=1.0, out_mode=OUT_ROWS,
-              out_scale=1.0, out_bias=0.0, sigmoid=False, c_batch_stride=0, seg=None) -> None:
+              out_scale=1.0, out_bias=0.0, sigmoid=False, c_batch_stride=0, seg=None, tuned_cfg=None) -> None:
     """``seg`` = (seg_rows, seg_end0, seg_end1, (s0, s1, s2), (b0, b1, b2)) or None."""
     hout = (hin + 2 * pad - kh) // stride + 1 if hout is None else hout
     wout = (win + 2 * pad - kw) // stride + 1 if wout is None else wout
@@ -127,6 +128,9 @@ def conv_gemm(a, w, bias, c, *, batch, hin, win, cin, lda, kh=1, kw=1, stride=1,
         p.seg_rows, p.seg_end0, p.seg_end1 = int(seg[0]), int(seg[1]), int(seg[2])
         p.seg_scale = (C.c_float * 3)(*[float(v) for v in seg[3]])
         p.seg_bias = (C.c_float * 3)(*[float(v) for v in seg[4]])
+    if tuned_cfg is not None:
+        check(LIB.wd_conv_gemm_tuned(C.byref(p), int(tuned_cfg), stream_ptr()), f"wd_conv_gemm_tuned[{tuned_cfg}]")
+        return
     check(LIB.wd_conv_gemm(C.byref(p), stream_ptr()), "wd_conv_gemm")
 
 
