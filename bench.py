@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--classes", type=int, default=80)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=2)
+    ap.add_argument("--cpu-images", type=int, default=8)
     return ap.parse_args()
 
 
@@ -89,6 +89,19 @@ class GemmTimer:
         return out
 
 
+def usable_cores() -> int:
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota
+    (the GPU box exposes 256 logical CPUs but a 16-CPU quota; oversubscribing it is ~50x slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(arch, size, classes, n_images):
     """The oracle (CPU port of the reference's PyTorch path) on a bounded sample: n_images
     single-image passes of the same workload, all host cores."""
@@ -96,7 +109,7 @@ def cpu_baseline(arch, size, classes, n_images):
     from oracle import ref_cpu as orc
     from wedetect_amd import weights as W
     from wedetect_amd.arch import get_arch
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(usable_cores())
     a = get_arch(arch)
     sd = orc.to_torch(W.make_state_dict(arch))
     text = torch.from_numpy(W.make_text_bank(classes))

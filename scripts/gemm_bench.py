@@ -15,7 +15,19 @@ SHAPES = {
     "s2_pw2 204800x256x1024 res": dict(m=204800, n=256, k=1024, res=True),
     "sim 268800x80x768 sigm": dict(m=268800, n=80, k=768, sim=True),
 }
-GROUPS = {"big": [0, 1, 2, 3, 4, 5, 6, 7, 8, 15], "sim": [9, 10, 11, 12, 13, 14]}
+GROUPS = {"big": ["old", 0, 8, 16, 17, 18, 21, 29, 31, 32], "sim": ["old", 9, 12, 23, 24, 26, 28, 30]}
+import ctypes
+_old_path = os.path.join(os.path.dirname(L.LIB_PATH), "libwedetect_old_gemm.so")
+OLD = ctypes.CDLL(_old_path) if os.path.exists(_old_path) else None
+if OLD is not None:
+    OLD.wd_conv_gemm.argtypes = [ctypes.POINTER(L.ConvGemm), ctypes.c_void_p]
+    _orig_check = L.LIB.wd_conv_gemm_tuned
+
+    class _Shim:
+        """route tuned_cfg="old" to the round-1 first-cut kernel kept for A/B"""
+    def _old_call(p, cfg, stream):
+        return OLD.wd_conv_gemm(p, stream)
+
 reps = int(os.environ.get("REPS", "8"))
 only = os.environ.get("ONLY")
 for name, sh in SHAPES.items():
@@ -32,13 +44,26 @@ for name, sh in SHAPES.items():
         kw.update(res=r, ldres=n)
     if sh.get("sim"):
         kw.update(sigmoid=True, seg=(8400, 6400, 8000, (0.7, 0.58, 0.82), (-2.6, -2.2, -1.9)))
+    def run(cfg, c):
+        if cfg == "old":
+            if OLD is None:
+                raise RuntimeError("old lib not present")
+            saved = L.LIB.wd_conv_gemm
+            L.LIB.__dict__["wd_conv_gemm"] = OLD.wd_conv_gemm
+            try:
+                L.conv_gemm(a, w, b, c, **kw)
+            finally:
+                L.LIB.__dict__["wd_conv_gemm"] = saved
+        else:
+            L.conv_gemm(a, w, b, c, tuned_cfg=cfg, **kw)
+
     for cfg in GROUPS["sim" if sh.get("sim") else "big"]:
         c = torch.empty(m, n, device=dev)
         try:
-            L.conv_gemm(a, w, b, c, tuned_cfg=cfg, **kw)
+            run(cfg, c)
             torch.cuda.synchronize()
         except Exception as e:
-            print(f"{name:32s} cfg {cfg:2d}: FAILED {e}")
+            print(f"{name:32s} cfg {cfg!s:>3}: FAILED {e}")
             continue
         if ref is None:
             ref = c.clone()
@@ -48,8 +73,8 @@ for name, sh in SHAPES.items():
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         for _ in range(reps):
-            L.conv_gemm(a, w, b, c, tuned_cfg=cfg, **kw)
+            run(cfg, c)
         e.record()
         torch.cuda.synchronize()
         us = 1e3 * s.elapsed_time(e) / reps
-        print(f"{name:32s} cfg {cfg:2d}: {us:9.1f} us  {2.0*m*n*k/us/1e6:7.1f} TF   max|d vs first| {err:.2e}", flush=True)
+        print(f"{name:32s} cfg {cfg!s:>3}: {us:9.1f} us  {2.0*m*n*k/us/1e6:7.1f} TF   max|d vs first| {err:.2e}", flush=True)

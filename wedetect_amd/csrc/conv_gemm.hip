@@ -30,6 +30,12 @@ namespace {
 // bit 1 = pin an MFMA / LDS-read interleave with sched_group_barrier.
 constexpr int VAR_PRIO = 1, VAR_SGB = 2;
 
+// Out-of-range operand chunks (M/N/K tails, conv zero padding) are READ from this zero
+// block instead of being masked after the load: the K loop stays branch-free and the loaded
+// registers have no consumer before the LDS store, so the loads stay in flight across the
+// whole MFMA phase.
+__device__ __attribute__((aligned(16))) float g_zero4[4] = {0.f, 0.f, 0.f, 0.f};
+
 template <int TM, int TN, int WM, int WN, int BK_ = 32>
 struct Tile {
   static constexpr int BK = BK_;
@@ -48,8 +54,7 @@ struct Tile {
 };
 
 // ---------------------------------------------------------------------------------------
-// A-operand gather, branch-free: an out-of-range chunk reads the (always valid, 16-byte
-// aligned) tensor base and is zeroed by a select, so the K loop stays one basic block.
+// A-operand gather, branch-free: an out-of-range chunk reads g_zero4.
 // CONV=false: plain row-major [m][k] with row stride lda.
 // CONV=true : NHWC implicit im2col, k = (kh, kw, ci).
 // ---------------------------------------------------------------------------------------
@@ -98,13 +103,12 @@ struct ALoader {
       if (CONV) {
         const int hi = hi0[i] + kh, wi = wi0[i] + kw;
         valid = ok[i] && kok && (unsigned)hi < (unsigned)hin && (unsigned)wi < (unsigned)win;
-        off = valid ? (size_t)(pix[i] + hi * win + wi) * lda + ci : 0;
+        off = (size_t)(pix[i] + hi * win + wi) * lda + ci;
       } else {
         valid = ok[i] && kok;
         off = (size_t)pix[i] * lda + ci;
       }
-      const f32x4 v = *reinterpret_cast<const f32x4*>(a + off);
-      reg[i] = valid ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      reg[i] = *reinterpret_cast<const f32x4*>(valid ? a + off : g_zero4);
     }
   }
 };
@@ -125,8 +129,7 @@ struct RegionLoader {
 #pragma unroll
     for (int i = 0; i < A_PT; ++i) {
       const bool valid = row[i] < rows && k < dim;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(base + (valid ? (size_t)row[i] * dim + k : 0));
-      reg[i] = valid ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      reg[i] = *reinterpret_cast<const f32x4*>(valid ? base + (size_t)row[i] * dim + k : g_zero4);
     }
   }
 };
@@ -160,10 +163,8 @@ __device__ __forceinline__ void gemm_mainloop(const AL& al, const float* __restr
     const bool kok = k < K;
     const int kk = kok ? k : 0;
 #pragma unroll
-    for (int j = 0; j < B_PT; ++j) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(w + boff[j] + kk);
-      breg[j] = (bok[j] && kok) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int j = 0; j < B_PT; ++j)
+      breg[j] = *reinterpret_cast<const f32x4*>((bok[j] && kok) ? w + boff[j] + kk : g_zero4);
   };
   auto store = [&](int buf) {
     float* ad = As + buf * BM * LD + r0 * LD + kc * 4;
@@ -440,14 +441,17 @@ int pick_bn(int n) {
 
 }  // namespace
 
+// Production tile table (picked on device with scripts/gemm_bench.py, profiles/r01_gemm_ab.txt):
+// K step 16 and 8 waves per workgroup keep 4-5 waves per SIMD resident, which is what keeps
+// the fp32 MFMA pipe busy; results are bit-identical across configurations (same k order).
 extern "C" const char* wd_conv_gemm_config(int32_t m, int32_t n, int32_t k) {
   (void)m; (void)k;
   switch (pick_bn(n)) {
-    case 128: return "128x128x32/4w";
-    case 96: return "256x96x32/4w";
-    case 80: return "256x80x32/4w";
-    case 64: return "256x64x32/4w";
-    default: return "256x48x32/4w";
+    case 128: return "128x128x16/8w";
+    case 96: return "128x96x16/8w";
+    case 80: return "128x80x16/8w";
+    case 64: return "128x64x16/8w";
+    default: return "128x48x16/8w";
   }
 }
 
@@ -477,11 +481,11 @@ extern "C" int wd_conv_gemm(const WdConvGemm* pp, void* stream) {
     return WD_ERR_BAD_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (pick_bn(p.n)) {
-    case 128: return launch_cfg<4, 4, 2, 2>(p, st);
-    case 96: return launch_cfg<4, 6, 4, 1>(p, st);
-    case 80: return launch_cfg<4, 5, 4, 1>(p, st);
-    case 64: return launch_cfg<4, 4, 4, 1>(p, st);
-    default: return launch_cfg<4, 3, 4, 1>(p, st);
+    case 128: return launch_cfg<2, 4, 4, 2, 16>(p, st);
+    case 96: return launch_cfg<1, 6, 8, 1, 16>(p, st);
+    case 80: return launch_cfg<1, 5, 8, 1, 16>(p, st);
+    case 64: return launch_cfg<1, 4, 8, 1, 16>(p, st);
+    default: return launch_cfg<1, 3, 8, 1, 16>(p, st);
   }
 }
 
@@ -508,6 +512,22 @@ extern "C" int wd_conv_gemm_tuned(const WdConvGemm* pp, int32_t cfg, void* strea
     case 13: return launch_cfg<4, 5, 4, 1, 16, 0>(p, st);           // 256x80x16, 4 waves
     case 14: return launch_cfg<3, 5, 4, 1, 32, VAR_PRIO>(p, st);
     case 15: return launch_cfg<4, 4, 2, 2, 64, 0>(p, st);            // 128x128x64, 4 waves (1 block/CU)
+    case 16: return launch_cfg<2, 4, 4, 2, 32, VAR_PRIO>(p, st);
+    case 17: return launch_cfg<2, 4, 4, 2, 16, 0>(p, st);            // 128x128x16, 8 waves
+    case 18: return launch_cfg<2, 2, 4, 4, 32, 0>(p, st);            // 128x128x32, 16 waves
+    case 20: return launch_cfg<2, 4, 2, 2, 32, 0>(p, st);            // 64x128x32, 4 waves
+    case 21: return launch_cfg<1, 4, 8, 2, 32, 0>(p, st);            // 128x128x32, 16 waves (16x64 wave tiles)
+    case 22: return launch_cfg<2, 4, 8, 2, 32, 0>(p, st);            // 256x128x32, 16 waves
+    case 23: return launch_cfg<1, 5, 8, 1, 32, 0>(p, st);            // 128x80x32, 8 waves
+    case 24: return launch_cfg<2, 5, 8, 1, 16, 0>(p, st);            // 256x80x16, 8 waves
+    case 25: return launch_cfg<1, 5, 16, 1, 32, 0>(p, st);           // 256x80x32, 16 waves
+    case 26: return launch_cfg<2, 5, 4, 1, 16, 0>(p, st);            // 128x80x16, 4 waves
+    case 27: return launch_cfg<2, 5, 8, 1, 32, VAR_PRIO>(p, st);
+    case 28: return launch_cfg<1, 5, 4, 1, 32, 0>(p, st);            // 64x80x32, 4 waves
+    case 29: return launch_cfg<2, 4, 4, 2, 16, VAR_PRIO>(p, st);
+    case 30: return launch_cfg<1, 5, 8, 1, 16, 0>(p, st);            // 128x80x16, 8 waves
+    case 31: return launch_cfg<2, 2, 4, 4, 32, VAR_PRIO>(p, st);
+    case 32: return launch_cfg<2, 4, 8, 2, 16, 0>(p, st);            // 256x128x16, 16 waves
     default: return WD_ERR_UNSUPPORTED;
   }
 }
