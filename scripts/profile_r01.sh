@@ -2,12 +2,12 @@
 # rocprofv3 evidence for round 1 (run on the GPU box from the repo root).
 set -x
 export TMPDIR=/tmp
-OUT=$PWD/gpurun_out/prof
+OUT=$PWD/gpurun_out/prof_b
 mkdir -p $OUT
 CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o r01 -- $CMD > $OUT/trace_bench.json 2> $OUT/trace.err
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F32 -d $OUT/pmc_sq -o r01 -- $CMD > /dev/null 2> $OUT/pmc_sq.err
-rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o r01 -- $CMD > /dev/null 2> $OUT/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o r01 -- $CMD > /dev/null 2> $OUT/pmc_write.err
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o r01b -- $CMD > $OUT/trace_bench.json 2> $OUT/trace.err
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -d $OUT/pmc_sq -o r01b -- $CMD > /dev/null 2> $OUT/pmc_sq.err
+rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o r01b -- $CMD > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o r01b -- $CMD > /dev/null 2> $OUT/pmc_write.err
 find $OUT -name "*.csv" | head -30
 ls -la $OUT/*

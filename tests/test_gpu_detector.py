@@ -1,0 +1,158 @@
+"""Operator-surface parity (GPU): the drop-in detector classes against the CPU oracle, plus the
+larger BASELINE configurations (LVIS-size bank, big retrieval bank)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import assert_close, to_np
+
+pytestmark = pytest.mark.gpu
+
+
+def _images():
+    from PIL import Image
+    g = np.random.default_rng(3)
+    return [Image.fromarray(g.integers(0, 256, (h, w, 3), dtype=np.uint8)) for h, w in ((120, 200), (128, 64), (90, 90))]
+
+
+def test_simple_yolo_world_detector_matches_oracle_with_letterbox():
+    """generate_proposal.py:1082-1117 end to end: PIL letterbox -> tower -> head_predict -> un-letterbox."""
+    from oracle import postprocess as opp
+    from oracle import ref_cpu as orc
+    from wedetect_amd import weights as W
+    from wedetect_amd.arch import HD, get_arch
+    from wedetect_amd.detector import SimpleYOLOWorldDetector, letterbox
+    sd_np = W.make_state_dict("nano", num_prompts=32)
+    model = SimpleYOLOWorldDetector("nano", prompt_dim=768, num_prompts=32, num_proposals=100)
+    msg = model.load_state_dict({k: torch.from_numpy(v) for k, v in W.to_uni_keys(sd_np).items()}, strict=False)
+    assert not msg.missing_keys
+    model = model.cuda()
+    model.eval()
+    imgs = _images()
+    outs = model(imgs)
+    assert len(outs) == 3
+    sd = orc.to_torch(sd_np)
+    ls = np.asarray([sd[HD + f"cls_contrasts.{l}.logit_scale"].item() for l in range(3)], np.float32)
+    cb = np.asarray([sd[HD + f"cls_contrasts.{l}.bias"].item() for l in range(3)], np.float32)
+    for img, out in zip(imgs, outs):
+        lb, ratio, (dw, dh) = letterbox(img, (128, 128))
+        x = np.asarray(lb, dtype=np.uint8)[None]
+        with torch.no_grad():
+            _, p = orc.forward_features(sd, get_arch("nano"), x)
+            flat = orc.head_flat(sd, p, sd["embeddings"], normalize_text=False)
+        o = opp.uni_predict_image(flat["boxes"][0].numpy(), flat["embed"][0].numpy(), flat["scores"][0].numpy(),
+                                  flat["level_of"].numpy(), ls, cb, num_proposals=100)
+        n = o["scores"].shape[0]
+        assert out["scores"].shape[0] == n and out["labels"].dtype == torch.int64
+        assert_close("uni scores", out["scores"], o["scores"], 1e-3)
+        same = np.mean(to_np(out["labels"]) == o["labels"])
+        assert same > 0.97, f"labels agree on {same:.3f}"
+        ref_boxes = opp.unletterbox(o["bboxes"], (dw, dh), ratio, (img.size[1], img.size[0]))
+        ok = to_np(out["labels"]) == o["labels"]
+        assert_close("uni boxes (original pixels)", to_np(out["bboxes"])[ok], ref_boxes[ok], 5e-2, 1e-5)
+        assert_close("uni embeddings", to_np(out["embeddings"])[ok], o["embeddings"][ok], 1e-3, 1e-3)
+        assert_close("scales", to_np(out["scales"])[ok], o["scales"][ok], 0)
+        assert_close("bias", to_np(out["bias"])[ok], o["bias"][ok], 0)
+        assert float(out["bboxes"].min()) >= 0 and float(out["bboxes"][:, 0::2].max()) <= img.size[0]
+
+
+def test_yolo_world_detector_test_step_matches_oracle():
+    """infer_wedetect.py:102-131: BGR CHW uint8 inputs + data samples with letterbox metadata."""
+    from oracle import postprocess as opp
+    from oracle import ref_cpu as orc
+    from wedetect_amd import weights as W
+    from wedetect_amd.arch import get_arch
+    from wedetect_amd.detector import DetDataSample, YOLOWorldDetector
+    sd_np = W.make_state_dict("nano")
+    k = 81                                                       # 80 classes + the blank the demo appends
+    bank = W.make_text_bank(k) * np.float32(2.5)
+    model = YOLOWorldDetector("nano", test_cfg=dict(max_per_img=50), max_classes=k)
+    model.load_state_dict({"state_dict": {n: torch.from_numpy(v) for n, v in sd_np.items()}})
+    model.cuda().eval()
+    with pytest.raises(RuntimeError):
+        model.test_step(dict(inputs=[torch.zeros(3, 128, 128, dtype=torch.uint8)], data_samples=[DetDataSample()]))
+    model.set_text_embeddings(torch.from_numpy(bank))
+    rgb = W.make_images(2, 128, 128, seed=77)
+    bgr_chw = [torch.from_numpy(np.ascontiguousarray(im[..., ::-1].transpose(2, 0, 1))) for im in rgb]
+    metas = [dict(ori_shape=(200, 256), scale_factor=(0.5, 0.5), pad_param=np.array([14., 14., 0., 0.])),
+             dict(ori_shape=(128, 100), scale_factor=(1.0, 1.0), pad_param=np.array([0., 0., 14., 14.]))]
+    samples = [DetDataSample(metainfo=m) for m in metas]
+    res = model.test_step(dict(inputs=bgr_chw, data_samples=samples))
+    sd = orc.to_torch(sd_np)
+    with torch.no_grad():
+        _, p = orc.forward_features(sd, get_arch("nano"), rgb)
+        flat = orc.head_flat(sd, p, torch.from_numpy(bank), normalize_text=True)
+    for i, (m, r) in enumerate(zip(metas, res)):
+        o = opp.mmdet_predict_image(flat["boxes"][i].numpy(), flat["scores"][i].numpy(), m["pad_param"],
+                                    m["scale_factor"], m["ori_shape"], max_per_img=50)
+        pi = r.pred_instances
+        assert len(pi) == o["scores"].shape[0] == 50
+        assert_close("det scores", pi.scores, o["scores"], 1e-3)
+        ok = to_np(pi.labels) == o["labels"]
+        assert ok.mean() > 0.95
+        assert_close("det boxes", to_np(pi.bboxes)[ok], o["bboxes"][ok], 5e-2, 1e-5)
+        keep = pi[pi.scores > float(np.median(o["scores"]))]
+        assert 0 < len(keep) <= 50 and keep.cpu().numpy()["bboxes"].shape[1] == 4
+
+
+def test_large_lvis_bank_config3_small_input():
+    """WeDetect-Large tower with a 1203-class bank (BASELINE configs[2]) at 128x128 so the CPU
+    oracle stays quick: scores parity and exact post-process on >400k candidates per image."""
+    from oracle import postprocess as opp
+    from oracle import ref_cpu as orc
+    from wedetect_amd import weights as W
+    from wedetect_amd.arch import get_arch
+    from wedetect_amd.engine import ImageTower
+    from wedetect_amd.pack import pack
+    arch, b, hw, k = "large", 2, 128, 1203
+    sd_np = W.make_state_dict(arch)
+    tower = ImageTower(arch, pack(sd_np, arch), b, hw, hw, max_classes=k)
+    imgs = W.make_images(b, hw, hw)
+    bank = W.make_text_bank(k)
+    sd = orc.to_torch(sd_np)
+    with torch.no_grad():
+        _, p = orc.forward_features(sd, get_arch(arch), imgs)
+        flat = orc.head_flat(sd, p, torch.from_numpy(bank), normalize_text=True)
+    meta = tower.identity_meta()
+    meta[:, 7] = 1.0
+    res = tower.detect(torch.from_numpy(imgs).cuda(), torch.from_numpy(bank).cuda(), meta, normalize_text=True,
+                       score_thr=0.001)
+    scores, boxes = to_np(tower.scores.view(-1)[: b * tower.ntot * k].view(b, tower.ntot, k)), to_np(tower.boxes)
+    assert_close("large scores K=1203", scores, flat["scores"], 1e-3)
+    for i in range(b):
+        o = opp.mmdet_predict_image(boxes[i], scores[i], None, (1.0, 1.0), (hw, hw))
+        n = int(res["count"][i])
+        assert n == o["scores"].shape[0]
+        assert np.array_equal(to_np(res["anchors"][i, :n]), o["anchors"])
+        assert np.array_equal(to_np(res["labels"][i, :n]), o["labels"])
+        assert np.array_equal(to_np(res["bboxes"][i, :n]), o["bboxes"])
+
+
+def test_retrieval_big_bank_properties():
+    """configs[4]-style retrieval: 300 regions x 200k-class bank per image without materialising
+    logits.  Checked against chunked fp64 math on a sample of classes, and for the class-shard
+    identity: scoring bank shards separately == scoring the whole bank."""
+    from wedetect_amd import lib as L
+    from wedetect_amd import weights as W
+    from wedetect_amd.parallel import shard_range
+    n_img, rows, k = 2, 300, 200_000
+    g = torch.Generator(device="cuda").manual_seed(5)
+    e = torch.randn(n_img, rows, 768, device="cuda", generator=g) * 1.4
+    t = torch.nn.functional.normalize(torch.randn(k, 768, device="cuda", generator=g), dim=-1)
+    scale = torch.full((n_img, rows), -0.35, device="cuda")
+    bias = torch.full((n_img, rows), -2.6, device="cuda")
+    cnt = torch.tensor([300, 211], dtype=torch.int32, device="cuda")
+    out = torch.empty(n_img, k, device="cuda")
+    L.retrieval_max(e, t, scale, bias, cnt, out, n_img, rows, k, 768)
+    idx = torch.randint(0, k, (512,), device="cuda", generator=g)
+    for i in range(n_img):
+        lg = e[i, : int(cnt[i])].double() @ t[idx].double().T
+        ref = torch.sigmoid(lg * float(np.exp(np.float32(-0.35))) - 2.6).max(dim=0)[0]
+        assert_close(f"retrieval img{i} sampled classes", out[i, idx], ref, 2e-6, 1e-5)
+    parts = []
+    for r in range(8):
+        sr = shard_range(k, 8, r)
+        o = torch.empty(n_img, len(sr), device="cuda")
+        L.retrieval_max(e, t[sr.start:sr.stop].contiguous(), scale, bias, cnt, o, n_img, rows, len(sr), 768)
+        parts.append(o)
+    assert torch.equal(torch.cat(parts, dim=1), out), "class-sharded scoring must equal whole-bank scoring bit for bit"
