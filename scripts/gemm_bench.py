@@ -10,12 +10,18 @@ torch.manual_seed(0)
 dev = "cuda"
 SHAPES = {
     "s3_pw1 51200x2048x512 gelu": dict(m=51200, n=2048, k=512, act=L.ACT_GELU),
+    "s3_pw1 51200x2048x512 noact": dict(m=51200, n=2048, k=512),
     "s3_pw2 51200x512x2048 res": dict(m=51200, n=512, k=2048, res=True),
     "s1_pw1 819200x512x128 gelu": dict(m=819200, n=512, k=128, act=L.ACT_GELU),
     "s2_pw2 204800x256x1024 res": dict(m=204800, n=256, k=1024, res=True),
     "sim 268800x80x768 sigm": dict(m=268800, n=80, k=768, sim=True),
+    "conv3 128->128 @40 silu": dict(conv=(32, 40, 40, 128, 128)),
+    "conv3 64->64 @80 silu": dict(conv=(32, 80, 80, 64, 64)),
+    "conv3 256->256 @20 silu": dict(conv=(32, 20, 20, 256, 256)),
+    "conv3 128->256 @80 silu": dict(conv=(32, 80, 80, 128, 256)),
+    "conv3 512->256 @20 silu": dict(conv=(32, 20, 20, 512, 256)),
 }
-GROUPS = {"big": ["old", 0, 8, 16, 17, 18, 21, 29, 31, 32], "sim": ["old", 9, 12, 23, 24, 26, 28, 30]}
+GROUPS = {"big": [17, 62, 42, 17, 62, 42], "sim": [30], "conv": [None, 17, 50, 51, 52, 53, 54]}
 import ctypes
 _old_path = os.path.join(os.path.dirname(L.LIB_PATH), "libwedetect_old_gemm.so")
 OLD = ctypes.CDLL(_old_path) if os.path.exists(_old_path) else None
@@ -33,13 +39,20 @@ only = os.environ.get("ONLY")
 for name, sh in SHAPES.items():
     if only and only not in name:
         continue
-    m, n, k = sh["m"], sh["n"], sh["k"]
-    a = torch.randn(m, k, device=dev)
+    if "conv" in sh:
+        bb, hh, ww, ci, co = sh["conv"]
+        m, n, k = bb * hh * ww, co, 9 * ci
+        a = torch.randn(bb * hh * ww, ci, device=dev)
+    else:
+        m, n, k = sh["m"], sh["n"], sh["k"]
+        a = torch.randn(m, k, device=dev)
     w = torch.randn(n, k, device=dev) * k ** -0.5
     b = torch.randn(n, device=dev)
     r = torch.randn(m, n, device=dev) if sh.get("res") else None
     ref = None
     kw = dict(batch=1, hin=1, win=m, cin=k, lda=k, n=n, ldc=n, act=sh.get("act", L.ACT_NONE))
+    if "conv" in sh:
+        kw = dict(batch=bb, hin=hh, win=ww, cin=ci, lda=ci, kh=3, kw=3, stride=1, pad=1, n=n, ldc=n, act=L.ACT_SILU)
     if r is not None:
         kw.update(res=r, ldres=n)
     if sh.get("sim"):
@@ -54,10 +67,12 @@ for name, sh in SHAPES.items():
                 L.conv_gemm(a, w, b, c, **kw)
             finally:
                 L.LIB.__dict__["wd_conv_gemm"] = saved
+        elif cfg is None:
+            L.conv_gemm(a, w, b, c, **kw)
         else:
             L.conv_gemm(a, w, b, c, tuned_cfg=cfg, **kw)
 
-    for cfg in GROUPS["sim" if sh.get("sim") else "big"]:
+    for cfg in GROUPS["sim" if sh.get("sim") else "conv" if "conv" in sh else "big"]:
         c = torch.empty(m, n, device=dev)
         try:
             run(cfg, c)
@@ -70,6 +85,8 @@ for name, sh in SHAPES.items():
             err = 0.0
         else:
             err = float((c - ref).abs().max())
+        for _ in range(3):
+            run(cfg, c)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         for _ in range(reps):

@@ -29,6 +29,13 @@ namespace {
 // tuning variants (template int VAR): bit 0 = raise wave priority over the MFMA cluster,
 // bit 1 = pin an MFMA / LDS-read interleave with sched_group_barrier.
 constexpr int VAR_PRIO = 1, VAR_SGB = 2;
+// timing-only ablations (WRONG results by construction; reachable only through
+// wd_conv_gemm_tuned): skip the in-loop global loads / the in-loop barrier / the epilogue math
+constexpr int ABL_NOLOAD = 4, ABL_NOBAR = 8, ABL_NOEPI = 16, ABL_NOLDS = 32;
+// bit 6: delay the second co-resident workgroup of every CU by half a tile at kernel start so
+// that the two workgroups' epilogues and main loops interleave instead of coinciding
+constexpr int VAR_STAGGER = 64;
+constexpr int ABL_NOSTORE = 128;   // epilogue math kept, stores predicated off (timing only)
 
 // Out-of-range operand chunks (M/N/K tails, conv zero padding) are READ from this zero
 // block instead of being masked after the load: the K loop stays branch-free and the loaded
@@ -137,9 +144,9 @@ struct RegionLoader {
 // ---------------------------------------------------------------------------------------
 // Main loop shared by all kernels: acc[tm][tn] (+)= X[m, :] . W[n, :]
 // ---------------------------------------------------------------------------------------
-template <class T, int TM, int TN, int WN, int VAR, class AL>
+template <class T, int TM, int TN, int WN, int VAR, class AL, class PreLast>
 __device__ __forceinline__ void gemm_mainloop(const AL& al, const float* __restrict__ w, int n0, int N, int K,
-                                              f32x4 (&acc)[TM][TN], float* smem) {
+                                              f32x4 (&acc)[TM][TN], float* smem, PreLast&& pre_last) {
   constexpr int BK = T::BK, LD = T::LD, KCH = T::KCH;
   constexpr int BM = T::BM, NT = T::NT, A_PT = T::A_PT, B_PT = T::B_PT, RSTEP = T::RSTEP, BN_LDS = T::BN_LDS;
   float* As = smem;
@@ -219,13 +226,16 @@ __device__ __forceinline__ void gemm_mainloop(const AL& al, const float* __restr
   int cur = 0;
   for (int kt = 1; kt < nk; ++kt) {
     const int k = kt * BK + kc * 4;
-    al.load(k, areg);              // tile kt: global -> VGPR, in flight during the MFMAs of tile kt-1
-    load_b(k);
+    if (!(VAR & ABL_NOLOAD)) {
+      al.load(k, areg);            // tile kt: global -> VGPR, in flight during the MFMAs of tile kt-1
+      load_b(k);
+    }
     compute(cur);
-    store(cur ^ 1);
-    __syncthreads();
+    if (!(VAR & ABL_NOLDS)) store(cur ^ 1);
+    if (!(VAR & ABL_NOBAR)) __syncthreads();
     cur ^= 1;
   }
+  pre_last();          // epilogue operand loads (bias, residual) fly during the last K step's MFMAs
   compute(cur);
 }
 
@@ -233,7 +243,7 @@ __device__ __forceinline__ void gemm_mainloop(const AL& al, const float* __restr
 // conv / linear / similarity kernel
 // ---------------------------------------------------------------------------------------
 template <int TM, int TN, int WM, int WN, bool CONV, int BKT = 32, int VAR = 0>
-__global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const WdConvGemm p, int nbn, int vec_c, int vec_res) {
+__global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const WdConvGemm p, int nbn, int vec_c, int vec_res, int vec_bias) {
   using T = Tile<TM, TN, WM, WN, BKT>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -241,11 +251,29 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const WdConvGem
   const int bn = blockIdx.x % nbn, bm = blockIdx.x / nbn;
   const int m0 = bm * T::BM, n0 = bn * T::BN;
 
+  if (VAR & VAR_STAGGER) {
+    // first dispatch round only: workgroups 256..511 are (observed, never relied upon for
+    // correctness) the second residents of the 256 CUs
+    if (blockIdx.x >= 256 && blockIdx.x < 512) {
+      const int nk = (p.k + T::BK - 1) / T::BK;
+      const int loops = (nk * (T::BK == 16 ? 2048 : 4096)) / 8128;
+      for (int i = 0; i < loops; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+  }
   ALoader<T::A_PT, T::RSTEP, CONV> al;
   al.init(p, m0, t / T::KCH);
   f32x4 acc[TM][TN];
-  gemm_mainloop<T, TM, TN, WN, VAR>(al, p.w, n0, p.n, p.k, acc, smem);
+  gemm_mainloop<T, TM, TN, WN, VAR>(al, p.w, n0, p.n, p.k, acc, smem, [] {});
 
+  if (VAR & ABL_NOEPI) {           // keep the accumulators live, store one value per lane
+    f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) s4 += acc[tm][tn];
+    if (m0 + (int)(t % T::BM) < p.m) p.c[(size_t)(m0 + t % T::BM) * p.ldc + n0] = s4[0] + s4[1] + s4[2] + s4[3];
+    return;
+  }
   // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + 4*(lane>>4) + 0..3] per tile
   const int ncq = p.n >> 2;   // deconv: channels per tap
 #pragma unroll
@@ -313,6 +341,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const WdConvGem
       } else {
         cp = p.c + crow * p.ldc + n;
       }
+      if ((VAR & ABL_NOSTORE) && o[0] != -1.2345e30f) continue;
       if (full && vec_c) {
         *reinterpret_cast<f32x4*>(cp) = f32x4{o[0], o[1], o[2], o[3]};
       } else {
@@ -342,7 +371,7 @@ __global__ void __launch_bounds__(256) retrieval_max_kernel(const float* __restr
   RegionLoader<T::A_PT, T::RSTEP> al;
   al.init(e, img, rows_per_img, dim, t / T::KCH);
   f32x4 acc[RT_TM][RT_TN];
-  gemm_mainloop<T, RT_TM, RT_TN, RT_WN, 0>(al, tb, n0, n_cls, dim, acc, smem);
+  gemm_mainloop<T, RT_TM, RT_TN, RT_WN, 0>(al, tb, n0, n_cls, dim, acc, smem, [] {});
 
   const int cnt = count[img];
   float cmax[RT_TN][4];
@@ -404,6 +433,7 @@ int launch_cfg(const WdConvGemm& p, hipStream_t st) {
   if (nblk <= 0 || nblk > 0x7fffffffLL) return WD_ERR_BAD_ARG;
   const int vec_c = (p.ldc % 4 == 0) && wd_aligned16(p.c) && (p.out_mode == WD_OUT_ROWS || (p.n % 16 == 0));
   const int vec_res = p.res ? ((p.ldres % 4 == 0) && wd_aligned16(p.res)) : 0;
+  const int vec_bias = p.bias ? wd_aligned16(p.bias) : 0;
   static bool attr_plain = false, attr_conv = false;
   if (conv) {
     auto k = conv_gemm_kernel<TM, TN, WM, WN, true, BKT, VAR>;
@@ -412,7 +442,7 @@ int launch_cfg(const WdConvGemm& p, hipStream_t st) {
                               T::LDS_BYTES) != hipSuccess) return WD_ERR_LAUNCH;
       attr_conv = true;
     }
-    hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(T::NT), T::LDS_BYTES, st, p, nbn, vec_c, vec_res);
+    hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(T::NT), T::LDS_BYTES, st, p, nbn, vec_c, vec_res, vec_bias);
   } else {
     auto k = conv_gemm_kernel<TM, TN, WM, WN, false, BKT, VAR>;
     if (!attr_plain) {
@@ -420,7 +450,7 @@ int launch_cfg(const WdConvGemm& p, hipStream_t st) {
                               T::LDS_BYTES) != hipSuccess) return WD_ERR_LAUNCH;
       attr_plain = true;
     }
-    hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(T::NT), T::LDS_BYTES, st, p, nbn, vec_c, vec_res);
+    hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(T::NT), T::LDS_BYTES, st, p, nbn, vec_c, vec_res, vec_bias);
   }
   return wd_launch_status();
 }
@@ -528,6 +558,21 @@ extern "C" int wd_conv_gemm_tuned(const WdConvGemm* pp, int32_t cfg, void* strea
     case 30: return launch_cfg<1, 5, 8, 1, 16, 0>(p, st);            // 128x80x16, 8 waves
     case 31: return launch_cfg<2, 2, 4, 4, 32, VAR_PRIO>(p, st);
     case 32: return launch_cfg<2, 4, 8, 2, 16, 0>(p, st);            // 256x128x16, 16 waves
+    case 50: return launch_cfg<1, 8, 4, 1, 16, 0>(p, st);            // 64x128x16, 4 waves
+    case 51: return launch_cfg<1, 4, 4, 1, 16, 0>(p, st);            // 64x64x16, 4 waves
+    case 52: return launch_cfg<1, 4, 8, 1, 16, 0>(p, st);            // 128x64x16, 8 waves
+    case 53: return launch_cfg<2, 4, 2, 2, 16, 0>(p, st);            // 64x128x16, 4 waves (32x64 wave tiles)
+    case 54: return launch_cfg<2, 2, 2, 2, 16, 0>(p, st);            // 64x64x16, 4 waves (32x32 wave tiles)
+    case 62: return launch_cfg<2, 4, 4, 2, 16, ABL_NOSTORE>(p, st);
+    case 60: return launch_cfg<2, 4, 4, 2, 16, VAR_STAGGER>(p, st);
+    case 61: return launch_cfg<2, 4, 4, 2, 16, VAR_STAGGER | VAR_PRIO>(p, st);
+    case 40: return launch_cfg<2, 4, 4, 2, 16, ABL_NOLOAD>(p, st);
+    case 41: return launch_cfg<2, 4, 4, 2, 16, ABL_NOBAR>(p, st);
+    case 42: return launch_cfg<2, 4, 4, 2, 16, ABL_NOEPI>(p, st);
+    case 43: return launch_cfg<2, 4, 4, 2, 16, ABL_NOLOAD | ABL_NOLDS>(p, st);
+    case 44: return launch_cfg<2, 4, 4, 2, 16, ABL_NOLOAD | ABL_NOLDS | ABL_NOBAR>(p, st);
+    case 45: return launch_cfg<2, 4, 4, 2, 16, ABL_NOLOAD | ABL_NOLDS | ABL_NOBAR | ABL_NOEPI>(p, st);
+    case 46: return launch_cfg<2, 4, 4, 2, 16, VAR_SGB>(p, st);
     default: return WD_ERR_UNSUPPORTED;
   }
 }

@@ -94,6 +94,97 @@ __global__ void __launch_bounds__(256) dwconv7_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------
+// depthwise 7x7, LDS-tiled (c % 32 == 0): one workgroup = 8 x 16 output pixels x 32 channels.
+// The (8+6) x (16+6) x 32 input halo tile and the 49 x 32 weights are staged in LDS once
+// (pixel stride padded to 36 floats: conflict-free 16-byte reads), then every thread slides
+// a 1 x 4 output strip of one channel quad over the 7 kernel rows: 10 + 7 ds_read_b128 per
+// 112 fp32x4 FMAs.  HBM sees each input once per tile (+ halo, absorbed by L2).
+// ---------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) float g_zero4e[4] = {0.f, 0.f, 0.f, 0.f};   // source of padding reads
+constexpr int DT_TH = 8, DT_TW = 16, DT_CB = 32, DT_CP = 36;       // CP: padded pixel stride (floats)
+constexpr int DT_IH = DT_TH + 6, DT_IW = DT_TW + 6;
+constexpr int DT_LDS_FLOATS = DT_IH * DT_IW * DT_CP + 49 * DT_CB;
+
+__global__ void __launch_bounds__(256) dwconv7_tiled_kernel(const float* __restrict__ x, const float* __restrict__ w7,
+                                                            const float* __restrict__ bias, float* __restrict__ y,
+                                                            int h, int w, int c, int tiles_h, int tiles_w) {
+  __shared__ __attribute__((aligned(16))) float lds[DT_LDS_FLOATS];
+  float* tin = lds;
+  float* tw = lds + DT_IH * DT_IW * DT_CP;
+  const int t = threadIdx.x;
+  const int ncb = c / DT_CB;
+  int bid = blockIdx.x;
+  const int cb = bid % ncb; bid /= ncb;
+  const int tx = bid % tiles_w; bid /= tiles_w;
+  const int ty = bid % tiles_h;
+  const long long b = bid / tiles_h;
+  const int h0 = ty * DT_TH, w0 = tx * DT_TW, c0 = cb * DT_CB;
+  const float* xb = x + (b * h) * (long long)w * c + c0;
+
+  // stage the halo tile: 8 lanes cover the 32 channels of one pixel (128 B contiguous).
+  // All global loads are issued before the first LDS store (a load -> ds_write chain per
+  // iteration would serialise ten memory round trips per tile).
+  constexpr int NST = (DT_IH * DT_IW * 8 + 255) / 256;
+  f32x4 stage[NST];
+#pragma unroll
+  for (int i = 0; i < NST; ++i) {
+    const int e = t + i * 256;
+    const int pix = e >> 3;
+    const int py = pix / DT_IW, px = pix - py * DT_IW;
+    const int hi = h0 + py - 3, wi = w0 + px - 3;
+    const bool ok = e < DT_IH * DT_IW * 8 && (unsigned)hi < (unsigned)h && (unsigned)wi < (unsigned)w;
+    stage[i] = *reinterpret_cast<const f32x4*>(ok ? xb + ((long long)hi * w + wi) * c + (e & 7) * 4 : g_zero4e);
+  }
+  f32x4 wst[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = t + i * 256;
+    wst[i] = *reinterpret_cast<const f32x4*>(e < 49 * 8 ? w7 + (e >> 3) * c + c0 + (e & 7) * 4 : g_zero4e);
+  }
+#pragma unroll
+  for (int i = 0; i < NST; ++i) {
+    const int e = t + i * 256;
+    if (e < DT_IH * DT_IW * 8) *reinterpret_cast<f32x4*>(tin + (e >> 3) * DT_CP + (e & 7) * 4) = stage[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = t + i * 256;
+    if (e < 49 * 8) *reinterpret_cast<f32x4*>(tw + (e >> 3) * DT_CB + (e & 7) * 4) = wst[i];
+  }
+  __syncthreads();
+
+  const int q = t & 7;                   // channel quad
+  const int wg = (t >> 3) & 3;           // 4-pixel strip inside the 16-wide tile
+  const int oy = t >> 5;                 // output row inside the tile
+  f32x4 acc[4];
+  const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c0 + q * 4);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = bv;
+#pragma unroll 1
+  for (int kh = 0; kh < 7; ++kh) {
+    const float* row = tin + ((oy + kh) * DT_IW + wg * 4) * DT_CP + q * 4;
+    f32x4 in[10];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) in[j] = *reinterpret_cast<const f32x4*>(row + j * DT_CP);
+#pragma unroll
+    for (int kw = 0; kw < 7; ++kw) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(tw + (kh * 7 + kw) * DT_CB + q * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] += in[j + kw] * wv;
+    }
+  }
+  const int ho = h0 + oy;
+  if (ho < h) {
+    float* yr = y + ((b * h + ho) * (long long)w) * c + c0 + q * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int wo = w0 + wg * 4 + j;
+      if (wo < w) *reinterpret_cast<f32x4*>(yr + (long long)wo * c) = acc[j];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // LayerNorm over the channel axis of each row.  A group of G lanes (power of two, 8..64)
 // owns one row; each lane holds NV float4.  Two-pass (mean, then centred variance), fp32.
 // ---------------------------------------------------------------------------------------
@@ -216,6 +307,14 @@ extern "C" int wd_dwconv7(const float* x, const float* w7, const float* bias, fl
   if (!x || !w7 || !bias || !y || x == y) return WD_ERR_BAD_ARG;
   if (batch <= 0 || h <= 0 || w <= 0 || c <= 0 || (c & 3)) return WD_ERR_BAD_ARG;
   if (!wd_aligned16(x) || !wd_aligned16(w7) || !wd_aligned16(bias) || !wd_aligned16(y)) return WD_ERR_BAD_ARG;
+  if (c % DT_CB == 0) {
+    const int th = (h + DT_TH - 1) / DT_TH, tw = (w + DT_TW - 1) / DT_TW;
+    const long long nblk = (long long)batch * th * tw * (c / DT_CB);
+    if (nblk > 0x7fffffffLL) return WD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(dwconv7_tiled_kernel, dim3((unsigned)nblk), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                       w7, bias, y, h, w, c, th, tw);
+    return wd_launch_status();
+  }
   const int nstrip = (w + DW_TW - 1) / DW_TW;
   const long long total = (long long)batch * h * nstrip * (c / 4);
   const long long grid = (total + 255) / 256;

@@ -19,7 +19,7 @@ namespace {
 
 constexpr int HB = 2048;                 // histogram bins per radix level
 constexpr int CH = 4096;                 // elements per workgroup chunk (256 threads x 16)
-constexpr unsigned long long KEY_PAD = ~0ull;
+constexpr int SORT_CHUNK = 8192;          // keys sorted per LDS visit (64 KB)
 
 struct TopkState {                       // one per image, 64 bytes
   unsigned total_valid;                  // elements with score > thr
@@ -237,8 +237,34 @@ __global__ void __launch_bounds__(1024) topk_sort_kernel(unsigned long long* __r
   unsigned long long* k = keys + (size_t)b * cap;
   int n2 = 1;
   while (n2 < (int)want) n2 <<= 1;          // entries [want, cap) hold KEY_PAD and sort last
-  for (int size = 2; size <= n2; size <<= 1) {
-    for (int j = size >> 1; j > 0; j >>= 1) {
+  // Bitonic network with every stride below SORT_CHUNK done in LDS: chunks of 8192 keys
+  // (64 KB) are sorted locally, only the few large-stride stages of the last merges touch
+  // global memory (3 passes for 32768 keys instead of 120).
+  extern __shared__ __attribute__((aligned(16))) unsigned long long sk[];
+  const int chunk = n2 < SORT_CHUNK ? n2 : SORT_CHUNK;
+  auto lds_pass = [&](int base, int jj, int dir_bit) {
+    for (int i = t; i < chunk; i += 1024) {
+      const int p = i ^ jj;
+      if (p > i) {
+        const unsigned long long a = sk[i], c = sk[p];
+        const bool up = ((base + i) & dir_bit) == 0;
+        if ((a > c) == up) { sk[i] = c; sk[p] = a; }
+      }
+    }
+    __syncthreads();
+  };
+  // phase A: every chunk sorted on its own (ascending / descending alternately)
+  for (int base = 0; base < n2; base += chunk) {
+    for (int i = t; i < chunk; i += 1024) sk[i] = k[base + i];
+    __syncthreads();
+    for (int sz = 2; sz <= chunk; sz <<= 1)
+      for (int jj = sz >> 1; jj > 0; jj >>= 1) lds_pass(base, jj, sz);
+    for (int i = t; i < chunk; i += 1024) k[base + i] = sk[i];
+    __syncthreads();
+  }
+  // phase B: merges wider than a chunk — large strides in global memory, the rest in LDS
+  for (int size = chunk << 1; size <= n2; size <<= 1) {
+    for (int j = size >> 1; j >= chunk; j >>= 1) {
       for (int i = t; i < n2; i += 1024) {
         const int p = i ^ j;
         if (p > i) {
@@ -247,6 +273,13 @@ __global__ void __launch_bounds__(1024) topk_sort_kernel(unsigned long long* __r
           if ((a > c) == up) { k[i] = c; k[p] = a; }
         }
       }
+      __syncthreads();
+    }
+    for (int base = 0; base < n2; base += chunk) {
+      for (int i = t; i < chunk; i += 1024) sk[i] = k[base + i];
+      __syncthreads();
+      for (int jj = chunk >> 1; jj > 0; jj >>= 1) lds_pass(base, jj, size);
+      for (int i = t; i < chunk; i += 1024) k[base + i] = sk[i];
       __syncthreads();
     }
   }
@@ -447,7 +480,7 @@ extern "C" int wd_topk_candidates(const float* scores, int32_t batch, int64_t n,
   hipLaunchKernelGGL(topk_scan_kernel, gimg, dim3(256), 0, st, blk, L.nblk);
   hipLaunchKernelGGL(topk_scatter_kernel, gchunk, dim3(256), 0, st, scores, (long long)n, thr, state, blk, L.nblk, keys,
                      L.cap);
-  hipLaunchKernelGGL(topk_sort_kernel, gimg, dim3(1024), 0, st, keys, L.cap, state, out_idx, out_score, out_count);
+  hipLaunchKernelGGL(topk_sort_kernel, gimg, dim3(1024), SORT_CHUNK * 8, st, keys, L.cap, state, out_idx, out_score, out_count);
   return wd_launch_status();
 }
 
