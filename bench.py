@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--classes", type=int, default=80)
+    ap.add_argument("--mode", choices=["detect", "uni"], default="detect",
+                    help="detect: normalised text bank, thr 0.001, rescale-before-NMS (configs[1]); "
+                         "uni: WeDetect-Uni prompts as stored, thr 0.0, NMS in network pixels (configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=8)
     return ap.parse_args()
@@ -154,12 +157,15 @@ def main():
     images = torch.from_numpy(W.make_images(B, S, S, seed=1234 + rank)).cuda()
     text = torch.from_numpy(W.make_text_bank(K)).cuda()
     meta = tower.identity_meta()
-    meta[:, 7] = 1.0                        # mmdet order: rescale before NMS
+    uni = args.mode == "uni"
+    if not uni:
+        meta[:, 7] = 1.0                    # mmdet order: rescale before NMS
     timer = GemmTimer(L)
     timer.install()
 
     def step():
-        res = tower.detect(images, text, meta, normalize_text=True, score_thr=0.001, with_embed=True)
+        res = tower.detect(images, text, meta, normalize_text=not uni, score_thr=0.0 if uni else 0.001,
+                           with_embed=True)
         if world > 1:
             gather_regions(res["embeddings"], res["count"])
         return res
@@ -206,7 +212,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"WeDetect-{args.arch.capitalize()}, batch {B}x{S}x{S} per GPU, {K}-class similarity, "
-                                   f"thr 0.001 / nms_pre 30000 / NMS 0.7 / 300 per image (BASELINE.json configs[1])",
+                                   f"thr {0.0 if uni else 0.001} / nms_pre 30000 / NMS 0.7 / 300 per image, mode {args.mode}",
                        "global_batch": world * B, "per_gpu_batch": B, "image": [S, S], "classes": K,
                        "parallelism": f"image-shard x{world}" + (" + all-gather of kept-region embeddings" if world > 1 else ""),
                        "kept_regions_last_step_rank0": kept,

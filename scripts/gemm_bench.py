@@ -21,7 +21,7 @@ SHAPES = {
     "conv3 128->256 @80 silu": dict(conv=(32, 80, 80, 128, 256)),
     "conv3 512->256 @20 silu": dict(conv=(32, 20, 20, 512, 256)),
 }
-GROUPS = {"big": [17, 62, 42, 17, 62, 42], "sim": [30], "conv": [None, 17, 50, 51, 52, 53, 54]}
+GROUPS = {"big": [17, 63, 17, 63], "sim": [30, 64, 30, 64], "conv": [17, 63]}
 import ctypes
 _old_path = os.path.join(os.path.dirname(L.LIB_PATH), "libwedetect_old_gemm.so")
 OLD = ctypes.CDLL(_old_path) if os.path.exists(_old_path) else None

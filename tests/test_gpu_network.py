@@ -231,3 +231,34 @@ def test_full_size_properties_base_640():
     torch.cuda.synchronize()
     for k in ("bboxes", "scores", "labels", "anchors", "embeddings"):
         assert torch.equal(ra[k][0], r1[k][0]), f"image 0 differs between batch 1 and batch 4 in {k}"
+
+
+def test_hipgraph_replay_equals_eager_and_is_faster_at_batch1():
+    """A captured step must reproduce the eager step bit for bit on new inputs, and at batch 1
+    (the reference's operating point) it removes the host launch overhead."""
+    import time
+    from wedetect_amd import weights as W
+    from wedetect_amd.engine import GraphedDetect
+    sd_np, tower, imgs = build("tiny", 1, 640, num_prompts=0, max_classes=80)
+    text = torch.from_numpy(W.make_text_bank(80)).cuda()
+    meta = tower.identity_meta()
+    meta[:, 7] = 1.0
+    g = GraphedDetect(tower, 80, normalize_text=True, score_thr=0.001)
+    x1 = torch.from_numpy(W.make_images(1, 640, 640, seed=9)).cuda()
+    out_g = {k: v.clone() for k, v in g(x1, text, meta).items()}
+    out_e = tower.detect(x1, text, meta, normalize_text=True, score_thr=0.001, with_embed=True)
+    torch.cuda.synchronize()
+    for k in out_g:
+        assert torch.equal(out_g[k], out_e[k]), f"graph replay differs from eager in {k}"
+
+    def timeit(fn, n=10):
+        fn(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+    te = timeit(lambda: tower.detect(x1, text, meta, normalize_text=True, score_thr=0.001, with_embed=True))
+    tg = timeit(lambda: g(x1, text, meta))
+    print(f"[tiny b1 640] eager {te*1e3:.2f} ms/step, hipGraph {tg*1e3:.2f} ms/step")
+    assert tg < te * 1.05

@@ -35,7 +35,8 @@ constexpr int ABL_NOLOAD = 4, ABL_NOBAR = 8, ABL_NOEPI = 16, ABL_NOLDS = 32;
 // bit 6: delay the second co-resident workgroup of every CU by half a tile at kernel start so
 // that the two workgroups' epilogues and main loops interleave instead of coinciding
 constexpr int VAR_STAGGER = 64;
-constexpr int ABL_NOSTORE = 128;   // epilogue math kept, stores predicated off (timing only)
+constexpr int ABL_NOSTORE = 128;
+constexpr int VAR_XCD = 256;       // XCD-aware tile order: each XCD's L2 sees whole A row panels   // epilogue math kept, stores predicated off (timing only)
 
 // Out-of-range operand chunks (M/N/K tails, conv zero padding) are READ from this zero
 // block instead of being masked after the load: the K loop stays branch-free and the loaded
@@ -248,7 +249,15 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const WdConvGem
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int bn = blockIdx.x % nbn, bm = blockIdx.x / nbn;
+  int tile = blockIdx.x;
+  if (VAR & VAR_XCD) {
+    // workgroup b runs on XCD b % 8 (observed; only locality depends on it).  Give XCD x the
+    // contiguous tile range [start(x), start(x+1)): bijective for any grid size.
+    const int nwg = gridDim.x, xcd = tile & 7, idx = tile >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int bn = tile % nbn, bm = tile / nbn;
   const int m0 = bm * T::BM, n0 = bn * T::BN;
 
   if (VAR & VAR_STAGGER) {
@@ -511,11 +520,11 @@ extern "C" int wd_conv_gemm(const WdConvGemm* pp, void* stream) {
     return WD_ERR_BAD_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (pick_bn(p.n)) {
-    case 128: return launch_cfg<2, 4, 4, 2, 16>(p, st);
-    case 96: return launch_cfg<1, 6, 8, 1, 16>(p, st);
-    case 80: return launch_cfg<1, 5, 8, 1, 16>(p, st);
-    case 64: return launch_cfg<1, 4, 8, 1, 16>(p, st);
-    default: return launch_cfg<1, 3, 8, 1, 16>(p, st);
+    case 128: return launch_cfg<2, 4, 4, 2, 16, VAR_XCD>(p, st);
+    case 96: return launch_cfg<1, 6, 8, 1, 16, VAR_XCD>(p, st);
+    case 80: return launch_cfg<1, 5, 8, 1, 16, VAR_XCD>(p, st);
+    case 64: return launch_cfg<1, 4, 8, 1, 16, VAR_XCD>(p, st);
+    default: return launch_cfg<1, 3, 8, 1, 16, VAR_XCD>(p, st);
   }
 }
 
@@ -564,6 +573,8 @@ extern "C" int wd_conv_gemm_tuned(const WdConvGemm* pp, int32_t cfg, void* strea
     case 53: return launch_cfg<2, 4, 2, 2, 16, 0>(p, st);            // 64x128x16, 4 waves (32x64 wave tiles)
     case 54: return launch_cfg<2, 2, 2, 2, 16, 0>(p, st);            // 64x64x16, 4 waves (32x32 wave tiles)
     case 62: return launch_cfg<2, 4, 4, 2, 16, ABL_NOSTORE>(p, st);
+    case 63: return launch_cfg<2, 4, 4, 2, 16, VAR_XCD>(p, st);
+    case 64: return launch_cfg<1, 5, 8, 1, 16, VAR_XCD>(p, st);
     case 60: return launch_cfg<2, 4, 4, 2, 16, VAR_STAGGER>(p, st);
     case 61: return launch_cfg<2, 4, 4, 2, 16, VAR_STAGGER | VAR_PRIO>(p, st);
     case 40: return launch_cfg<2, 4, 4, 2, 16, ABL_NOLOAD>(p, st);

@@ -38,6 +38,12 @@ __device__ __forceinline__ bool in_prefix(unsigned key, unsigned prefix, int pas
   return pass == 0 ? true : pass == 1 ? (key >> 21) == prefix : (key >> 10) == prefix;
 }
 
+// 32-bit fill (own kernel instead of hipMemsetAsync: identical behaviour eagerly and inside a
+// captured hipGraph)
+__global__ void __launch_bounds__(256) fill_u32_kernel(unsigned* __restrict__ p, unsigned v, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = v;
+}
+
 // ---- level histogram ------------------------------------------------------------------
 template <int PASS>
 __global__ void __launch_bounds__(256) topk_hist_kernel(const float* __restrict__ scores, long long n, float thr,
@@ -467,8 +473,13 @@ extern "C" int wd_topk_candidates(const float* scores, int32_t batch, int64_t n,
   unsigned* blk = reinterpret_cast<unsigned*>(ws + L.blk);
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(ws + L.keys);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (hipMemsetAsync(ws + L.hist, 0, L.blk - L.hist, st) != hipSuccess) return WD_ERR_LAUNCH;   // hist + state
-  if (hipMemsetAsync(keys, 0xFF, (size_t)batch * L.cap * 8, st) != hipSuccess) return WD_ERR_LAUNCH;
+  {
+    const long long n0 = (long long)((L.blk - L.hist) / 4), n1 = (long long)batch * L.cap * 2;
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)((n0 + 255) / 256 < 1024 ? (n0 + 255) / 256 : 1024)), dim3(256), 0,
+                       st, reinterpret_cast<unsigned*>(ws + L.hist), 0u, n0);                      // hist + state
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)((n1 + 255) / 256 < 1024 ? (n1 + 255) / 256 : 1024)), dim3(256), 0,
+                       st, reinterpret_cast<unsigned*>(keys), 0xFFFFFFFFu, n1);                    // pad keys sort last
+  }
   const dim3 gchunk(L.nblk, batch), gimg(batch);
   hipLaunchKernelGGL(topk_hist_kernel<0>, gchunk, dim3(256), 0, st, scores, (long long)n, thr, state, hist);
   hipLaunchKernelGGL(topk_pick_kernel<0>, gimg, dim3(256), 0, st, state, hist, nms_pre);
