@@ -21,7 +21,7 @@ SHAPES = {
     "conv3 128->256 @80 silu": dict(conv=(32, 80, 80, 128, 256)),
     "conv3 512->256 @20 silu": dict(conv=(32, 20, 20, 512, 256)),
 }
-GROUPS = {"big": [17, 63, 17, 63], "sim": [30, 64, 30, 64], "conv": [17, 63]}
+GROUPS = {"big": [3, 0, 1, 2, 4, 5, 6, 22, 24], "sim": [10, 11, 12], "conv": [None, 3, 7, 8, 9]}
 import ctypes
 _old_path = os.path.join(os.path.dirname(L.LIB_PATH), "libwedetect_old_gemm.so")
 OLD = ctypes.CDLL(_old_path) if os.path.exists(_old_path) else None

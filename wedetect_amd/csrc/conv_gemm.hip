@@ -10,33 +10,40 @@
 // this dtype is 157.3 TFLOP/s (MI355X_MICROARCH.md).
 //
 // Tiling (per workgroup of WM x WN waves, wave = 64 lanes):
-//   block tile  BM = 16*TM*WM rows (m)  x  BN = 16*TN*WN cols (n),  K step BK = 32
+//   block tile  BM = 16*TM*WM rows (m)  x  BN = 16*TN*WN cols (n),  K step BK (16 in production)
 //   wave tile   (16*TM) x (16*TN), TM*TN accumulators of 4 VGPRs
-//   operands are staged global -> VGPR (16-byte loads, im2col gather + zero padding done
-//   here) -> LDS [rows][BK+4], double buffered: the loads of tile t+1 are issued before
-//   the 128 MFMAs of tile t and written to the other LDS buffer after them (one barrier
-//   per K step).
+//   production: 128 x 128 x 16 with 8 waves (32 x 64 wave tiles) for n % 128 == 0, and
+//   128 x {96,80,64,48} x 16 with 8 waves stacked along m otherwise; ~76 VGPRs and 41 KB of LDS,
+//   so three workgroups (6 waves per SIMD) stay resident per CU — on device that occupancy, not
+//   fragment reuse, is what keeps the (slow, 32-cycle) fp32 MFMA pipe fed.
+//   operands are staged global -> VGPR (16-byte loads, im2col gather; tails and conv padding are
+//   READ from a zero block so the K loop is branch-free) -> LDS [rows][BK+4], double buffered:
+//   the loads of tile t+1 are issued before the MFMAs of tile t and written to the other LDS
+//   buffer after them (one barrier per K step).
 //   The MFMA "A" operand carries WEIGHT rows and the "B" operand ACTIVATION rows, so a lane
 //   ends up holding 4 consecutive output channels of one pixel: epilogue loads/stores are
 //   16-byte vectors along n.
 //   K is consumed 16 at a time: lane (i = lane&15, g = lane>>4) reads the float4
 //   [k0+4g, k0+4g+4) of row i with one ds_read_b128 and feeds component r to the r-th of 4
-//   MFMAs — a permutation of k that is identical for both operands, hence harmless.
+//   MFMAs — a permutation of k that is identical for both operands, hence harmless; every tile
+//   configuration therefore sums k in the same order and results are bit-identical across them.
+//   Workgroups are renumbered so that each XCD (b % 8) walks a contiguous range of tiles: the
+//   column tiles that share an A row panel hit the same L2.
 #include "common.h"
 
 namespace {
 
-// tuning variants (template int VAR): bit 0 = raise wave priority over the MFMA cluster,
-// bit 1 = pin an MFMA / LDS-read interleave with sched_group_barrier.
-constexpr int VAR_PRIO = 1, VAR_SGB = 2;
-// timing-only ablations (WRONG results by construction; reachable only through
-// wd_conv_gemm_tuned): skip the in-loop global loads / the in-loop barrier / the epilogue math
-constexpr int ABL_NOLOAD = 4, ABL_NOBAR = 8, ABL_NOEPI = 16, ABL_NOLDS = 32;
-// bit 6: delay the second co-resident workgroup of every CU by half a tile at kernel start so
-// that the two workgroups' epilogues and main loops interleave instead of coinciding
-constexpr int VAR_STAGGER = 64;
-constexpr int ABL_NOSTORE = 128;
-constexpr int VAR_XCD = 256;       // XCD-aware tile order: each XCD's L2 sees whole A row panels   // epilogue math kept, stores predicated off (timing only)
+// Template int VAR — variants selectable through wd_conv_gemm_tuned for on-device A/B runs
+// (profiles/r01_gemm_ab.txt records what was measured).
+constexpr int VAR_PRIO = 1;        // s_setprio(1) over the MFMA cluster (measured: null)
+constexpr int VAR_XCD = 256;       // XCD-aware tile order: each XCD's L2 sees whole A row panels (+0..5 %)
+// timing-only ablations (WRONG results by construction): skip the in-loop global loads / LDS
+// stores / barrier / the epilogue / the epilogue's stores
+constexpr int ABL_NOLOAD = 4, ABL_NOBAR = 8, ABL_NOEPI = 16, ABL_NOLDS = 32, ABL_NOSTORE = 128;
+// Tried and dropped in round 1 (all bit-exact, none faster): prefetch two K steps ahead with two
+// register sets (-6..-13 %), hoisting / prefetching the epilogue operands (-9 %), staggering the
+// co-resident workgroups (0 %), sched_group_barrier interleave (0 %), v_mfma_f32_32x32x2_f32
+// tiles (0..-6 %), 4-wave 64x64 wave tiles and K step 32/64 (-10..-30 %).
 
 // Out-of-range operand chunks (M/N/K tails, conv zero padding) are READ from this zero
 // block instead of being masked after the load: the K loop stays branch-free and the loaded
@@ -202,16 +209,6 @@ __device__ __forceinline__ void gemm_mainloop(const AL& al, const float* __restr
             acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[tn][r], xf[tm][r], acc[tm][tn], 0, 0, 0);
       if (VAR & VAR_PRIO) __builtin_amdgcn_s_setprio(0);
     }
-    if (VAR & VAR_SGB) {
-      // per 16-k half: the TM+TN fragment reads first, then the MFMAs with the next half's
-      // reads / the next tile's global loads slotted in between them
-#pragma unroll
-      for (int g = 0; g < (BK / 16) * 4 * TM * TN / 8; ++g) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);   // 8 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
-      }
-    }
   };
 
 #pragma unroll
@@ -260,15 +257,6 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const WdConvGem
   const int bn = tile % nbn, bm = tile / nbn;
   const int m0 = bm * T::BM, n0 = bn * T::BN;
 
-  if (VAR & VAR_STAGGER) {
-    // first dispatch round only: workgroups 256..511 are (observed, never relied upon for
-    // correctness) the second residents of the 256 CUs
-    if (blockIdx.x >= 256 && blockIdx.x < 512) {
-      const int nk = (p.k + T::BK - 1) / T::BK;
-      const int loops = (nk * (T::BK == 16 ? 2048 : 4096)) / 8128;
-      for (int i = 0; i < loops; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-  }
   ALoader<T::A_PT, T::RSTEP, CONV> al;
   al.init(p, m0, t / T::KCH);
   f32x4 acc[TM][TN];
@@ -535,55 +523,24 @@ extern "C" int wd_conv_gemm_tuned(const WdConvGemm* pp, int32_t cfg, void* strea
   const WdConvGemm& p = *pp;
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (cfg) {
-    case 0: return launch_cfg<4, 4, 2, 2, 32, 0>(p, st);            // 128x128x32, 4 waves
-    case 1: return launch_cfg<4, 4, 2, 2, 32, VAR_PRIO>(p, st);
-    case 2: return launch_cfg<4, 4, 2, 2, 32, VAR_SGB>(p, st);
-    case 3: return launch_cfg<4, 4, 2, 2, 32, VAR_PRIO | VAR_SGB>(p, st);
-    case 4: return launch_cfg<4, 4, 4, 2, 32, 0>(p, st);            // 256x128x32, 8 waves
-    case 5: return launch_cfg<4, 4, 4, 2, 32, VAR_PRIO>(p, st);
-    case 6: return launch_cfg<4, 4, 2, 2, 16, 0>(p, st);            // 128x128x16, 4 waves (3-4 blocks/CU)
-    case 7: return launch_cfg<4, 4, 2, 4, 32, 0>(p, st);            // 128x256x32, 8 waves
-    case 8: return launch_cfg<2, 4, 4, 2, 32, 0>(p, st);            // 128x128x32, 8 waves (32x64 wave tiles)
-    case 9: return launch_cfg<4, 5, 4, 1, 32, 0>(p, st);            // 256x80x32, 4 waves
-    case 10: return launch_cfg<2, 5, 8, 1, 32, 0>(p, st);           // 256x80x32, 8 waves
-    case 11: return launch_cfg<3, 5, 4, 1, 32, 0>(p, st);           // 192x80x32, 4 waves
-    case 12: return launch_cfg<2, 5, 4, 1, 32, 0>(p, st);           // 128x80x32, 4 waves
-    case 13: return launch_cfg<4, 5, 4, 1, 16, 0>(p, st);           // 256x80x16, 4 waves
-    case 14: return launch_cfg<3, 5, 4, 1, 32, VAR_PRIO>(p, st);
-    case 15: return launch_cfg<4, 4, 2, 2, 64, 0>(p, st);            // 128x128x64, 4 waves (1 block/CU)
-    case 16: return launch_cfg<2, 4, 4, 2, 32, VAR_PRIO>(p, st);
-    case 17: return launch_cfg<2, 4, 4, 2, 16, 0>(p, st);            // 128x128x16, 8 waves
-    case 18: return launch_cfg<2, 2, 4, 4, 32, 0>(p, st);            // 128x128x32, 16 waves
-    case 20: return launch_cfg<2, 4, 2, 2, 32, 0>(p, st);            // 64x128x32, 4 waves
-    case 21: return launch_cfg<1, 4, 8, 2, 32, 0>(p, st);            // 128x128x32, 16 waves (16x64 wave tiles)
-    case 22: return launch_cfg<2, 4, 8, 2, 32, 0>(p, st);            // 256x128x32, 16 waves
-    case 23: return launch_cfg<1, 5, 8, 1, 32, 0>(p, st);            // 128x80x32, 8 waves
-    case 24: return launch_cfg<2, 5, 8, 1, 16, 0>(p, st);            // 256x80x16, 8 waves
-    case 25: return launch_cfg<1, 5, 16, 1, 32, 0>(p, st);           // 256x80x32, 16 waves
-    case 26: return launch_cfg<2, 5, 4, 1, 16, 0>(p, st);            // 128x80x16, 4 waves
-    case 27: return launch_cfg<2, 5, 8, 1, 32, VAR_PRIO>(p, st);
-    case 28: return launch_cfg<1, 5, 4, 1, 32, 0>(p, st);            // 64x80x32, 4 waves
-    case 29: return launch_cfg<2, 4, 4, 2, 16, VAR_PRIO>(p, st);
-    case 30: return launch_cfg<1, 5, 8, 1, 16, 0>(p, st);            // 128x80x16, 8 waves
-    case 31: return launch_cfg<2, 2, 4, 4, 32, VAR_PRIO>(p, st);
-    case 32: return launch_cfg<2, 4, 8, 2, 16, 0>(p, st);            // 256x128x16, 16 waves
-    case 50: return launch_cfg<1, 8, 4, 1, 16, 0>(p, st);            // 64x128x16, 4 waves
-    case 51: return launch_cfg<1, 4, 4, 1, 16, 0>(p, st);            // 64x64x16, 4 waves
-    case 52: return launch_cfg<1, 4, 8, 1, 16, 0>(p, st);            // 128x64x16, 8 waves
-    case 53: return launch_cfg<2, 4, 2, 2, 16, 0>(p, st);            // 64x128x16, 4 waves (32x64 wave tiles)
-    case 54: return launch_cfg<2, 2, 2, 2, 16, 0>(p, st);            // 64x64x16, 4 waves (32x32 wave tiles)
-    case 62: return launch_cfg<2, 4, 4, 2, 16, ABL_NOSTORE>(p, st);
-    case 63: return launch_cfg<2, 4, 4, 2, 16, VAR_XCD>(p, st);
-    case 64: return launch_cfg<1, 5, 8, 1, 16, VAR_XCD>(p, st);
-    case 60: return launch_cfg<2, 4, 4, 2, 16, VAR_STAGGER>(p, st);
-    case 61: return launch_cfg<2, 4, 4, 2, 16, VAR_STAGGER | VAR_PRIO>(p, st);
-    case 40: return launch_cfg<2, 4, 4, 2, 16, ABL_NOLOAD>(p, st);
-    case 41: return launch_cfg<2, 4, 4, 2, 16, ABL_NOBAR>(p, st);
-    case 42: return launch_cfg<2, 4, 4, 2, 16, ABL_NOEPI>(p, st);
-    case 43: return launch_cfg<2, 4, 4, 2, 16, ABL_NOLOAD | ABL_NOLDS>(p, st);
-    case 44: return launch_cfg<2, 4, 4, 2, 16, ABL_NOLOAD | ABL_NOLDS | ABL_NOBAR>(p, st);
-    case 45: return launch_cfg<2, 4, 4, 2, 16, ABL_NOLOAD | ABL_NOLDS | ABL_NOBAR | ABL_NOEPI>(p, st);
-    case 46: return launch_cfg<2, 4, 4, 2, 16, VAR_SGB>(p, st);
+    case 0: return launch_cfg<4, 4, 2, 2, 32, 0>(p, st);                  // 128x128x32, 4 waves (first cut)
+    case 1: return launch_cfg<2, 4, 4, 2, 32, 0>(p, st);                  // 128x128x32, 8 waves
+    case 2: return launch_cfg<2, 4, 4, 2, 16, 0>(p, st);                  // 128x128x16, 8 waves
+    case 3: return launch_cfg<2, 4, 4, 2, 16, VAR_XCD>(p, st);            // production tile for n % 128 == 0
+    case 4: return launch_cfg<2, 4, 4, 2, 16, VAR_XCD | VAR_PRIO>(p, st);
+    case 5: return launch_cfg<2, 2, 4, 4, 32, VAR_XCD>(p, st);            // 128x128x32, 16 waves
+    case 6: return launch_cfg<4, 4, 2, 2, 16, VAR_XCD>(p, st);            // 128x128x16, 4 waves
+    case 7: return launch_cfg<1, 8, 4, 1, 16, VAR_XCD>(p, st);            // 64x128x16, 4 waves
+    case 8: return launch_cfg<1, 4, 4, 1, 16, VAR_XCD>(p, st);            // 64x64x16, 4 waves
+    case 9: return launch_cfg<1, 4, 8, 1, 16, VAR_XCD>(p, st);            // 128x64x16, 8 waves (production, n = 64)
+    case 10: return launch_cfg<1, 5, 8, 1, 16, VAR_XCD>(p, st);           // 128x80x16, 8 waves (production, n = 80)
+    case 11: return launch_cfg<4, 5, 4, 1, 32, 0>(p, st);                 // 256x80x32, 4 waves (first cut)
+    case 12: return launch_cfg<2, 5, 8, 1, 16, VAR_XCD>(p, st);           // 256x80x16, 8 waves
+    case 20: return launch_cfg<2, 4, 4, 2, 16, VAR_XCD | ABL_NOLOAD>(p, st);
+    case 21: return launch_cfg<2, 4, 4, 2, 16, VAR_XCD | ABL_NOBAR>(p, st);
+    case 22: return launch_cfg<2, 4, 4, 2, 16, VAR_XCD | ABL_NOEPI>(p, st);
+    case 23: return launch_cfg<2, 4, 4, 2, 16, VAR_XCD | ABL_NOSTORE>(p, st);
+    case 24: return launch_cfg<2, 4, 4, 2, 16, VAR_XCD | ABL_NOLOAD | ABL_NOLDS | ABL_NOBAR | ABL_NOEPI>(p, st);
     default: return WD_ERR_UNSUPPORTED;
   }
 }
