@@ -43,7 +43,8 @@ constexpr int ABL_NOLOAD = 4, ABL_NOBAR = 8, ABL_NOEPI = 16, ABL_NOLDS = 32, ABL
 // Tried and dropped in round 1 (all bit-exact, none faster): prefetch two K steps ahead with two
 // register sets (-6..-13 %), hoisting / prefetching the epilogue operands (-9 %), staggering the
 // co-resident workgroups (0 %), sched_group_barrier interleave (0 %), v_mfma_f32_32x32x2_f32
-// tiles (0..-6 %), 4-wave 64x64 wave tiles and K step 32/64 (-10..-30 %).
+// tiles (0..-6 %), 4-wave 64x64 wave tiles and K step 32/64 (-10..-30 %), 6/10/12-wave workgroups
+// (96/160/192-row tiles, -10..-25 %: waves no longer spread evenly over the 4 SIMDs).
 
 // Out-of-range operand chunks (M/N/K tails, conv zero padding) are READ from this zero
 // block instead of being masked after the load: the K loop stays branch-free and the loaded
@@ -471,10 +472,19 @@ int pick_bn(int n) {
 // Production tile table (picked on device with scripts/gemm_bench.py, profiles/r01_gemm_ab.txt):
 // K step 16 and 8 waves per workgroup keep 4-5 waves per SIMD resident, which is what keeps
 // the fp32 MFMA pipe busy; results are bit-identical across configurations (same k order).
+// n % 128 == 0 problems with fewer than this many 128x128 tiles run 64x128 tiles (4 waves) instead:
+// twice the workgroups and five resident per CU cut the tile-quantisation tail (s3 pwconv2
+// 114 -> 120 TF, s4 pwconv2 101 -> 112 TF); above it the 8-wave 128x128 tile is faster.
+constexpr long long kSmallProblemTiles = 2048;
+
+static inline bool use_small_tile(int m, int n) {
+  return (long long)((m + 127) / 128) * ((n + 127) / 128) < kSmallProblemTiles;
+}
+
 extern "C" const char* wd_conv_gemm_config(int32_t m, int32_t n, int32_t k) {
-  (void)m; (void)k;
+  (void)k;
   switch (pick_bn(n)) {
-    case 128: return "128x128x16/8w";
+    case 128: return use_small_tile(m, n) ? "64x128x16/4w" : "128x128x16/8w";
     case 96: return "128x96x16/8w";
     case 80: return "128x80x16/8w";
     case 64: return "128x64x16/8w";
@@ -508,7 +518,9 @@ extern "C" int wd_conv_gemm(const WdConvGemm* pp, void* stream) {
     return WD_ERR_BAD_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (pick_bn(p.n)) {
-    case 128: return launch_cfg<2, 4, 4, 2, 16, VAR_XCD>(p, st);
+    case 128:
+      return use_small_tile(p.m, p.n) ? launch_cfg<2, 4, 2, 2, 16, VAR_XCD>(p, st)
+                                      : launch_cfg<2, 4, 4, 2, 16, VAR_XCD>(p, st);
     case 96: return launch_cfg<1, 6, 8, 1, 16, VAR_XCD>(p, st);
     case 80: return launch_cfg<1, 5, 8, 1, 16, VAR_XCD>(p, st);
     case 64: return launch_cfg<1, 4, 8, 1, 16, VAR_XCD>(p, st);
@@ -536,6 +548,7 @@ extern "C" int wd_conv_gemm_tuned(const WdConvGemm* pp, int32_t cfg, void* strea
     case 10: return launch_cfg<1, 5, 8, 1, 16, VAR_XCD>(p, st);           // 128x80x16, 8 waves (production, n = 80)
     case 11: return launch_cfg<4, 5, 4, 1, 32, 0>(p, st);                 // 256x80x32, 4 waves (first cut)
     case 12: return launch_cfg<2, 5, 8, 1, 16, VAR_XCD>(p, st);           // 256x80x16, 8 waves
+    case 13: return launch_cfg<2, 4, 2, 2, 16, VAR_XCD>(p, st);           // 64x128x16, 4 waves (production, small problems)
     case 20: return launch_cfg<2, 4, 4, 2, 16, VAR_XCD | ABL_NOLOAD>(p, st);
     case 21: return launch_cfg<2, 4, 4, 2, 16, VAR_XCD | ABL_NOBAR>(p, st);
     case 22: return launch_cfg<2, 4, 4, 2, 16, VAR_XCD | ABL_NOEPI>(p, st);
