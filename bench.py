@@ -33,6 +33,25 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+# bench tag -> kernel symbol in the rocprofv3 traces / profiles/r01_traffic.json
+KERNEL_SYMBOL = {
+    "128x128x16/8w/plain": "conv_gemm_kernel<2, 4, 4, 2, false, 16, 256>",
+    "128x128x16/8w/conv": "conv_gemm_kernel<2, 4, 4, 2, true, 16, 256>",
+    "64x128x16/4w/plain": "conv_gemm_kernel<2, 4, 2, 2, false, 16, 256>",
+    "64x128x16/4w/conv": "conv_gemm_kernel<2, 4, 2, 2, true, 16, 256>",
+    "128x80x16/8w/plain": "conv_gemm_kernel<1, 5, 8, 1, false, 16, 256>",
+}
+
+
+def measured_traffic(tag):
+    """HBM bytes per launch from the committed PMC passes (profiles/r01_traffic.json: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE doubled per
+    MI355X_MICROARCH.md).  None when no PMC record matches the kernel that ran."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"]
+        return round(rec[KERNEL_SYMBOL[tag]]["hbm_bytes_per_launch"])
+    except Exception:
+        return None
 HBM_PEAK_GBS = 8000.0
 
 
@@ -79,15 +98,18 @@ class GemmTimer:
             s.record()
             orig(a, w, bias, c, **kw)
             e.record()
-            rec.setdefault(tag, []).append((s, e, 2.0 * m * n * k))
+            # algorithmic HBM bytes: A (or the NHWC input once), W, C, residual — fp32
+            a_elems = kw["batch"] * hin * win * kw["cin"]
+            nbytes = 4.0 * (a_elems + n * k + m * n * (2 if kw.get("res") is not None else 1))
+            rec.setdefault(tag, []).append((s, e, 2.0 * m * n * k, nbytes))
         lib.conv_gemm = wrapped
 
     def summary(self):
         out = {}
         for tag, lst in self.rec.items():
-            ms = sum(s.elapsed_time(e) for s, e, _ in lst)
-            fl = sum(f for _, _, f in lst)
-            out[tag] = dict(launches=len(lst), ms_total=ms, flops_total=fl,
+            ms = sum(r[0].elapsed_time(r[1]) for r in lst)
+            fl = sum(r[2] for r in lst)
+            out[tag] = dict(launches=len(lst), ms_total=ms, flops_total=fl, bytes_total=sum(r[3] for r in lst),
                             avg_us=1e3 * ms / len(lst), tflops=fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0)
         return out
 
@@ -219,7 +241,10 @@ def main():
                        "gemm_gflop_per_image": round(flops_img / 1e9, 2)},
             "roofline": {"kernel": f"conv_gemm_kernel<{dom_tag}> (fp32 MFMA 16x16x4)", "bound": "mfma",
                          "achieved": round(dom["tflops"], 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(dom["tflops"] / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(dom["tflops"] / F32_MFMA_PEAK_TFLOPS, 4),
+                         "traffic": measured_traffic(dom_tag) if (B, S, K, args.arch, args.mode) == (32, 640, 80, "base", "detect") else None,
+                         "traffic_unit": "HBM bytes per launch (PMC, separate rocprofv3 passes)",
+                         "algorithmic_bytes_per_launch": round(dom["bytes_total"] / dom["launches"]),
                          "launches_per_step": dom["launches"] // args.steps, "avg_launch_us": round(dom["avg_us"], 2),
                          "algorithmic_gflop_per_launch": round(dom["flops_total"] / dom["launches"] / 1e9, 3)},
             "gemm_kernels": {k: {"launches_per_step": v["launches"] // args.steps, "avg_us": round(v["avg_us"], 2),

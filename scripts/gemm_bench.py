@@ -14,6 +14,8 @@ SHAPES = {
     "s3_pw2 51200x512x2048 res": dict(m=51200, n=512, k=2048, res=True),
     "s1_pw1 819200x512x128 gelu": dict(m=819200, n=512, k=128, act=L.ACT_GELU),
     "s2_pw2 204800x256x1024 res": dict(m=204800, n=256, k=1024, res=True),
+    "plain 51200x128x1152 silu": dict(m=51200, n=128, k=1152, act=L.ACT_SILU),
+    "plain 12800x256x2304 silu": dict(m=12800, n=256, k=2304, act=L.ACT_SILU),
     "s4_pw1 12800x4096x1024 gelu": dict(m=12800, n=4096, k=1024, act=L.ACT_GELU),
     "s4_pw2 12800x1024x4096 res": dict(m=12800, n=1024, k=4096, res=True),
     "sim 268800x80x768 sigm": dict(m=268800, n=80, k=768, sim=True),
@@ -23,7 +25,7 @@ SHAPES = {
     "conv3 128->256 @80 silu": dict(conv=(32, 80, 80, 128, 256)),
     "conv3 512->256 @20 silu": dict(conv=(32, 20, 20, 512, 256)),
 }
-GROUPS = {"big": [3, 13, 14, 15, 16, 3, 13], "sim": [10], "conv": [3]}
+GROUPS = {"big": [None, 13, 3], "sim": [10], "conv": [None, 13, 3]}
 import ctypes
 _old_path = os.path.join(os.path.dirname(L.LIB_PATH), "libwedetect_old_gemm.so")
 OLD = ctypes.CDLL(_old_path) if os.path.exists(_old_path) else None

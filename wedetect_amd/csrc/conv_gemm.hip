@@ -103,14 +103,26 @@ struct ALoader {
     }
   }
 
-  __device__ __forceinline__ void load(int k, f32x4 (&reg)[A_PT]) const {
+  // kbase = K-step origin (wave-uniform), kc4 = this thread's offset inside the step.
+  // When cin is a multiple of the K step a step never straddles a filter tap, so the tap
+  // decomposition is the same for every thread and runs on the scalar unit.
+  template <int BKS>
+  __device__ __forceinline__ void load(int kbase, int kc4, f32x4 (&reg)[A_PT]) const {
+    const int k = kbase + kc4;
     const bool kok = k < K;
     int kh = 0, kw = 0, ci = kok ? k : 0;
     if (CONV) {
-      const int tap = k / cin;
-      ci = k - tap * cin;
-      kh = tap / kw_;
-      kw = tap - kh * kw_;
+      if (cin % BKS == 0) {
+        const int tap = kbase / cin;
+        ci = kbase - tap * cin + kc4;
+        kh = tap / kw_;
+        kw = tap - kh * kw_;
+      } else {
+        const int tap = k / cin;
+        ci = k - tap * cin;
+        kh = tap / kw_;
+        kw = tap - kh * kw_;
+      }
     }
 #pragma unroll
     for (int i = 0; i < A_PT; ++i) {
@@ -141,7 +153,9 @@ struct RegionLoader {
 #pragma unroll
     for (int i = 0; i < A_PT; ++i) row[i] = r0 + i * RSTEP;
   }
-  __device__ __forceinline__ void load(int k, f32x4 (&reg)[A_PT]) const {
+  template <int BKS>
+  __device__ __forceinline__ void load(int kbase, int kc4, f32x4 (&reg)[A_PT]) const {
+    const int k = kbase + kc4;
 #pragma unroll
     for (int i = 0; i < A_PT; ++i) {
       const bool valid = row[i] < rows && k < dim;
@@ -217,7 +231,7 @@ __device__ __forceinline__ void gemm_mainloop(const AL& al, const float* __restr
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  al.load(kc * 4, areg);
+  al.template load<BK>(0, kc * 4, areg);
   load_b(kc * 4);
   store(0);
   __syncthreads();
@@ -226,7 +240,7 @@ __device__ __forceinline__ void gemm_mainloop(const AL& al, const float* __restr
   for (int kt = 1; kt < nk; ++kt) {
     const int k = kt * BK + kc * 4;
     if (!(VAR & ABL_NOLOAD)) {
-      al.load(k, areg);            // tile kt: global -> VGPR, in flight during the MFMAs of tile kt-1
+      al.template load<BK>(kt * BK, kc * 4, areg);   // tile kt: global -> VGPR, in flight during the MFMAs of tile kt-1
       load_b(k);
     }
     compute(cur);
