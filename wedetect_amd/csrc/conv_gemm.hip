@@ -367,9 +367,9 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const WdConvGem
 // ---------------------------------------------------------------------------------------
 // retrieval similarity: one workgroup = (64 classes, one image of <= 320 region rows)
 // ---------------------------------------------------------------------------------------
-constexpr int RT_TM = 5, RT_TN = 4, RT_WM = 4, RT_WN = 1;   // 320 rows x 64 classes
+constexpr int RT_TM = 5, RT_TN = 2, RT_WM = 4, RT_WN = 2;   // 320 rows x 64 classes, 8 waves of 80 x 32
 
-__global__ void __launch_bounds__(256) retrieval_max_kernel(const float* __restrict__ e, const float* __restrict__ tb,
+__global__ void __launch_bounds__(64 * RT_WM * RT_WN) retrieval_max_kernel(const float* __restrict__ e, const float* __restrict__ tb,
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ bias,
                                                             const int* __restrict__ count, float* __restrict__ out,
@@ -377,6 +377,7 @@ __global__ void __launch_bounds__(256) retrieval_max_kernel(const float* __restr
   using T = Tile<RT_TM, RT_TN, RT_WM, RT_WN>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave / RT_WN, wn = wave % RT_WN;
   const int img = blockIdx.y;
   const int n0 = blockIdx.x * T::BN;
 
@@ -393,7 +394,7 @@ __global__ void __launch_bounds__(256) retrieval_max_kernel(const float* __restr
     for (int r = 0; r < 4; ++r) cmax[tn][r] = 0.f;   // sigmoid > 0: 0 is the identity of max here
 #pragma unroll
   for (int tm = 0; tm < RT_TM; ++tm) {
-    const int row = (wave * RT_TM + tm) * 16 + (lane & 15);
+    const int row = (wm * RT_TM + tm) * 16 + (lane & 15);
     if (row < cnt && row < rows_per_img) {
       const float s = expf(scale[(size_t)img * rows_per_img + row]);
       const float b = bias[(size_t)img * rows_per_img + row];
@@ -416,12 +417,12 @@ __global__ void __launch_bounds__(256) retrieval_max_kernel(const float* __restr
       cmax[tn][r] = v;
     }
   __syncthreads();                 // all waves are done with the operand tiles in LDS
-  float* red = smem;               // [4 waves][64 classes]
+  float* red = smem;               // [RT_WM row groups][64 classes]
   if ((lane & 15) == 0) {
 #pragma unroll
     for (int tn = 0; tn < RT_TN; ++tn)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[wave * 64 + tn * 16 + 4 * (lane >> 4) + r] = cmax[tn][r];
+      for (int r = 0; r < 4; ++r) red[wm * 64 + (wn * RT_TN + tn) * 16 + 4 * (lane >> 4) + r] = cmax[tn][r];
   }
   __syncthreads();
   if (t < 64) {
@@ -588,7 +589,7 @@ extern "C" int wd_retrieval_max(const float* e, const float* t, const float* sca
     attr = true;
   }
   const int nbn = (n_cls + T::BN - 1) / T::BN;
-  hipLaunchKernelGGL(retrieval_max_kernel, dim3(nbn, n_img), dim3(256), T::LDS_BYTES,
+  hipLaunchKernelGGL(retrieval_max_kernel, dim3(nbn, n_img), dim3(T::NT), T::LDS_BYTES,
                      static_cast<hipStream_t>(stream), e, t, scale, bias, count, out, rows_per_img, n_cls, dim);
   return wd_launch_status();
 }
