@@ -36,6 +36,8 @@ namespace {
 // Template int VAR — variants selectable through wd_conv_gemm_tuned for on-device A/B runs
 // (profiles/r01_gemm_ab.txt records what was measured).
 constexpr int VAR_PRIO = 1;        // s_setprio(1) over the MFMA cluster (measured: null)
+constexpr int VAR_PIN = 2;         // sched_barrier fences: loads first, MFMAs, then wait + LDS store
+                                   // (measured: +8 % on small low-occupancy problems, -4..-10 % on saturated ones)
 constexpr int VAR_XCD = 256;       // XCD-aware tile order: each XCD's L2 sees whole A row panels (+0..5 %)
 // timing-only ablations (WRONG results by construction): skip the in-loop global loads / LDS
 // stores / barrier / the epilogue / the epilogue's stores
@@ -243,7 +245,12 @@ __device__ __forceinline__ void gemm_mainloop(const AL& al, const float* __restr
       al.template load<BK>(kt * BK, kc * 4, areg);   // tile kt: global -> VGPR, in flight during the MFMAs of tile kt-1
       load_b(k);
     }
+    // Without these fences hipcc sinks the two global loads down to their only consumer (the
+    // ds_write at the end of the step) and waits for them on the spot, exposing the whole
+    // memory round trip every K step; pinned, the loads fly during this step's MFMAs.
+    if (VAR & VAR_PIN) __builtin_amdgcn_sched_barrier(0);
     compute(cur);
+    if (VAR & VAR_PIN) __builtin_amdgcn_sched_barrier(0);
     if (!(VAR & ABL_NOLDS)) store(cur ^ 1);
     if (!(VAR & ABL_NOBAR)) __syncthreads();
     cur ^= 1;
@@ -564,6 +571,10 @@ extern "C" int wd_conv_gemm_tuned(const WdConvGemm* pp, int32_t cfg, void* strea
     case 11: return launch_cfg<4, 5, 4, 1, 32, 0>(p, st);                 // 256x80x32, 4 waves (first cut)
     case 12: return launch_cfg<2, 5, 8, 1, 16, VAR_XCD>(p, st);           // 256x80x16, 8 waves
     case 13: return launch_cfg<2, 4, 2, 2, 16, VAR_XCD>(p, st);           // 64x128x16, 4 waves (production, small problems)
+    case 14: return launch_cfg<2, 4, 4, 2, 16, VAR_XCD | VAR_PIN>(p, st);
+    case 15: return launch_cfg<2, 4, 2, 2, 16, VAR_XCD | VAR_PIN>(p, st);
+    case 16: return launch_cfg<1, 5, 8, 1, 16, VAR_XCD | VAR_PIN>(p, st);
+    case 17: return launch_cfg<1, 4, 8, 1, 16, VAR_XCD | VAR_PIN>(p, st);
     case 20: return launch_cfg<2, 4, 4, 2, 16, VAR_XCD | ABL_NOLOAD>(p, st);
     case 21: return launch_cfg<2, 4, 4, 2, 16, VAR_XCD | ABL_NOBAR>(p, st);
     case 22: return launch_cfg<2, 4, 4, 2, 16, VAR_XCD | ABL_NOEPI>(p, st);
