@@ -7,7 +7,8 @@
 // top-k: 3-level radix select on the raw fp32 bit pattern (scores are positive, so the
 // unsigned bit pattern is monotone) -> exact threshold key T, then an ORDERED compaction
 // (elements > T, plus the lowest-index elements == T) into 64-bit composite keys
-// (~bits << 32 | flat_index), then a per-image bitonic sort of <= 32768 unique keys.
+// (~bits << 32 | flat_index), then a bitonic sort of <= 32768 unique keys per image, run as
+// LDS-resident 8192-key chunks (one workgroup each) plus three global-stride stages.
 // NMS: one wave per image; a 64-candidate chunk is first tested against the kept list
 // (LDS), then resolved sequentially inside the wave with ballots.  It stops at max_out
 // kept boxes, which equals slicing the full NMS result (greedy NMS is prefix-consistent).
@@ -234,64 +235,78 @@ __global__ void __launch_bounds__(256) topk_scatter_kernel(const float* __restri
 }
 
 // ---- per-image bitonic sort of the composite keys + unpack ----------------------------
-__global__ void __launch_bounds__(1024) topk_sort_kernel(unsigned long long* __restrict__ keys, int cap,
-                                                         const TopkState* __restrict__ state,
-                                                         int* __restrict__ out_idx, float* __restrict__ out_score,
-                                                         int* __restrict__ out_count) {
-  const int b = blockIdx.x, t = threadIdx.x;
-  const unsigned want = state[b].want;
-  unsigned long long* k = keys + (size_t)b * cap;
+// The network is cut into kernels so that every 8192-key chunk (64 KB of LDS) is its own
+// workgroup: (1) sort each chunk locally, ascending / descending by global position;
+// (2) for every merge wider than a chunk: the strides >= chunk in global memory (one launch
+// each), then the strides < chunk again per chunk in LDS.  7 launches for 32768 keys,
+// 4 x batch workgroups instead of one workgroup per image.  Entries [want, cap) hold ~0 and
+// sort last; n2 = next power of two >= want bounds the work.
+__device__ __forceinline__ int sort_n2(unsigned want) {
   int n2 = 1;
-  while (n2 < (int)want) n2 <<= 1;          // entries [want, cap) hold KEY_PAD and sort last
-  // Bitonic network with every stride below SORT_CHUNK done in LDS: chunks of 8192 keys
-  // (64 KB) are sorted locally, only the few large-stride stages of the last merges touch
-  // global memory (3 passes for 32768 keys instead of 120).
+  while (n2 < (int)want) n2 <<= 1;
+  return n2;
+}
+
+__device__ __forceinline__ void lds_bitonic_pass(unsigned long long* sk, int chunk, int base, int jj, int dir_bit) {
+  for (int i = threadIdx.x; i < chunk; i += 1024) {
+    const int p = i ^ jj;
+    if (p > i) {
+      const unsigned long long a = sk[i], c = sk[p];
+      const bool up = ((base + i) & dir_bit) == 0;
+      if ((a > c) == up) { sk[i] = c; sk[p] = a; }
+    }
+  }
+  __syncthreads();
+}
+
+// size == 0: phase A (full local sort of the chunk); size > chunk: tail strides of that merge
+__global__ void __launch_bounds__(1024) topk_sort_chunk_kernel(unsigned long long* __restrict__ keys, int cap,
+                                                               const TopkState* __restrict__ state, int size) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long sk[];
+  const int b = blockIdx.y, t = threadIdx.x;
+  const int n2 = sort_n2(state[b].want);
   const int chunk = n2 < SORT_CHUNK ? n2 : SORT_CHUNK;
-  auto lds_pass = [&](int base, int jj, int dir_bit) {
-    for (int i = t; i < chunk; i += 1024) {
-      const int p = i ^ jj;
-      if (p > i) {
-        const unsigned long long a = sk[i], c = sk[p];
-        const bool up = ((base + i) & dir_bit) == 0;
-        if ((a > c) == up) { sk[i] = c; sk[p] = a; }
-      }
-    }
-    __syncthreads();
-  };
-  // phase A: every chunk sorted on its own (ascending / descending alternately)
-  for (int base = 0; base < n2; base += chunk) {
-    for (int i = t; i < chunk; i += 1024) sk[i] = k[base + i];
-    __syncthreads();
+  const int base = blockIdx.x * SORT_CHUNK;
+  if (base >= n2 || (size != 0 && size > n2)) return;
+  unsigned long long* k = keys + (size_t)b * cap + base;
+  for (int i = t; i < chunk; i += 1024) sk[i] = k[i];
+  __syncthreads();
+  if (size == 0) {
     for (int sz = 2; sz <= chunk; sz <<= 1)
-      for (int jj = sz >> 1; jj > 0; jj >>= 1) lds_pass(base, jj, sz);
-    for (int i = t; i < chunk; i += 1024) k[base + i] = sk[i];
-    __syncthreads();
+      for (int jj = sz >> 1; jj > 0; jj >>= 1) lds_bitonic_pass(sk, chunk, base, jj, sz);
+  } else {
+    for (int jj = chunk >> 1; jj > 0; jj >>= 1) lds_bitonic_pass(sk, chunk, base, jj, size);
   }
-  // phase B: merges wider than a chunk — large strides in global memory, the rest in LDS
-  for (int size = chunk << 1; size <= n2; size <<= 1) {
-    for (int j = size >> 1; j >= chunk; j >>= 1) {
-      for (int i = t; i < n2; i += 1024) {
-        const int p = i ^ j;
-        if (p > i) {
-          const unsigned long long a = k[i], c = k[p];
-          const bool up = (i & size) == 0;
-          if ((a > c) == up) { k[i] = c; k[p] = a; }
-        }
-      }
-      __syncthreads();
-    }
-    for (int base = 0; base < n2; base += chunk) {
-      for (int i = t; i < chunk; i += 1024) sk[i] = k[base + i];
-      __syncthreads();
-      for (int jj = chunk >> 1; jj > 0; jj >>= 1) lds_pass(base, jj, size);
-      for (int i = t; i < chunk; i += 1024) k[base + i] = sk[i];
-      __syncthreads();
-    }
+  for (int i = t; i < chunk; i += 1024) k[i] = sk[i];
+}
+
+// one global-memory stage (stride j >= SORT_CHUNK) of the merge of width `size`
+__global__ void __launch_bounds__(256) topk_sort_global_kernel(unsigned long long* __restrict__ keys, int cap,
+                                                               const TopkState* __restrict__ state, int size, int j) {
+  const int b = blockIdx.y;
+  const int n2 = sort_n2(state[b].want);
+  if (size > n2) return;
+  unsigned long long* k = keys + (size_t)b * cap;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n2) return;
+  const int p = i ^ j;
+  if (p > i) {
+    const unsigned long long a = k[i], c = k[p];
+    const bool up = (i & size) == 0;
+    if ((a > c) == up) { k[i] = c; k[p] = a; }
   }
-  for (int i = t; i < cap; i += 1024) {
+}
+
+__global__ void __launch_bounds__(256) topk_unpack_kernel(const unsigned long long* __restrict__ keys, int cap,
+                                                          const TopkState* __restrict__ state,
+                                                          int* __restrict__ out_idx, float* __restrict__ out_score,
+                                                          int* __restrict__ out_count) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const unsigned want = state[b].want;
+  if (i < cap) {
     if (i < (int)want) {
-      const unsigned long long ck = k[i];
+      const unsigned long long ck = keys[(size_t)b * cap + i];
       out_idx[(size_t)b * cap + i] = (int)(unsigned)(ck & 0xFFFFFFFFull);
       out_score[(size_t)b * cap + i] = __uint_as_float(~(unsigned)(ck >> 32));
     } else {
@@ -299,7 +314,7 @@ __global__ void __launch_bounds__(1024) topk_sort_kernel(unsigned long long* __r
       out_score[(size_t)b * cap + i] = 0.f;
     }
   }
-  if (t == 0) out_count[b] = (int)want;
+  if (i == 0) out_count[b] = (int)want;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -346,8 +361,10 @@ __global__ void __launch_bounds__(64) nms_kernel(const int* __restrict__ cand_id
                                                  int* __restrict__ out_labels, int* __restrict__ out_anchors,
                                                  int* __restrict__ out_count) {
   __shared__ f32x4 kept_box[NMS_MAX_OUT];
-  __shared__ int kept_label[NMS_MAX_OUT];
+  __shared__ __attribute__((aligned(16))) int kept_label[NMS_MAX_OUT];
   const int b = blockIdx.x, lane = threadIdx.x;
+  for (int i = lane; i < NMS_MAX_OUT; i += 64) kept_label[i] = -2;      // never equals a candidate label
+  __syncthreads();
   const float* mt = meta + (size_t)b * 8;
   const bool pre = mt[7] != 0.f;
   const int count = cand_count[b];
@@ -359,27 +376,44 @@ __global__ void __launch_bounds__(64) nms_kernel(const int* __restrict__ cand_id
   int* ol = out_labels + (size_t)b * max_out;
   int* oa = out_anchors + (size_t)b * max_out;
   int nk = 0;
-  for (int base = 0; base < count && nk < max_out; base += 64) {
+  // software-pipelined candidate fetch: the (index -> anchor -> box) dependent loads of chunk
+  // c+1 are issued before chunk c is resolved, so their two memory round trips overlap with it
+  int n_anchor_ = 0, n_label = -1;
+  float n_score = 0.f;
+  f32x4 n_box = {0.f, 0.f, 0.f, 0.f};
+  auto fetch = [&](int base) {
     const int i = base + lane;
-    const bool valid = i < count;
-    int anchor = 0, label = -1;
-    float score = 0.f;
-    f32x4 box = {0.f, 0.f, 0.f, 0.f};
-    if (valid) {
+    n_anchor_ = 0; n_label = -1; n_score = 0.f; n_box = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (i < count) {
       const int idx = ci[i];
-      anchor = idx / k;
-      label = idx - anchor * k;
-      score = cs[i];
-      box = bx[anchor];
-      if (pre) box = rescale_box(box, mt);
+      n_anchor_ = idx / k;
+      n_label = idx - n_anchor_ * k;
+      n_score = cs[i];
+      n_box = bx[n_anchor_];
     }
+  };
+  fetch(0);
+  for (int base = 0; base < count && nk < max_out; base += 64) {
+    const bool valid = base + lane < count;
+    const int anchor = n_anchor_, label = n_label;
+    const float score = n_score;
+    f32x4 box = n_box;
+    if (base + 64 < count) fetch(base + 64);
+    if (valid && pre) box = rescale_box(box, mt);
     bool alive = valid;
-    for (int j = 0; j < nk; ++j) {
-      if (alive && kept_label[j] == label && iou_gt(kept_box[j], box, iou_thr)) alive = false;
+    // candidates vs. the kept list: labels are scanned four at a time (one broadcast
+    // ds_read_b128); the IoU test only runs on a class match (slots >= nk hold label -2)
+    for (int j = 0; j < nk; j += 4) {
+      const int4 l4 = *reinterpret_cast<const int4*>(&kept_label[j]);
+      if (alive && l4.x == label && iou_gt(kept_box[j], box, iou_thr)) alive = false;
+      if (alive && l4.y == label && iou_gt(kept_box[j + 1], box, iou_thr)) alive = false;
+      if (alive && l4.z == label && iou_gt(kept_box[j + 2], box, iou_thr)) alive = false;
+      if (alive && l4.w == label && iou_gt(kept_box[j + 3], box, iou_thr)) alive = false;
     }
+    // sequential resolution inside the chunk, visiting only the candidates that are still alive
     unsigned long long mask = __ballot(alive);
-    for (int p = 0; p < 64 && nk < max_out; ++p) {
-      if (!((mask >> p) & 1ull)) continue;
+    while (mask != 0ull && nk < max_out) {
+      const int p = __ffsll((long long)mask) - 1;          // lowest alive lane = next kept box
       f32x4 bp;
       bp[0] = __shfl(box[0], p, 64); bp[1] = __shfl(box[1], p, 64);
       bp[2] = __shfl(box[2], p, 64); bp[3] = __shfl(box[3], p, 64);
@@ -397,7 +431,7 @@ __global__ void __launch_bounds__(64) nms_kernel(const int* __restrict__ cand_id
       }
       ++nk;
       if (lane > p && alive && label == lp && iou_gt(bp, box, iou_thr)) alive = false;
-      mask = __ballot(alive);
+      mask = __ballot(alive && lane > p);
     }
     __syncthreads();   // single-wave workgroup: orders the LDS writes above before the next chunk's reads
   }
@@ -491,7 +525,17 @@ extern "C" int wd_topk_candidates(const float* scores, int32_t batch, int64_t n,
   hipLaunchKernelGGL(topk_scan_kernel, gimg, dim3(256), 0, st, blk, L.nblk);
   hipLaunchKernelGGL(topk_scatter_kernel, gchunk, dim3(256), 0, st, scores, (long long)n, thr, state, blk, L.nblk, keys,
                      L.cap);
-  hipLaunchKernelGGL(topk_sort_kernel, gimg, dim3(1024), SORT_CHUNK * 8, st, keys, L.cap, state, out_idx, out_score, out_count);
+  {
+    const int nchunk = (L.cap + SORT_CHUNK - 1) / SORT_CHUNK;
+    const dim3 gch(nchunk, batch), gel((L.cap + 255) / 256, batch);
+    hipLaunchKernelGGL(topk_sort_chunk_kernel, gch, dim3(1024), SORT_CHUNK * 8, st, keys, L.cap, state, 0);
+    for (int size = 2 * SORT_CHUNK; size <= L.cap; size <<= 1) {
+      for (int j = size >> 1; j >= SORT_CHUNK; j >>= 1)
+        hipLaunchKernelGGL(topk_sort_global_kernel, gel, dim3(256), 0, st, keys, L.cap, state, size, j);
+      hipLaunchKernelGGL(topk_sort_chunk_kernel, gch, dim3(1024), SORT_CHUNK * 8, st, keys, L.cap, state, size);
+    }
+    hipLaunchKernelGGL(topk_unpack_kernel, gel, dim3(256), 0, st, keys, L.cap, state, out_idx, out_score, out_count);
+  }
   return wd_launch_status();
 }
 
