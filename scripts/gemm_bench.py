@@ -25,7 +25,7 @@ SHAPES = {
     "conv3 128->256 @80 silu": dict(conv=(32, 80, 80, 128, 256)),
     "conv3 512->256 @20 silu": dict(conv=(32, 20, 20, 512, 256)),
 }
-GROUPS = {"big": [3, 14, 13, 15, 3, 14], "sim": [10, 16, 10, 16], "conv": [3, 14, 13, 15]}
+GROUPS = {"big": [3, 22, 13, 3, 22], "sim": [10, 10], "conv": [3, 13]}
 import ctypes
 _old_path = os.path.join(os.path.dirname(L.LIB_PATH), "libwedetect_old_gemm.so")
 OLD = ctypes.CDLL(_old_path) if os.path.exists(_old_path) else None

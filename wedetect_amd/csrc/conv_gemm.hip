@@ -40,8 +40,8 @@ constexpr int VAR_PIN = 2;         // sched_barrier fences: loads first, MFMAs, 
                                    // (measured: +8 % on small low-occupancy problems, -4..-10 % on saturated ones)
 constexpr int VAR_XCD = 256;       // XCD-aware tile order: each XCD's L2 sees whole A row panels (+0..5 %)
 // timing-only ablations (WRONG results by construction): skip the in-loop global loads / LDS
-// stores / barrier / the epilogue / the epilogue's stores
-constexpr int ABL_NOLOAD = 4, ABL_NOBAR = 8, ABL_NOEPI = 16, ABL_NOLDS = 32, ABL_NOSTORE = 128;
+// stores / barrier / the epilogue
+constexpr int ABL_NOLOAD = 4, ABL_NOBAR = 8, ABL_NOEPI = 16, ABL_NOLDS = 32;
 // Tried and dropped in round 1 (all bit-exact, none faster): prefetch two K steps ahead with two
 // register sets (-6..-13 %), hoisting / prefetching the epilogue operands (-9 %), staggering the
 // co-resident workgroups (0 %), sched_group_barrier interleave (0 %), v_mfma_f32_32x32x2_f32
@@ -260,10 +260,118 @@ __device__ __forceinline__ void gemm_mainloop(const AL& al, const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------
+// Epilogue.  Lane holds C[m = .. + (lane&15)][n = .. + 4*(lane>>4) + 0..3] per 16x16 tile.
+// SPECIAL = false: row-major output, no scale/bias/sigmoid (every MLP / conv layer);
+// SPECIAL = true : deconv scatter, batch-strided rows, per-level affine, sigmoid.
+// ---------------------------------------------------------------------------------------
+struct EpiCtx { int m0, n0, wm, wn, lane, vec_c, vec_res, vec_bias; };
+
+template <int ACT>
+__device__ __forceinline__ float act_fast(float v) {
+  if (ACT == WD_ACT_RELU) return fmaxf(v, 0.0f);
+  if (ACT == WD_ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));   // <= 2 ulp
+  if (ACT == WD_ACT_GELU) return wd_gelu(v);
+  return v;
+}
+
+template <int TM, int TN, int ACT, bool SPECIAL>
+__device__ __forceinline__ void epilogue(const WdConvGemm& p, const EpiCtx& ec, const f32x4 (&acc)[TM][TN]) {
+  const int lane = ec.lane;
+  const int ncq = p.n >> 2;   // deconv: channels per tap
+  const bool has_res = p.res != nullptr;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int m = ec.m0 + (ec.wm * TM + tm) * 16 + (lane & 15);
+    if (m >= p.m) continue;
+    size_t crow = (size_t)m;
+    int hw2 = 0;
+    float oscale = 1.0f, obias = 0.0f;
+    if (SPECIAL) {
+      if (p.out_mode == WD_OUT_DECONV2X2) {
+        const int wq = m % p.wout;
+        const int q = m / p.wout;
+        const int hq = q % p.hout;
+        const int b = q / p.hout;
+        crow = ((size_t)(b * 2 * p.hout + 2 * hq) * (2 * p.wout) + 2 * wq);   // pixel of tap (0,0)
+        hw2 = 2 * p.wout;
+      } else if (p.c_batch_stride > 0) {
+        const int hw = p.hout * p.wout;
+        const int b = m / hw;
+        crow = (size_t)b * p.c_batch_stride + (size_t)(m - b * hw);
+      }
+      oscale = p.out_scale; obias = p.out_bias;
+      if (p.seg_rows > 0) {
+        const int pos = m % p.seg_rows;
+        const int lvl = (pos >= p.seg_end0) + (pos >= p.seg_end1);
+        oscale = lvl == 0 ? p.seg_scale[0] : lvl == 1 ? p.seg_scale[1] : p.seg_scale[2];
+        obias = lvl == 0 ? p.seg_bias[0] : lvl == 1 ? p.seg_bias[1] : p.seg_bias[2];
+      }
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int n = ec.n0 + (ec.wn * TN + tn) * 16 + 4 * (lane >> 4);
+      if (n >= p.n) continue;
+      const f32x4 v = acc[tm][tn];
+      const bool full = n + 3 < p.n;
+      f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) {
+        if (full && ec.vec_bias) {
+          b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (n + r < p.n) b4[r] = p.bias[n + r];
+        }
+      }
+      float o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float x = act_fast<ACT>(v[r] + b4[r]);
+        if (SPECIAL) {
+          x = x * oscale + obias;
+          if (p.sigmoid) x = wd_sigmoid(x);
+        }
+        o[r] = x;
+      }
+      if (has_res) {
+        const float* rp = p.res + (size_t)m * p.ldres + n;
+        if (full && ec.vec_res) {
+          const f32x4 rv = *reinterpret_cast<const f32x4*>(rp);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] += p.res_alpha * rv[r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (n + r < p.n) o[r] += p.res_alpha * rp[r];
+        }
+      }
+      float* cp;
+      if (SPECIAL && p.out_mode == WD_OUT_DECONV2X2) {
+        const int tap = n / ncq, co = n - tap * ncq;
+        cp = p.c + (crow + (size_t)(tap >> 1) * hw2 + (tap & 1)) * p.ldc + co;
+      } else {
+        cp = p.c + crow * p.ldc + n;
+      }
+      if (full && ec.vec_c) {
+        *reinterpret_cast<f32x4*>(cp) = f32x4{o[0], o[1], o[2], o[3]};
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (n + r < p.n) cp[r] = o[r];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // conv / linear / similarity kernel
 // ---------------------------------------------------------------------------------------
+// Register budget: ask for the occupancy the tile was tuned at (the second __launch_bounds__
+// argument is waves per SIMD).  Without it hipcc spends AGPRs on the 4-wave kernels (137
+// registers, 3 waves per SIMD) and the 64x128 tile loses 8 %.
+constexpr int min_waves_per_simd(int waves, int acc_tiles) {
+  return (acc_tiles > 8) ? 1 : (waves == 4) ? 5 : (waves == 8) ? 6 : 1;
+}
+
 template <int TM, int TN, int WM, int WN, bool CONV, int BKT = 32, int VAR = 0>
-__global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const WdConvGemm p, int nbn, int vec_c, int vec_res, int vec_bias) {
+__global__ void __launch_bounds__(64 * WM * WN, min_waves_per_simd(WM * WN, TM * TN)) conv_gemm_kernel(const WdConvGemm p, int nbn, int vec_c, int vec_res, int vec_bias) {
   using T = Tile<TM, TN, WM, WN, BKT>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -293,80 +401,25 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const WdConvGem
     if (m0 + (int)(t % T::BM) < p.m) p.c[(size_t)(m0 + t % T::BM) * p.ldc + n0] = s4[0] + s4[1] + s4[2] + s4[3];
     return;
   }
-  // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + 4*(lane>>4) + 0..3] per tile
-  const int ncq = p.n >> 2;   // deconv: channels per tap
-#pragma unroll
-  for (int tm = 0; tm < TM; ++tm) {
-    const int m = m0 + (wm * TM + tm) * 16 + (lane & 15);
-    if (m >= p.m) continue;
-    size_t crow;
-    int hw2 = 0;
-    if (p.out_mode == WD_OUT_DECONV2X2) {
-      const int wq = m % p.wout;
-      const int q = m / p.wout;
-      const int hq = q % p.hout;
-      const int b = q / p.hout;
-      crow = ((size_t)(b * 2 * p.hout + 2 * hq) * (2 * p.wout) + 2 * wq);   // pixel of tap (0,0)
-      hw2 = 2 * p.wout;
-    } else if (p.c_batch_stride > 0) {
-      const int hw = p.hout * p.wout;
-      const int b = m / hw;
-      crow = (size_t)b * p.c_batch_stride + (size_t)(m - b * hw);
-    } else {
-      crow = (size_t)m;
+  // ---- epilogue, specialised at compile time on (activation, residual, plain/special output)
+  // so that the executed path is straight-line code: with the switches inside the unrolled
+  // element loops the epilogue was ~6000 instructions and 13 % of the short-K GEMMs.
+  const bool special = p.out_mode != WD_OUT_ROWS || p.c_batch_stride > 0 || p.seg_rows > 0 || p.sigmoid ||
+                       p.out_scale != 1.0f || p.out_bias != 0.0f;
+  EpiCtx ec{m0, n0, wm, wn, lane, vec_c, vec_res, vec_bias};
+  if (special) {
+    switch (p.act) {
+      case WD_ACT_RELU: epilogue<TM, TN, WD_ACT_RELU, true>(p, ec, acc); break;
+      case WD_ACT_SILU: epilogue<TM, TN, WD_ACT_SILU, true>(p, ec, acc); break;
+      case WD_ACT_GELU: epilogue<TM, TN, WD_ACT_GELU, true>(p, ec, acc); break;
+      default: epilogue<TM, TN, WD_ACT_NONE, true>(p, ec, acc); break;
     }
-    float oscale = p.out_scale, obias = p.out_bias;
-    if (p.seg_rows > 0) {
-      const int pos = m % p.seg_rows;
-      const int lvl = (pos >= p.seg_end0) + (pos >= p.seg_end1);
-      oscale = lvl == 0 ? p.seg_scale[0] : lvl == 1 ? p.seg_scale[1] : p.seg_scale[2];
-      obias = lvl == 0 ? p.seg_bias[0] : lvl == 1 ? p.seg_bias[1] : p.seg_bias[2];
-    }
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      const int n = n0 + (wn * TN + tn) * 16 + 4 * (lane >> 4);
-      if (n >= p.n) continue;
-      f32x4 v = acc[tm][tn];
-      const bool full = n + 3 < p.n;
-      float vb[4] = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) if (n + r < p.n) vb[r] = p.bias[n + r];
-      }
-      float o[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float x = v[r] + vb[r];
-        x = wd_act(x, p.act);
-        x = x * oscale + obias;
-        if (p.sigmoid) x = wd_sigmoid(x);
-        o[r] = x;
-      }
-      if (p.res) {
-        const float* rp = p.res + (size_t)m * p.ldres + n;
-        if (full && vec_res) {
-          const f32x4 rv = *reinterpret_cast<const f32x4*>(rp);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] += p.res_alpha * rv[r];
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) if (n + r < p.n) o[r] += p.res_alpha * rp[r];
-        }
-      }
-      float* cp;
-      if (p.out_mode == WD_OUT_DECONV2X2) {
-        const int tap = n / ncq, co = n - tap * ncq;
-        cp = p.c + (crow + (size_t)(tap >> 1) * hw2 + (tap & 1)) * p.ldc + co;
-      } else {
-        cp = p.c + crow * p.ldc + n;
-      }
-      if ((VAR & ABL_NOSTORE) && o[0] != -1.2345e30f) continue;
-      if (full && vec_c) {
-        *reinterpret_cast<f32x4*>(cp) = f32x4{o[0], o[1], o[2], o[3]};
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) if (n + r < p.n) cp[r] = o[r];
-      }
+  } else {
+    switch (p.act) {
+      case WD_ACT_RELU: epilogue<TM, TN, WD_ACT_RELU, false>(p, ec, acc); break;
+      case WD_ACT_SILU: epilogue<TM, TN, WD_ACT_SILU, false>(p, ec, acc); break;
+      case WD_ACT_GELU: epilogue<TM, TN, WD_ACT_GELU, false>(p, ec, acc); break;
+      default: epilogue<TM, TN, WD_ACT_NONE, false>(p, ec, acc); break;
     }
   }
 }
@@ -578,7 +631,6 @@ extern "C" int wd_conv_gemm_tuned(const WdConvGemm* pp, int32_t cfg, void* strea
     case 20: return launch_cfg<2, 4, 4, 2, 16, VAR_XCD | ABL_NOLOAD>(p, st);
     case 21: return launch_cfg<2, 4, 4, 2, 16, VAR_XCD | ABL_NOBAR>(p, st);
     case 22: return launch_cfg<2, 4, 4, 2, 16, VAR_XCD | ABL_NOEPI>(p, st);
-    case 23: return launch_cfg<2, 4, 4, 2, 16, VAR_XCD | ABL_NOSTORE>(p, st);
     case 24: return launch_cfg<2, 4, 4, 2, 16, VAR_XCD | ABL_NOLOAD | ABL_NOLDS | ABL_NOBAR | ABL_NOEPI>(p, st);
     default: return WD_ERR_UNSUPPORTED;
   }
