@@ -33,6 +33,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+F16_MFMA_PEAK_TFLOPS = 2516.6    # MI355X_MICROARCH.md: fp16/bf16 dense (v_mfma_f32_32x32x16_f16)
+SPLIT_PASSES = 3                 # fp16x3: hi*hi + hi*lo + lo*hi per fp32-accurate product
 # bench tag -> kernel symbol in the rocprofv3 traces / profiles/r01_traffic.json
 KERNEL_SYMBOL = {
     "128x128x16/8w/plain": "conv_gemm_kernel<2, 4, 4, 2, false, 16, 256>",
@@ -40,6 +42,9 @@ KERNEL_SYMBOL = {
     "64x128x16/4w/plain": "conv_gemm_kernel<2, 4, 2, 2, false, 16, 256>",
     "64x128x16/4w/conv": "conv_gemm_kernel<2, 4, 2, 2, true, 16, 256>",
     "128x80x16/8w/plain": "conv_gemm_kernel<1, 5, 8, 1, false, 16, 256>",
+    "fp16x3 128x256x16/8w/plain": "split_gemm_kernel<2, 2, 2, 4, 16, false, 258>",
+    "fp16x3 128x128x32/4w/plain": "split_gemm_kernel<2, 2, 2, 2, 32, false, 258>",
+    "fp16x3 128x128x32/4w/conv": "split_gemm_kernel<2, 2, 2, 2, 32, true, 258>",
 }
 
 
@@ -67,6 +72,9 @@ def parse():
     ap.add_argument("--mode", choices=["detect", "uni"], default="detect",
                     help="detect: normalised text bank, thr 0.001, rescale-before-NMS (configs[1]); "
                          "uni: WeDetect-Uni prompts as stored, thr 0.0, NMS in network pixels (configs[3])")
+    ap.add_argument("--precision", choices=["fp32", "fp16x3"], default=None,
+                    help="arithmetic of the dense convs/linears (default: wedetect_amd.engine.DEFAULT_PRECISION); "
+                         "fp16x3 = fp32 operands split into fp16 hi+lo, three MFMA passes, fp32 accumulate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=8)
     return ap.parse_args()
@@ -93,7 +101,7 @@ class GemmTimer:
             wout = (win + 2 * pad - kw_) // stride + 1
             m, n, k = kw["batch"] * hout * wout, kw["n"], kh * kw_ * kw["cin"]
             plain = kh == 1 and kw_ == 1 and stride == 1 and pad == 0
-            tag = lib.gemm_config(m, n, k) + ("/plain" if plain else "/conv")
+            tag = lib.gemm_config(m, n, k, split=kw.get("w_split") is not None) + ("/plain" if plain else "/conv")
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             orig(a, w, bias, c, **kw)
@@ -175,7 +183,9 @@ def main():
     from wedetect_amd.parallel import gather_regions
 
     B, S, K = args.batch, args.size, args.classes
-    tower = ImageTower(args.arch, pack(W.make_state_dict(args.arch), args.arch), B, S, S, max_classes=K)
+    tower = ImageTower(args.arch, pack(W.make_state_dict(args.arch), args.arch), B, S, S, max_classes=K,
+                       precision=args.precision)
+    split = tower.precision == "fp16x3"
     images = torch.from_numpy(W.make_images(B, S, S, seed=1234 + rank)).cuda()
     text = torch.from_numpy(W.make_text_bank(K)).cuda()
     meta = tower.identity_meta()
@@ -220,8 +230,14 @@ def main():
         sim_tag = L.gemm_config(B * tower.ntot, K, 768) + "/plain"
         sim = summ.get(sim_tag)
         flops_img = sum(v["flops_total"] for v in summ.values()) / (args.steps * B)
+        dom_split = dom_tag.startswith("fp16x3")
+        # fp16x3 issues three fp16 MFMA passes per fp32-accurate product: the roof for ALGORITHMIC
+        # flops is the fp16 dense peak / 3; the fraction of the raw fp16 peak is reported beside it.
+        dom_peak = round(F16_MFMA_PEAK_TFLOPS / SPLIT_PASSES, 1) if dom_split else F32_MFMA_PEAK_TFLOPS
+        dom_kernel = (f"split_gemm_kernel<{dom_tag}> (3 x v_mfma_f32_32x32x16_f16 per product)" if dom_split
+                      else f"conv_gemm_kernel<{dom_tag}> (fp32 MFMA 16x16x4)")
         out = {
-            "metric": "images/s at 640x640 (WeDetect-Base image tower + 80-class similarity + top-k/NMS)",
+            "metric": f"images/s at {S}x{S} (WeDetect-{args.arch.capitalize()} image tower + {K}-class similarity + top-k/NMS)",
             "value": round(world * B * args.steps / dt, 3),
             "unit": "images/s",
             "n_gpus": world,
@@ -231,17 +247,20 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f16x3 (fp32 operands as fp16 hi+lo, fp32 accumulate; similarity GEMM, dwconv, LN, post-process f32)" if split else "f32",
             "data": "synthetic",
             "config": {"workload": f"WeDetect-{args.arch.capitalize()}, batch {B}x{S}x{S} per GPU, {K}-class similarity, "
                                    f"thr {0.0 if uni else 0.001} / nms_pre 30000 / NMS 0.7 / 300 per image, mode {args.mode}",
                        "global_batch": world * B, "per_gpu_batch": B, "image": [S, S], "classes": K,
                        "parallelism": f"image-shard x{world}" + (" + all-gather of kept-region embeddings" if world > 1 else ""),
-                       "kept_regions_last_step_rank0": kept,
+                       "precision": tower.precision, "kept_regions_last_step_rank0": kept,
                        "gemm_gflop_per_image": round(flops_img / 1e9, 2)},
-            "roofline": {"kernel": f"conv_gemm_kernel<{dom_tag}> (fp32 MFMA 16x16x4)", "bound": "mfma",
-                         "achieved": round(dom["tflops"], 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(dom["tflops"] / F32_MFMA_PEAK_TFLOPS, 4),
+            "roofline": {"kernel": dom_kernel, "bound": "mfma",
+                         "achieved": round(dom["tflops"], 2), "peak": dom_peak, "unit": "TFLOP/s",
+                         "frac": round(dom["tflops"] / dom_peak, 4),
+                         **({"peak_note": f"fp16 dense MFMA peak {F16_MFMA_PEAK_TFLOPS} / {SPLIT_PASSES} passes per product",
+                             "mfma_issued_tflops": round(SPLIT_PASSES * dom["tflops"], 1),
+                             "frac_of_fp16_peak": round(SPLIT_PASSES * dom["tflops"] / F16_MFMA_PEAK_TFLOPS, 4)} if dom_split else {}),
                          "traffic": measured_traffic(dom_tag) if (B, S, K, args.arch, args.mode) == (32, 640, 80, "base", "detect") else None,
                          "traffic_unit": "HBM bytes per launch (PMC, separate rocprofv3 passes)",
                          "algorithmic_bytes_per_launch": round(dom["bytes_total"] / dom["launches"]),

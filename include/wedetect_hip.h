@@ -106,6 +106,23 @@ int wd_conv_gemm(const WdConvGemm* p, void* stream);
  * No argument validation beyond the config id; used by scripts/gemm_bench.py only. */
 int wd_conv_gemm_tuned(const WdConvGemm* p, int32_t cfg, void* stream);
 
+/* ---- fp16x3 variant of wd_conv_gemm --------------------------------------------------------
+ * Same contraction, same WdConvGemm description (p->w is ignored), same epilogue, computed with
+ * three v_mfma_f32_32x32x16_f16 per product on operands split into fp16 (hi, lo) halves:
+ * fp32-equivalent accuracy (2^-22 relative per operand) at the fp16 matrix rate.  Replaces the
+ * same reference sites as wd_conv_gemm (nn.Linear / nn.Conv2d in mm_backbone.py:112-125,
+ * yolo_world_pafpn.py, yolo_world_head.py); the reference computes them in fp32.
+ * Activations must be finite with |x| < 65504.  Weights are prepared once:
+ *   wd_split_weights_bytes(n, k)  -> size of the split buffer (rows padded to 16 k)
+ *   wd_split_weights(w, n, k, scale, out): out <- halves of w * scale, scale a power of two
+ *     chosen by the caller so that max|w| * scale <= 2^14; pass w_unscale = 1 / scale below.
+ * cfg < 0 picks the production tile; cfg >= 0 selects a tile for A/B runs (split_gemm.hip). */
+int64_t wd_split_weights_bytes(int32_t n, int32_t k);
+int wd_split_weights(const float* w, int32_t n, int32_t k, float scale, void* out, void* stream);
+int wd_conv_gemm_split(const WdConvGemm* p, const void* w_split, float w_unscale, int32_t cfg, void* stream);
+/* Name of the tile wd_conv_gemm_split picks for (m, n, k) with cfg < 0 (diagnostic). */
+const char* wd_conv_gemm_split_config(int32_t m, int32_t n, int32_t k);
+
 /* sizeof(WdConvGemm) as compiled into the library, so a binding can verify its mirror. */
 int wd_sizeof_conv_gemm(void);
 

@@ -15,7 +15,11 @@ def _images():
     return [Image.fromarray(g.integers(0, 256, (h, w, 3), dtype=np.uint8)) for h, w in ((120, 200), (128, 64), (90, 90))]
 
 
-def test_simple_yolo_world_detector_matches_oracle_with_letterbox():
+BOTH = pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
+
+
+@BOTH
+def test_simple_yolo_world_detector_matches_oracle_with_letterbox(precision):
     """generate_proposal.py:1082-1117 end to end: PIL letterbox -> tower -> head_predict -> un-letterbox."""
     from oracle import postprocess as opp
     from oracle import ref_cpu as orc
@@ -23,7 +27,7 @@ def test_simple_yolo_world_detector_matches_oracle_with_letterbox():
     from wedetect_amd.arch import HD, get_arch
     from wedetect_amd.detector import SimpleYOLOWorldDetector, letterbox
     sd_np = W.make_state_dict("nano", num_prompts=32)
-    model = SimpleYOLOWorldDetector("nano", prompt_dim=768, num_prompts=32, num_proposals=100)
+    model = SimpleYOLOWorldDetector("nano", prompt_dim=768, num_prompts=32, num_proposals=100, precision=precision)
     msg = model.load_state_dict({k: torch.from_numpy(v) for k, v in W.to_uni_keys(sd_np).items()}, strict=False)
     assert not msg.missing_keys
     model = model.cuda()
@@ -56,7 +60,8 @@ def test_simple_yolo_world_detector_matches_oracle_with_letterbox():
         assert float(out["bboxes"].min()) >= 0 and float(out["bboxes"][:, 0::2].max()) <= img.size[0]
 
 
-def test_yolo_world_detector_test_step_matches_oracle():
+@BOTH
+def test_yolo_world_detector_test_step_matches_oracle(precision):
     """infer_wedetect.py:102-131: BGR CHW uint8 inputs + data samples with letterbox metadata."""
     from oracle import postprocess as opp
     from oracle import ref_cpu as orc
@@ -66,7 +71,7 @@ def test_yolo_world_detector_test_step_matches_oracle():
     sd_np = W.make_state_dict("nano")
     k = 81                                                       # 80 classes + the blank the demo appends
     bank = W.make_text_bank(k) * np.float32(2.5)
-    model = YOLOWorldDetector("nano", test_cfg=dict(max_per_img=50), max_classes=k)
+    model = YOLOWorldDetector("nano", test_cfg=dict(max_per_img=50), max_classes=k, precision=precision)
     model.load_state_dict({"state_dict": {n: torch.from_numpy(v) for n, v in sd_np.items()}})
     model.cuda().eval()
     with pytest.raises(RuntimeError):
@@ -95,7 +100,8 @@ def test_yolo_world_detector_test_step_matches_oracle():
         assert 0 < len(keep) <= 50 and keep.cpu().numpy()["bboxes"].shape[1] == 4
 
 
-def test_large_lvis_bank_config3_small_input():
+@BOTH
+def test_large_lvis_bank_config3_small_input(precision):
     """WeDetect-Large tower with a 1203-class bank (BASELINE configs[2]) at 128x128 so the CPU
     oracle stays quick: scores parity and exact post-process on >400k candidates per image."""
     from oracle import postprocess as opp
@@ -106,7 +112,7 @@ def test_large_lvis_bank_config3_small_input():
     from wedetect_amd.pack import pack
     arch, b, hw, k = "large", 2, 128, 1203
     sd_np = W.make_state_dict(arch)
-    tower = ImageTower(arch, pack(sd_np, arch), b, hw, hw, max_classes=k)
+    tower = ImageTower(arch, pack(sd_np, arch), b, hw, hw, max_classes=k, precision=precision)
     imgs = W.make_images(b, hw, hw)
     bank = W.make_text_bank(k)
     sd = orc.to_torch(sd_np)

@@ -15,9 +15,18 @@ from tests.util import assert_close, check_checksum, golden, to_np
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-3
+PRECISION = {"value": "fp32"}
+
+
+@pytest.fixture(params=["fp32", "fp16x3"], autouse=True)
+def precision(request):
+    """Every network-level parity test runs in both arithmetic modes at the SAME tolerances."""
+    PRECISION["value"] = request.param
+    yield request.param
 
 
 def build(arch, b, hw, num_prompts=256, seed=2026, **kw):
+    kw.setdefault("precision", PRECISION["value"])
     from wedetect_amd import weights as W
     from wedetect_amd.engine import ImageTower
     from wedetect_amd.pack import pack

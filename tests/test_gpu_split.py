@@ -1,0 +1,158 @@
+"""fp16x3 GEMM (wd_conv_gemm_split) parity: against float64 math and against the fp32 MFMA
+kernel, over every tile configuration, conv geometry, epilogue mode and ragged size."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import assert_close, to_np
+
+pytestmark = pytest.mark.gpu
+
+ALL_CFGS = [-1] + list(range(18))
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return torch.randn(*shape, device="cuda", generator=g) * scale
+
+
+def test_split_weights_layout_bit_exact():
+    """wd_split_weights == numpy restatement: per row, per 8 k: [8 hi | 8 lo] fp16 of w * scale."""
+    from wedetect_amd import lib as L
+    for n, k in ((5, 48), (130, 24), (64, 1152)):
+        w = _rand((n, k), 1, 0.05)
+        buf, unscale = L.split_weights(w)
+        scale = 1.0 / unscale
+        assert scale == 2.0 ** round(np.log2(scale)) and float(w.abs().max()) * scale <= 2 ** 14
+        k16 = (k + 15) // 16 * 16
+        x = np.zeros((n, k16), np.float32)
+        x[:, :k] = to_np(w) * np.float32(scale)
+        hi = x.astype(np.float16)
+        lo = (x - hi.astype(np.float32)).astype(np.float16)
+        want = np.stack([hi.reshape(n, k16 // 8, 8), lo.reshape(n, k16 // 8, 8)], axis=2).reshape(n, 2 * k16)
+        got = to_np(buf).view(np.float16).reshape(n, 2 * k16)
+        assert np.array_equal(got.view(np.uint16), want.view(np.uint16))
+        # hi + lo reproduces the scaled weight to 2^-22 relative
+        rec = hi.astype(np.float64) + lo.astype(np.float64)
+        assert np.max(np.abs(rec - x) / np.maximum(np.abs(x), 1e-30)) < 2.0 ** -21
+
+
+def _ref64(a, w, b, act, res=None, res_alpha=1.0):
+    y = a.double() @ w.double().T + b.double()
+    if act == "relu":
+        y = torch.relu(y)
+    elif act == "silu":
+        y = y * torch.sigmoid(y)
+    elif act == "gelu":
+        y = torch.nn.functional.gelu(y)
+    if res is not None:
+        y = y + res_alpha * res.double()
+    return y
+
+
+@pytest.mark.parametrize("cfg", ALL_CFGS)
+def test_split_gemm_plain_all_tiles(cfg):
+    """Ragged m / n / k (tails in every dimension), bias + GELU, then residual: vs float64."""
+    from wedetect_amd import lib as L
+    m, n, k = 1000, 328, 200
+    a, w, b = _rand((m, k), 2), _rand((n, k), 3, k ** -0.5), _rand((n,), 4)
+    ws = L.split_weights(w)
+    c = torch.full((m, n), float("nan"), device="cuda")
+    L.conv_gemm(a, None, b, c, batch=1, hin=1, win=m, cin=k, lda=k, n=n, ldc=n, act=L.ACT_GELU, w_split=ws,
+                split_cfg=cfg)
+    assert_close(f"split gelu cfg{cfg}", c, _ref64(a, w, b, "gelu"), 6e-6, 2e-6)
+    r = _rand((m, n), 5)
+    L.conv_gemm(a, None, b, c, batch=1, hin=1, win=m, cin=k, lda=k, n=n, ldc=n, res=r, ldres=n, res_alpha=0.5,
+                w_split=ws, split_cfg=cfg)
+    assert_close(f"split res cfg{cfg}", c, _ref64(a, w, b, None, r, 0.5), 6e-6, 2e-6)
+
+
+def test_split_gemm_accuracy_is_fp32_level():
+    """Long K, wide dynamic range: the fp16x3 error against float64 stays within 2x of the fp32 MFMA
+    kernel's own error (both are accumulation-rounding dominated)."""
+    from wedetect_amd import lib as L
+    m, n, k = 512, 256, 4096
+    g = torch.Generator(device="cuda").manual_seed(11)
+    a = torch.randn(m, k, device="cuda", generator=g) * torch.exp(2.0 * torch.randn(m, k, device="cuda", generator=g))
+    w = _rand((n, k), 12, k ** -0.5) * torch.exp(_rand((n, k), 13))
+    b = _rand((n,), 14)
+    ref = _ref64(a, w, b, None)
+    c32, c16 = torch.empty(m, n, device="cuda"), torch.empty(m, n, device="cuda")
+    L.conv_gemm(a, w, b, c32, batch=1, hin=1, win=m, cin=k, lda=k, n=n, ldc=n)
+    L.conv_gemm(a, None, b, c16, batch=1, hin=1, win=m, cin=k, lda=k, n=n, ldc=n, w_split=L.split_weights(w))
+    e32 = float((c32.double() - ref).abs().max())
+    e16 = float((c16.double() - ref).abs().max())
+    rms32 = float((c32.double() - ref).pow(2).mean().sqrt())
+    rms16 = float((c16.double() - ref).pow(2).mean().sqrt())
+    print(f"max err fp32 {e32:.3e} fp16x3 {e16:.3e}; rms fp32 {rms32:.3e} fp16x3 {rms16:.3e}; |ref| max {float(ref.abs().max()):.1f}")
+    assert rms16 <= 2.0 * rms32 + 1e-7 and e16 <= 3.0 * e32 + 1e-6
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 9])
+@pytest.mark.parametrize("geom", [(3, 1, 1), (3, 2, 1), (2, 2, 0)])
+def test_split_conv_geometries(cfg, geom):
+    """Implicit-GEMM conv loader (3x3 s1/s2 with padding, 2x2 s2) + SiLU vs torch conv in float64."""
+    from wedetect_amd import lib as L
+    kk, stride, pad = geom
+    b_, h, w_, ci, co = 2, 18, 22, 32, 96
+    x = _rand((b_, h, w_, ci), 21)
+    wt = _rand((co, ci, kk, kk), 22, (ci * kk * kk) ** -0.5)
+    bias = _rand((co,), 23)
+    wrow = wt.permute(0, 2, 3, 1).reshape(co, kk * kk * ci).contiguous()
+    ho, wo = (h + 2 * pad - kk) // stride + 1, (w_ + 2 * pad - kk) // stride + 1
+    c = torch.empty(b_ * ho * wo, co, device="cuda")
+    L.conv_gemm(x, None, bias, c, batch=b_, hin=h, win=w_, cin=ci, lda=ci, kh=kk, kw=kk, stride=stride, pad=pad, n=co,
+                ldc=co, act=L.ACT_SILU, w_split=L.split_weights(wrow), split_cfg=cfg)
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), wt.double(), bias.double(), stride=stride,
+                                     padding=pad)
+    ref = (ref * torch.sigmoid(ref)).permute(0, 2, 3, 1).reshape(-1, co)
+    assert_close(f"split conv k{kk}s{stride} cfg{cfg}", c, ref, 6e-6, 2e-6)
+
+
+def test_split_special_epilogues_match_fp32_kernel():
+    """Channel-slice output (ldc > n), batch-strided rows, per-level affine + sigmoid, deconv scatter:
+    the fp16x3 kernel must land every element where the fp32 kernel does."""
+    from wedetect_amd import lib as L
+    # similarity-style: seg affine + sigmoid into [B, ntot, K] rows
+    m, n, k = 2 * 84, 80, 768
+    a, w = _rand((m, k), 31), torch.nn.functional.normalize(_rand((n, k), 32), dim=-1)
+    seg = (84, 64, 80, (0.7, 0.58, 0.82), (-2.6, -2.2, -1.9))
+    c0, c1 = torch.zeros(m, n, device="cuda"), torch.zeros(m, n, device="cuda")
+    kw = dict(batch=2, hin=1, win=84, cin=k, lda=k, n=n, ldc=n, sigmoid=True, seg=seg)
+    L.conv_gemm(a, w, None, c0, **kw)
+    L.conv_gemm(a, None, None, c1, w_split=L.split_weights(w), **kw)
+    assert_close("split seg+sigmoid", c1, c0, 2e-6)
+    # concat slice + batch stride: level rows written into a [B, 100, 64+32] buffer at column 64, row 10
+    bsz, hw, cin, co = 2, 36, 64, 32
+    a = _rand((bsz * hw, cin), 33)
+    w, bias = _rand((co, cin), 34, 0.1), _rand((co,), 35)
+    big0 = torch.zeros(bsz, 100, 96, device="cuda")
+    big1 = torch.zeros(bsz, 100, 96, device="cuda")
+    kw = dict(batch=bsz, hin=6, win=6, cin=cin, lda=cin, n=co, ldc=96, act=L.ACT_RELU, c_batch_stride=100)
+    L.conv_gemm(a, w, bias, big0[0, 10:, 64:], **kw)
+    L.conv_gemm(a, None, bias, big1[0, 10:, 64:], w_split=L.split_weights(w), **kw)
+    assert_close("split slice/batch-stride", big1, big0, 2e-6)
+    assert float(big1[:, :10].abs().max()) == 0 and float(big1[:, :, :64].abs().max()) == 0
+    # 2x2 transposed conv scatter
+    bsz, h, w_, cin, co = 2, 5, 7, 32, 16
+    a = _rand((bsz * h * w_, cin), 36)
+    wd, bias = _rand((4 * co, cin), 37, 0.1), _rand((4 * co,), 38)
+    o0 = torch.zeros(bsz * 2 * h * 2 * w_, co, device="cuda")
+    o1 = torch.zeros_like(o0)
+    kw = dict(batch=bsz, hin=h, win=w_, cin=cin, lda=cin, n=4 * co, ldc=co, out_mode=L.OUT_DECONV2X2)
+    L.conv_gemm(a, wd, bias, o0, **kw)
+    L.conv_gemm(a, None, bias, o1, w_split=L.split_weights(wd), **kw)
+    assert_close("split deconv scatter", o1, o0, 2e-6)
+
+
+def test_split_gemm_rejects_bad_arguments():
+    from wedetect_amd import lib as L
+    a, w = _rand((64, 32), 41), _rand((32, 32), 42)
+    ws = L.split_weights(w)
+    c = torch.empty(64, 32, device="cuda")
+    with pytest.raises(L.WedetectHipError):
+        L.conv_gemm(a, None, None, c, batch=1, hin=1, win=64, cin=32, lda=32, n=32, ldc=32, w_split=(ws[0], 0.0))
+    with pytest.raises(L.WedetectHipError):
+        L.conv_gemm(a, None, None, c, batch=1, hin=1, win=64, cin=32, lda=32, n=32, ldc=32, w_split=ws, split_cfg=99)
+    with pytest.raises(L.WedetectHipError):
+        L.conv_gemm(a, None, None, c, batch=1, hin=1, win=64, cin=32, lda=32, n=32, ldc=16, w_split=ws)

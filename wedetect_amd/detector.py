@@ -93,8 +93,10 @@ def letterbox(img, new_shape=(640, 640), color=(114, 114, 114)):
 class _TowerHolder:
     """Shared plumbing: weights -> packed device tensors -> ImageTower per batch size."""
 
-    def __init__(self, arch: str, num_prompts: int, img_size, max_classes: int, max_out: int):
+    def __init__(self, arch: str, num_prompts: int, img_size, max_classes: int, max_out: int,
+                 precision: Optional[str] = None):
         self.arch = get_arch(arch)
+        self.precision = precision
         self.num_prompts = num_prompts
         self.img_size = tuple(img_size)
         self.max_classes, self.max_out = max_classes, max_out
@@ -133,7 +135,8 @@ class _TowerHolder:
             self._packed = pack(self._sd, self.arch, self.device)
         if batch not in self._towers:
             self._towers[batch] = ImageTower(self.arch, self._packed, batch, self.img_size[0], self.img_size[1],
-                                             device=self.device, max_classes=self.max_classes, max_out=self.max_out)
+                                             device=self.device, max_classes=self.max_classes, max_out=self.max_out,
+                                             precision=self.precision)
         return self._towers[batch]
 
 
@@ -143,13 +146,14 @@ class _TowerHolder:
 class SimpleYOLOWorldDetector:
     """Drop-in for generate_proposal.py:1052 / extract_embedding.py:1088."""
 
-    def __init__(self, backbone_size, prompt_dim=768, num_prompts=512, num_proposals=300, img_size=None):
+    def __init__(self, backbone_size, prompt_dim=768, num_prompts=512, num_proposals=300, img_size=None,
+                 precision: Optional[str] = None):
         if prompt_dim != EMBED_DIM:
             raise ValueError("prompt_dim must be 768")
         self.backbone_size = backbone_size
         self.num_proposals = num_proposals
         self.img_size = tuple(img_size) if img_size is not None else _IMG_SIZE[backbone_size]
-        self._h = _TowerHolder(backbone_size, num_prompts, self.img_size, max(num_prompts, 1), num_proposals)
+        self._h = _TowerHolder(backbone_size, num_prompts, self.img_size, max(num_prompts, 1), num_proposals, precision)
         self.training = False
 
     # -- nn.Module-like surface used by the reference scripts
@@ -251,7 +255,7 @@ class YOLOWorldDetector:
     ``set_text_embeddings``; ``reparameterize`` without either raises."""
 
     def __init__(self, model_size="base", img_scale=None, test_cfg=None, text_encoder: Optional[Callable] = None,
-                 max_classes: int = 1203):
+                 max_classes: int = 1203, precision: Optional[str] = None):
         cfg = dict(multi_label=True, nms_pre=30000, score_thr=0.001, nms=dict(type="nms", iou_threshold=0.7),
                    max_per_img=300)
         cfg.update(test_cfg or {})
@@ -260,7 +264,7 @@ class YOLOWorldDetector:
         self.test_cfg = cfg
         self.model_size = model_size
         self.img_scale = tuple(img_scale) if img_scale is not None else _IMG_SIZE[model_size]
-        self._h = _TowerHolder(model_size, 0, self.img_scale, max_classes, cfg["max_per_img"])
+        self._h = _TowerHolder(model_size, 0, self.img_scale, max_classes, cfg["max_per_img"], precision)
         self.text_encoder = text_encoder
         self.texts = None
         self.text_feats: Optional[torch.Tensor] = None

@@ -15,6 +15,7 @@ Reference call stack being replaced:
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -25,11 +26,28 @@ from .arch import ArchSpec, CLS_MID, EMBED_DIM, REG_MID, STRIDES, get_arch, leve
 from .pack import Packed
 
 
+DEFAULT_PRECISION = "fp16x3"
+
+
 class ImageTower:
+    PRECISIONS = ("fp32", "fp16x3")
+
     def __init__(self, arch, packed: Packed, batch: int, height: int, width: int, device="cuda",
-                 max_classes: int = 256, nms_pre: int = 30000, max_out: int = 300):
+                 max_classes: int = 256, nms_pre: int = 30000, max_out: int = 300,
+                 precision: Optional[str] = None):
+        """``precision``: arithmetic of the dense convs / linears of backbone, neck and head —
+        "fp32" = v_mfma_f32_16x16x4_f32 (conv_gemm.hip); "fp16x3" = three fp16 MFMA passes on
+        operands split into (hi, lo) halves, fp32-equivalent accuracy at 2-2.5x the speed
+        (split_gemm.hip).  The region x text similarity GEMM, depthwise convs, LayerNorm and
+        the post-process are fp32 in both modes.  None = $WEDETECT_PRECISION or DEFAULT_PRECISION."""
         self.a: ArchSpec = get_arch(arch) if isinstance(arch, str) else arch
         self.P = packed
+        if precision is None:
+            precision = os.environ.get("WEDETECT_PRECISION", DEFAULT_PRECISION)
+        if precision not in self.PRECISIONS:
+            raise ValueError(f"precision must be one of {self.PRECISIONS}")
+        self.precision = precision
+        self.Ws: Dict[str, tuple] = {}          # weight name -> (split buffer, unscale), fp16x3 mode only
         self.B, self.H, self.W = batch, height, width
         self.dev = torch.device(device)
         if height % 32 or width % 32:
@@ -101,11 +119,21 @@ class ImageTower:
         self.topk_ws = self.topk_ws[off:off + nbytes]
 
     # ------------------------------------------------------------------ helpers
+    def _gemm(self, a, w: str, b: Optional[str], c, **kw):
+        """One dense layer with packed weight ``w`` / bias ``b`` in the tower's precision."""
+        ws = None
+        if self.precision == "fp16x3":
+            ws = self.Ws.get(w)
+            if ws is None:                      # first use: split once, keep resident
+                wt = self.P[w]
+                ws = self.Ws[w] = L.split_weights(wt.view(wt.shape[0], -1))
+        L.conv_gemm(a, None if ws is not None else self.P[w], self.P[b] if b else None, c, batch=self.B,
+                    w_split=ws, **kw)
+
     def _conv(self, a, w, b, c, *, hin, win, cin, lda, n, ldc, k=1, stride=1, act=L.ACT_NONE, res=None, ldres=0,
               res_alpha=1.0, **kw):
-        L.conv_gemm(a, self.P[w], self.P[b] if b else None, c, batch=self.B, hin=hin, win=win, cin=cin, lda=lda,
-                    kh=k, kw=k, stride=stride, pad=(k // 2 if k == 3 else 0), n=n, ldc=ldc, act=act, res=res,
-                    ldres=ldres, res_alpha=res_alpha, **kw)
+        self._gemm(a, w, b, c, hin=hin, win=win, cin=cin, lda=lda, kh=k, kw=k, stride=stride,
+                   pad=(k // 2 if k == 3 else 0), n=n, ldc=ldc, act=act, res=res, ldres=ldres, res_alpha=res_alpha, **kw)
 
     # ------------------------------------------------------------------ backbone
     def backbone(self, images_u8: torch.Tensor) -> List[torch.Tensor]:
@@ -127,8 +155,8 @@ class ImageTower:
                 hp, wp = self.hw[i - 1]
                 L.layernorm_rows(self.x[i - 1], self.tmp, self.P[f"down{i}.ln_w"], self.P[f"down{i}.ln_b"],
                                  self.M[i - 1], cp)
-                L.conv_gemm(self.tmp, self.P[f"down{i}.w"], self.P[f"down{i}.b"], self.x[i], batch=B, hin=hp, win=wp,
-                            cin=cp, lda=cp, kh=2, kw=2, stride=2, pad=0, n=c, ldc=c)
+                self._gemm(self.tmp, f"down{i}.w", f"down{i}.b", self.x[i], hin=hp, win=wp, cin=cp, lda=cp, kh=2, kw=2,
+                           stride=2, pad=0, n=c, ldc=c)
             for j in range(a.depths[i]):
                 q = f"s{i}.{j}."
                 L.dwconv7(self.x[i], self.P[q + "dw_w"], self.P[q + "dw_b"], self.tmp, B, h, w, c)
@@ -171,8 +199,8 @@ class ImageTower:
         ht, wt = hw_top
         hm, wm = hw_mid
         hl, wl = hw_low
-        L.conv_gemm(top, self.P[name + ".up.w"], self.P[name + ".up.b"], cat, batch=B, hin=ht, win=wt, cin=cout,
-                    lda=ld_top, n=4 * cout, ldc=3 * cout, out_mode=L.OUT_DECONV2X2)
+        self._gemm(top, name + ".up.w", name + ".up.b", cat, hin=ht, win=wt, cin=cout, lda=ld_top, n=4 * cout,
+                   ldc=3 * cout, out_mode=L.OUT_DECONV2X2)
         self._conv(mid, name + ".cv1.w", name + ".cv1.b", cat[:, cout:], hin=hm, win=wm, cin=c_mid, lda=c_mid, n=cout,
                    ldc=3 * cout, act=L.ACT_RELU)
         self._conv(low, name + ".cv2.w", name + ".cv2.b", tbuf, hin=hl, win=wl, cin=c_low, lda=c_low, n=cout, ldc=cout,

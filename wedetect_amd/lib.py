@@ -8,6 +8,7 @@ stream; torch is used only for memory and streams.
 from __future__ import annotations
 
 import ctypes as C
+import math
 import os
 
 import torch
@@ -17,12 +18,13 @@ LIB_PATH = os.path.join(_HERE, "libwedetect_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU = 0, 1, 2, 3
 OUT_ROWS, OUT_DECONV2X2 = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 EXPORTS = (
     "wd_abi_version", "wd_strerror", "wd_sizeof_conv_gemm", "wd_conv_gemm", "wd_conv_gemm_tuned", "wd_conv_gemm_config", "wd_stem_patchify", "wd_dwconv7",
     "wd_layernorm_rows", "wd_l2norm_rows", "wd_dfl_decode", "wd_topk_workspace_bytes", "wd_topk_capacity",
     "wd_topk_candidates", "wd_nms_gather", "wd_retrieval_max",
+    "wd_split_weights_bytes", "wd_split_weights", "wd_conv_gemm_split", "wd_conv_gemm_split_config",
 )
 
 
@@ -81,6 +83,12 @@ def _load():
     lib.wd_topk_candidates.argtypes = [vp, i32, i64, f32, i32, vp, vp, vp, vp, i64, vp]
     lib.wd_nms_gather.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp, f32, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp]
     lib.wd_retrieval_max.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.wd_split_weights_bytes.restype = i64
+    lib.wd_split_weights_bytes.argtypes = [i32, i32]
+    lib.wd_split_weights.argtypes = [vp, i32, i32, f32, vp, vp]
+    lib.wd_conv_gemm_split.argtypes = [C.POINTER(ConvGemm), vp, f32, i32, vp]
+    lib.wd_conv_gemm_split_config.restype = C.c_char_p
+    lib.wd_conv_gemm_split_config.argtypes = [i32, i32, i32]
     if lib.wd_sizeof_conv_gemm() != C.sizeof(ConvGemm):
         raise WedetectHipMissing("struct WdConvGemm layout differs between the library and lib.ConvGemm; rebuild")
     if lib.wd_abi_version() != ABI_VERSION:
@@ -115,8 +123,10 @@ def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------
 def conv_gemm(a, w, bias, c, *, batch, hin, win, cin, lda, kh=1, kw=1, stride=1, pad=0, hout=None, wout=None,
               n, ldc, act=ACT_NONE, res=None, ldres=0, res_alpha=1.0, out_mode=OUT_ROWS,
-              out_scale=1.0, out_bias=0.0, sigmoid=False, c_batch_stride=0, seg=None, tuned_cfg=None) -> None:
-    """``seg`` = (seg_rows, seg_end0, seg_end1, (s0, s1, s2), (b0, b1, b2)) or None."""
+              out_scale=1.0, out_bias=0.0, sigmoid=False, c_batch_stride=0, seg=None, tuned_cfg=None,
+              w_split=None, split_cfg=-1) -> None:
+    """``seg`` = (seg_rows, seg_end0, seg_end1, (s0, s1, s2), (b0, b1, b2)) or None.
+    ``w_split`` = (split weight buffer, unscale) from :func:`split_weights` selects the fp16x3 kernel."""
     hout = (hin + 2 * pad - kh) // stride + 1 if hout is None else hout
     wout = (win + 2 * pad - kw) // stride + 1 if wout is None else wout
     p = ConvGemm(a=_p(a), w=_p(w), bias=_p(bias), res=_p(res), c=_p(c), batch=batch, hin=hin, win=win, cin=cin,
@@ -128,14 +138,34 @@ def conv_gemm(a, w, bias, c, *, batch, hin, win, cin, lda, kh=1, kw=1, stride=1,
         p.seg_rows, p.seg_end0, p.seg_end1 = int(seg[0]), int(seg[1]), int(seg[2])
         p.seg_scale = (C.c_float * 3)(*[float(v) for v in seg[3]])
         p.seg_bias = (C.c_float * 3)(*[float(v) for v in seg[4]])
+    if w_split is not None:
+        check(LIB.wd_conv_gemm_split(C.byref(p), _p(w_split[0]), float(w_split[1]), int(split_cfg), stream_ptr()),
+              f"wd_conv_gemm_split[{split_cfg}]")
+        return
     if tuned_cfg is not None:
         check(LIB.wd_conv_gemm_tuned(C.byref(p), int(tuned_cfg), stream_ptr()), f"wd_conv_gemm_tuned[{tuned_cfg}]")
         return
     check(LIB.wd_conv_gemm(C.byref(p), stream_ptr()), "wd_conv_gemm")
 
 
-def gemm_config(m: int, n: int, k: int) -> str:
-    return LIB.wd_conv_gemm_config(m, n, k).decode()
+def split_weights(w: torch.Tensor):
+    """fp32 weight rows [n, k] -> (fp16 hi/lo buffer for wd_conv_gemm_split, unscale).
+
+    The weights are scaled by the power of two that brings max|w| just under 2^14 before
+    splitting (keeps the low halves out of the fp16 subnormal range); ``unscale`` undoes it in
+    the GEMM epilogue.  One device sync (max|w|): pack-time only."""
+    _f32(w, "w")
+    n, k = w.shape
+    w = w.contiguous()
+    amax = float(w.abs().max())
+    scale = 1.0 if amax == 0.0 else 2.0 ** (13 - math.floor(math.log2(amax)))
+    out = torch.empty(LIB.wd_split_weights_bytes(n, k), dtype=torch.uint8, device=w.device)
+    check(LIB.wd_split_weights(_p(w), n, k, scale, _p(out), stream_ptr()), "wd_split_weights")
+    return out, 1.0 / scale
+
+
+def gemm_config(m: int, n: int, k: int, split: bool = False) -> str:
+    return (LIB.wd_conv_gemm_split_config if split else LIB.wd_conv_gemm_config)(m, n, k).decode()
 
 
 def stem_patchify(img_u8: torch.Tensor, out: torch.Tensor) -> None:
