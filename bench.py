@@ -42,18 +42,22 @@ KERNEL_SYMBOL = {
     "64x128x16/4w/plain": "conv_gemm_kernel<2, 4, 2, 2, false, 16, 256>",
     "64x128x16/4w/conv": "conv_gemm_kernel<2, 4, 2, 2, true, 16, 256>",
     "128x80x16/8w/plain": "conv_gemm_kernel<1, 5, 8, 1, false, 16, 256>",
-    "fp16x3 128x256x16/8w/plain": "split_gemm_kernel<2, 2, 2, 4, 16, false, 258>",
-    "fp16x3 128x128x32/4w/plain": "split_gemm_kernel<2, 2, 2, 2, 32, false, 258>",
-    "fp16x3 128x128x32/4w/conv": "split_gemm_kernel<2, 2, 2, 2, 32, true, 258>",
+    "fp16x3 128x128x16/4w/plain": "split_gemm_kernel<2, 2, 2, 2, 16, false, 770>",
+    "fp16x3 128x128x16/4w/conv": "split_gemm_kernel<2, 2, 2, 2, 16, true, 770>",
+    "fp16x3 128x128x32/4w/plain": "split_gemm_kernel<2, 2, 2, 2, 32, false, 770>",
+    "fp16x3 128x128x32/4w/conv": "split_gemm_kernel<2, 2, 2, 2, 32, true, 770>",
+    "fp16x3 128x128x32/4w/pf2/plain": "split_gemm_kernel<2, 2, 2, 2, 32, false, 896>",
 }
 
 
 def measured_traffic(tag):
-    """HBM bytes per launch from the committed PMC passes (profiles/r01_traffic.json: separate
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE doubled per
-    MI355X_MICROARCH.md).  None when no PMC record matches the kernel that ran."""
+    """HBM bytes per launch from the committed PMC passes (profiles/r01_traffic.json for the fp32
+    build, profiles/r01_fp16x3_traffic.json for fp16x3: separate rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE runs of this same command, FETCH_SIZE doubled per MI355X_MICROARCH.md).  None when
+    no PMC record matches the kernel that ran."""
     try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"]
+        name = "r01_fp16x3_traffic.json" if tag.startswith("fp16x3") else "r01_traffic.json"
+        rec = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
         return round(rec[KERNEL_SYMBOL[tag]]["hbm_bytes_per_launch"])
     except Exception:
         return None
@@ -101,7 +105,7 @@ class GemmTimer:
             wout = (win + 2 * pad - kw_) // stride + 1
             m, n, k = kw["batch"] * hout * wout, kw["n"], kh * kw_ * kw["cin"]
             plain = kh == 1 and kw_ == 1 and stride == 1 and pad == 0
-            tag = lib.gemm_config(m, n, k, split=kw.get("w_split") is not None) + ("/plain" if plain else "/conv")
+            tag = lib.gemm_config(m, n, k, split=kw.get("w_split") is not None, conv=not plain) + ("/plain" if plain else "/conv")
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             orig(a, w, bias, c, **kw)

@@ -120,8 +120,9 @@ int wd_conv_gemm_tuned(const WdConvGemm* p, int32_t cfg, void* stream);
 int64_t wd_split_weights_bytes(int32_t n, int32_t k);
 int wd_split_weights(const float* w, int32_t n, int32_t k, float scale, void* out, void* stream);
 int wd_conv_gemm_split(const WdConvGemm* p, const void* w_split, float w_unscale, int32_t cfg, void* stream);
-/* Name of the tile wd_conv_gemm_split picks for (m, n, k) with cfg < 0 (diagnostic). */
-const char* wd_conv_gemm_split_config(int32_t m, int32_t n, int32_t k);
+/* Name of the tile wd_conv_gemm_split picks with cfg < 0 for an (m, n, k) problem; is_conv != 0:
+ * not a 1x1 / stride 1 / pad 0 layer (diagnostic). */
+const char* wd_conv_gemm_split_config(int32_t m, int32_t n, int32_t k, int32_t is_conv);
 
 /* sizeof(WdConvGemm) as compiled into the library, so a binding can verify its mirror. */
 int wd_sizeof_conv_gemm(void);

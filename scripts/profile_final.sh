@@ -1,11 +1,19 @@
 #!/bin/bash
-# rocprofv3 evidence for the final round-1 build (run on the GPU box from the repo root).
+# rocprofv3 evidence for the current build (run on the GPU box from the repo root):
+#   kernel trace + stats, one SQ counter pass, FETCH_SIZE and WRITE_SIZE passes (separate, as the
+#   MI355X guide prescribes), all over the same `bench.py --steps 2 --warmup 1` command.
+# usage: scripts/profile_final.sh [tag] [extra bench args]      -> gpurun_out/prof_<tag>/
 export TMPDIR=/tmp
-OUT=$PWD/gpurun_out/prof_final
+TAG=${1:-final}; shift
+OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
-CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o r01f -- $CMD > $OUT/trace_bench.json 2> $OUT/trace.err
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -d $OUT/pmc_sq -o r01f -- $CMD > /dev/null 2> $OUT/pmc_sq.err
-rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o r01f -- $CMD > /dev/null 2> $OUT/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o r01f -- $CMD > /dev/null 2> $OUT/pmc_write.err
-ls $OUT/*/
+CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline $*"
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o p -- $CMD > $OUT/trace_bench.json 2> $OUT/trace.err
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $OUT/pmc_sq -o p -- $CMD > /dev/null 2> $OUT/pmc_sq.err
+rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- $CMD > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o p -- $CMD > /dev/null 2> $OUT/pmc_write.err
+T=$(ls $OUT/trace/*.db | head -1); S=$(ls $OUT/pmc_sq/*.db | head -1); F=$(ls $OUT/pmc_fetch/*.db | head -1); W=$(ls $OUT/pmc_write/*.db | head -1)
+python scripts/rocpd_summary.py $T --pmc $S > $OUT/summary.txt 2>&1
+python scripts/traffic_json.py $F $W > $OUT/traffic.json 2> $OUT/traffic.err
+rm -f $OUT/*/*.db            # keep the merge-back small: summaries only
+head -40 $OUT/summary.txt; cat $OUT/trace_bench.json | cut -c1-400

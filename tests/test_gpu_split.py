@@ -8,7 +8,7 @@ from tests.util import assert_close, to_np
 
 pytestmark = pytest.mark.gpu
 
-ALL_CFGS = [-1] + list(range(18))
+ALL_CFGS = [-1, 41, 50, 51, 52, 53, 55]
 
 
 def _rand(shape, seed, scale=1.0):
@@ -88,7 +88,7 @@ def test_split_gemm_accuracy_is_fp32_level():
     assert rms16 <= 2.0 * rms32 + 1e-7 and e16 <= 3.0 * e32 + 1e-6
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 9])
+@pytest.mark.parametrize("cfg", [-1, 41, 50, 51, 52])
 @pytest.mark.parametrize("geom", [(3, 1, 1), (3, 2, 1), (2, 2, 0)])
 def test_split_conv_geometries(cfg, geom):
     """Implicit-GEMM conv loader (3x3 s1/s2 with padding, 2x2 s2) + SiLU vs torch conv in float64."""

@@ -98,7 +98,7 @@ template <class T, int TM, int TN, int WN, int VAR, class AL, class PreLast>
 __device__ __forceinline__ void gemm_mainloop(const AL& al, const float* __restrict__ w, int n0, int N, int K,
                                               f32x4 (&acc)[TM][TN], float* smem, PreLast&& pre_last) {
   constexpr int BK = T::BK, LD = T::LD, KCH = T::KCH;
-  constexpr int BM = T::BM, NT = T::NT, A_PT = T::A_PT, B_PT = T::B_PT, RSTEP = T::RSTEP, BN_LDS = T::BN_LDS;
+  constexpr int BM = T::BM, A_PT = T::A_PT, B_PT = T::B_PT, RSTEP = T::RSTEP, BN_LDS = T::BN_LDS;
   float* As = smem;
   float* Bs = smem + 2 * BM * LD;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;

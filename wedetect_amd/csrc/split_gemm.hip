@@ -20,6 +20,7 @@
 //   multiples of 16, so the 16 lanes of a ds_read_b128 group hit 16 distinct bank quads);
 //   weights are the MFMA "A" operand, activations "B": a lane ends with 4 consecutive output
 //   channels of a pixel per accumulator quad, and the epilogue is the one of conv_gemm.hip.
+#include <type_traits>
 #include "common.h"
 #include "gemm_loader.h"
 
@@ -34,6 +35,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SVAR_XCD = 256;      // XCD-aware tile order (as in conv_gemm.hip)
 constexpr int SVAR_PIN = 2;        // sched_barrier fences: global loads, then MFMAs, then split + LDS store
+// timing-only ablations (WRONG results by construction) for on-device diagnosis
+constexpr int SVAR_PF2 = 128;      // global loads run two K stages ahead (two register sets)
+constexpr int SVAR_LDSEPI = 512;   // epilogue through LDS: every global access of C / residual / bias is a full 128-byte row segment
+constexpr int SABL_NOLOAD = 4, SABL_NOBAR = 8, SABL_NOEPI = 16, SABL_NOLDS = 32, SABL_NOSPLIT = 64;
 
 template <int TM, int TN, int WM, int WN, int BK_>
 struct STile {
@@ -195,15 +200,73 @@ __device__ __forceinline__ void split_epilogue(const WdConvGemm& p, const EpiVec
   }
 }
 
-constexpr int split_waves_per_simd(int waves, int lds_bytes) {
-  // resident workgroups are LDS-limited (160 KB per CU); ask for the register budget that fits them
+// Same epilogue through LDS: each wave transposes its 32 x 32 accumulator tiles in a private
+// 32 x 36-float patch, so that a lane ends with 4 consecutive channels of a row and 8 lanes cover
+// a full 128-byte row segment: C stores, residual and bias loads are whole cache lines (the
+// direct epilogue writes 32-byte pieces of 32 different rows per instruction).
+constexpr int EPI_LDT = 36;
+
+template <int I, int J, int TM, int TN, int ACT, bool SPECIAL>
+__device__ __forceinline__ void epi_lds_tile(const WdConvGemm& p, const EpiVec& ev, int mw, int nw, int lane,
+                                             const f32x16 (&acc)[TM][TN], float* patch) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    *reinterpret_cast<f32x4*>(patch + (lane & 31) * EPI_LDT + 8 * g + 4 * (lane >> 5)) =
+        f32x4{acc[I][J][4 * g], acc[I][J][4 * g + 1], acc[I][J][4 * g + 2], acc[I][J][4 * g + 3]};
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    const int row = ps * 8 + (lane >> 3);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(patch + row * EPI_LDT + 4 * (lane & 7));
+    const int m = mw + I * 32 + row;
+    const int n = nw + J * 32 + 4 * (lane & 7);
+    if (m < p.m) {
+      const EpiRow er = epi_row<SPECIAL>(p, m);
+      epi_quad<ACT, SPECIAL>(p, er, ev, m, n, v);
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// compile-time walk over the TM x TN accumulator tiles (a #pragma unroll loop around the fences is
+// not always honoured, and a rolled loop would index the accumulators through scratch)
+template <int IJ, int TM, int TN, int ACT, bool SPECIAL>
+struct EpiLdsWalk {
+  static __device__ __forceinline__ void run(const WdConvGemm& p, const EpiVec& ev, int mw, int nw, int lane,
+                                             const f32x16 (&acc)[TM][TN], float* patch) {
+    epi_lds_tile<IJ / TN, IJ % TN, TM, TN, ACT, SPECIAL>(p, ev, mw, nw, lane, acc, patch);
+    EpiLdsWalk<IJ + 1, TM, TN, ACT, SPECIAL>::run(p, ev, mw, nw, lane, acc, patch);
+  }
+};
+template <int TM, int TN, int ACT, bool SPECIAL>
+struct EpiLdsWalk<TM * TN, TM, TN, ACT, SPECIAL> {
+  static __device__ __forceinline__ void run(const WdConvGemm&, const EpiVec&, int, int, int,
+                                             const f32x16 (&)[TM][TN], float*) {}
+};
+
+template <int TM, int TN, int ACT, bool SPECIAL>
+__device__ __forceinline__ void split_epilogue_lds(const WdConvGemm& p, const EpiVec& ev, int mw, int nw, int lane,
+                                                   const f32x16 (&acc)[TM][TN], float* patch) {
+  EpiLdsWalk<0, TM, TN, ACT, SPECIAL>::run(p, ev, mw, nw, lane, acc, patch);
+}
+
+constexpr int split_waves_per_simd(int waves, int lds_bytes, int acc_tiles, bool two_sets) {
+  // resident workgroups are LDS-limited (160 KB per CU); ask for the register budget that fits
+  // them, but never squeeze a 128-register accumulator set (64 x 128 wave tiles) below 256 registers
   const int wgs = (160 * 1024) / lds_bytes;
   const int w = (wgs * waves) / 4;
-  return w > 4 ? 4 : (w < 1 ? 1 : w);
+  // a second staging register set (prefetch distance 2) does not fit 128 registers: trade one
+  // resident wave per SIMD for it
+  const int cap = acc_tiles > 4 ? 2 : (two_sets ? 3 : 4);
+  return w > cap ? cap : (w < 1 ? 1 : w);
 }
 
 template <int TM, int TN, int WM, int WN, int BKT, bool CONV, int VAR>
-__global__ void __launch_bounds__(64 * WM * WN, split_waves_per_simd(WM * WN, STile<TM, TN, WM, WN, BKT>::LDS_BYTES))
+__global__ void __launch_bounds__(64 * WM * WN, split_waves_per_simd(WM * WN, STile<TM, TN, WM, WN, BKT>::LDS_BYTES, TM * TN, (VAR & SVAR_PF2) != 0))
 split_gemm_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, const float* __restrict__ zero,
                   int k16, float unscale, int nbn, int vec_c, int vec_res, int vec_bias) {
   using T = STile<TM, TN, WM, WN, BKT>;
@@ -242,28 +305,40 @@ split_gemm_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, con
   const int a_off = (kc >> 2) * 64 + (kc & 3) * 8;                              // hi; lo at +32
   const int b_off = (kc >> 2) * 64 + (kc & 1) * 32 + ((kc >> 1) & 1) * 16;
 
-  f32x4 areg[A_PT];
-  u32x4 breg[B_PT];
-  auto load_b = [&](int kbase) {
+  constexpr int NSET = (VAR & SVAR_PF2) ? 2 : 1;
+  f32x4 areg[NSET][A_PT];
+  u32x4 breg[NSET][B_PT];
+  // stage at kbase -> register set S (k beyond K reads the zero block: over-running loads are harmless)
+  auto load = [&](int kbase, auto set) {
+    constexpr int S = decltype(set)::value;
+    al.template load<BK>(kbase, kc * 4, areg[S]);
     const bool kok = kbase + (kc >> 1) * 8 < k16;
 #pragma unroll
     for (int j = 0; j < B_PT; ++j)
-      breg[j] = *reinterpret_cast<const u32x4*>((wok[j] && kok) ? wrow[j] + (size_t)kbase * 4
-                                                                : reinterpret_cast<const unsigned char*>(zero));
+      breg[S][j] = *reinterpret_cast<const u32x4*>((wok[j] && kok) ? wrow[j] + (size_t)kbase * 4
+                                                                   : reinterpret_cast<const unsigned char*>(zero));
   };
-  auto store = [&](int buf) {
+  auto store = [&](int buf, auto set) {
+    constexpr int S = decltype(set)::value;
     unsigned char* ad = As + (buf * BM + r0) * ROWB + a_off;
 #pragma unroll
     for (int i = 0; i < A_PT; ++i) {
       u32x2 hi, lo;
-      split4(areg[i], hi, lo);
+      if (VAR & SABL_NOSPLIT) {
+        hi = u32x2{__builtin_bit_cast(unsigned, areg[S][i][0]), __builtin_bit_cast(unsigned, areg[S][i][1])};
+        lo = u32x2{__builtin_bit_cast(unsigned, areg[S][i][2]), __builtin_bit_cast(unsigned, areg[S][i][3])};
+      } else {
+        split4(areg[S][i], hi, lo);
+      }
       *reinterpret_cast<u32x2*>(ad + i * RSTEP * ROWB) = hi;
       *reinterpret_cast<u32x2*>(ad + i * RSTEP * ROWB + 32) = lo;
     }
     unsigned char* bd = Bs + (buf * BN + r0) * ROWB + b_off;
 #pragma unroll
-    for (int j = 0; j < B_PT; ++j) *reinterpret_cast<u32x4*>(bd + j * RSTEP * ROWB) = breg[j];
+    for (int j = 0; j < B_PT; ++j) *reinterpret_cast<u32x4*>(bd + j * RSTEP * ROWB) = breg[S][j];
   };
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, NSET - 1>;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -308,27 +383,80 @@ split_gemm_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, con
     }
   };
 
-  al.template load<BK>(0, kc * 4, areg);
-  load_b(0);
-  store(0);
+  load(0, Set0{});
+  store(0, Set0{});
   __syncthreads();
-  int cur = 0;
-  for (int kt = 1; kt < nk; ++kt) {
-    al.template load<BK>(kt * BK, kc * 4, areg);
-    load_b(kt * BK);
-    if (VAR & SVAR_PIN) __builtin_amdgcn_sched_barrier(0);
+  if (VAR & SVAR_PF2) {
+    // stage s is computed from LDS buffer s & 1 while stage s+1 waits in registers and the loads
+    // of stage s+2 are issued: a global load has a whole K stage of MFMAs to land
+    load(BK, Set1{});
+    for (int s = 0; s < nk; s += 2) {
+      load((s + 2) * BK, Set0{});
+      if (VAR & SVAR_PIN) __builtin_amdgcn_sched_barrier(0);
+      compute(0);
+      if (VAR & SVAR_PIN) __builtin_amdgcn_sched_barrier(0);
+      store(1, Set1{});
+      __syncthreads();
+      if (s + 1 >= nk) break;
+      load((s + 3) * BK, Set1{});
+      if (VAR & SVAR_PIN) __builtin_amdgcn_sched_barrier(0);
+      compute(1);
+      if (VAR & SVAR_PIN) __builtin_amdgcn_sched_barrier(0);
+      store(0, Set0{});
+      __syncthreads();
+    }
+  } else {
+    int cur = 0;
+    for (int kt = 1; kt < nk; ++kt) {
+      if (!(VAR & SABL_NOLOAD)) load(kt * BK, Set0{});
+      if (VAR & SVAR_PIN) __builtin_amdgcn_sched_barrier(0);
+      compute(cur);
+      if (VAR & SVAR_PIN) __builtin_amdgcn_sched_barrier(0);
+      if (!(VAR & SABL_NOLDS)) store(cur ^ 1, Set0{});
+      if (!(VAR & SABL_NOBAR)) __syncthreads();
+      cur ^= 1;
+    }
     compute(cur);
-    if (VAR & SVAR_PIN) __builtin_amdgcn_sched_barrier(0);
-    store(cur ^ 1);
-    __syncthreads();
-    cur ^= 1;
   }
-  compute(cur);
 
+  if (VAR & SABL_NOEPI) {            // keep the accumulators live, store one value per lane
+    float sacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+    if (m0 + (int)(t % BM) < p.m) p.c[(size_t)(m0 + t % BM) * p.ldc + n0] = sacc;
+    return;
+  }
   const bool special = p.out_mode != WD_OUT_ROWS || p.c_batch_stride > 0 || p.seg_rows > 0 || p.sigmoid ||
                        p.out_scale != 1.0f || p.out_bias != 0.0f;
   const EpiVec ev{vec_c, vec_res, vec_bias, unscale};
   const int mw = m0 + wm * TM * 32, nw = n0 + wn * TN * 32;
+  if (VAR & SVAR_LDSEPI) {
+    static_assert(T::LDS_BYTES >= WM * WN * 32 * EPI_LDT * 4, "operand LDS must hold one patch per wave");
+    __syncthreads();                                   // every wave is done reading the last operand stage
+    float* patch = reinterpret_cast<float*>(smem_raw) + wave * 32 * EPI_LDT;
+#define WD_SPLIT_EPI(A, S) split_epilogue_lds<TM, TN, A, S>(p, ev, mw, nw, lane, acc, patch)
+    if (special) {
+      switch (p.act) {
+        case WD_ACT_RELU: WD_SPLIT_EPI(WD_ACT_RELU, true); break;
+        case WD_ACT_SILU: WD_SPLIT_EPI(WD_ACT_SILU, true); break;
+        case WD_ACT_GELU: WD_SPLIT_EPI(WD_ACT_GELU, true); break;
+        default: WD_SPLIT_EPI(WD_ACT_NONE, true); break;
+      }
+    } else {
+      switch (p.act) {
+        case WD_ACT_RELU: WD_SPLIT_EPI(WD_ACT_RELU, false); break;
+        case WD_ACT_SILU: WD_SPLIT_EPI(WD_ACT_SILU, false); break;
+        case WD_ACT_GELU: WD_SPLIT_EPI(WD_ACT_GELU, false); break;
+        default: WD_SPLIT_EPI(WD_ACT_NONE, false); break;
+      }
+    }
+#undef WD_SPLIT_EPI
+    return;
+  }
   if (special) {
     switch (p.act) {
       case WD_ACT_RELU: split_epilogue<TM, TN, WD_ACT_RELU, true>(p, ev, mw, nw, lane, acc); break;
@@ -429,28 +557,27 @@ extern "C" int wd_split_weights(const float* w, int32_t n, int32_t k, float scal
   return wd_launch_status();
 }
 
-// Production tile choice (profiles/r01_split_gemm_ab.txt): 128 x 256 x 16 (8 waves) for wide n,
-// 128 x 128 x 32 (4 waves) for n <= 256 or few tiles, 64-wide tiles for narrow n.
-static int pick_split_cfg(int m, int n, int k) {
-  int bn = 256;
-  long long best = -1;
-  const int widths[3] = {256, 128, 64};
-  for (int i = 0; i < 3; ++i) {
-    const long long padded = (long long)((n + widths[i] - 1) / widths[i]) * widths[i];
-    if (best < 0 || padded < best) { best = padded; bn = widths[i]; }
-  }
-  if (bn == 256 && (n < 512 || (long long)((m + 127) / 128) * ((n + 255) / 256) < 256)) bn = 128;
-  if (bn == 256) return 12;
-  if (bn == 128) return k >= 256 ? 10 : 9;
-  return m >= 65536 ? 15 : 14;
+// Production tile choice (profiles/r01_split_gemm_ab.txt): 128 x 128 x 16 (4 waves, four
+// workgroups per CU), 128 x 128 x 32 when there are few tiles, 64-wide tiles for narrow n.
+static int pick_split_cfg(const WdConvGemm& p) {
+  const int m = p.m, n = p.n;
+  const long long pad128 = (long long)((n + 127) / 128) * 128, pad64 = (long long)((n + 63) / 64) * 64;
+  if (pad64 < pad128) return m >= 65536 ? 52 : 53;                 // narrow n: 64-wide tiles
+  const bool plain = p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0;
+  if (plain && p.k >= 1024) return 55;                             // long K: loads two stages ahead
+  const long long tiles = (long long)((m + 127) / 128) * ((n + 127) / 128);
+  return tiles < 1024 ? 50 : 51;                                    // few tiles: deeper K stage
 }
 
-extern "C" const char* wd_conv_gemm_split_config(int32_t m, int32_t n, int32_t k) {
-  switch (pick_split_cfg(m, n, k)) {
-    case 12: return "fp16x3 128x256x16/8w";
-    case 10: return "fp16x3 128x128x32/4w";
-    case 9: return "fp16x3 128x128x16/4w";
-    case 15: return "fp16x3 256x64x16/4w";
+extern "C" const char* wd_conv_gemm_split_config(int32_t m, int32_t n, int32_t k, int32_t is_conv) {
+  WdConvGemm q{};
+  q.m = m; q.n = n; q.k = k; q.kh = q.kw = q.stride = 1;
+  if (is_conv) q.kh = q.kw = 3;                                      // any non-1x1 geometry selects the conv loader
+  switch (pick_split_cfg(q)) {
+    case 50: return "fp16x3 128x128x32/4w";
+    case 51: return "fp16x3 128x128x16/4w";
+    case 52: return "fp16x3 256x64x16/4w";
+    case 55: return "fp16x3 128x128x32/4w/pf2";
     default: return "fp16x3 128x64x16/2w";
   }
 }
@@ -463,26 +590,15 @@ extern "C" int wd_conv_gemm_split(const WdConvGemm* pp, const void* w_split, flo
   const int rc = check_split_args(p, w_split, w_unscale);
   if (rc != WD_OK) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (cfg < 0) cfg = pick_split_cfg(p.m, p.n, p.k);
+  if (cfg < 0) cfg = pick_split_cfg(p);
   switch (cfg) {
-    case 0: return launch_split<2, 2, 4, 2, 16, SVAR_XCD>(p, w_split, w_unscale, st);   // 256 x 128 x 16, 8 waves
-    case 1: return launch_split<2, 2, 2, 2, 16, SVAR_XCD>(p, w_split, w_unscale, st);   // 128 x 128 x 16, 4 waves
-    case 2: return launch_split<2, 2, 2, 2, 32, SVAR_XCD>(p, w_split, w_unscale, st);   // 128 x 128 x 32, 4 waves
-    case 3: return launch_split<2, 2, 4, 2, 32, SVAR_XCD>(p, w_split, w_unscale, st);   // 256 x 128 x 32, 8 waves
-    case 4: return launch_split<2, 2, 2, 4, 16, SVAR_XCD>(p, w_split, w_unscale, st);   // 128 x 256 x 16, 8 waves
-    case 5: return launch_split<2, 2, 4, 4, 16, SVAR_XCD>(p, w_split, w_unscale, st);   // 256 x 256 x 16, 16 waves
-    case 6: return launch_split<2, 2, 2, 1, 16, SVAR_XCD>(p, w_split, w_unscale, st);   // 128 x 64 x 16, 2 waves
-    case 7: return launch_split<2, 2, 4, 1, 16, SVAR_XCD>(p, w_split, w_unscale, st);   // 256 x 64 x 16, 4 waves
-    case 8: return launch_split<2, 2, 4, 2, 16, SVAR_XCD | SVAR_PIN>(p, w_split, w_unscale, st);
-    case 9: return launch_split<2, 2, 2, 2, 16, SVAR_XCD | SVAR_PIN>(p, w_split, w_unscale, st);
-    case 10: return launch_split<2, 2, 2, 2, 32, SVAR_XCD | SVAR_PIN>(p, w_split, w_unscale, st);
-    case 11: return launch_split<2, 2, 4, 2, 32, SVAR_XCD | SVAR_PIN>(p, w_split, w_unscale, st);
-    case 12: return launch_split<2, 2, 2, 4, 16, SVAR_XCD | SVAR_PIN>(p, w_split, w_unscale, st);
-    case 13: return launch_split<2, 2, 4, 4, 16, SVAR_XCD | SVAR_PIN>(p, w_split, w_unscale, st);
-    case 14: return launch_split<2, 2, 2, 1, 16, SVAR_XCD | SVAR_PIN>(p, w_split, w_unscale, st);
-    case 15: return launch_split<2, 2, 4, 1, 16, SVAR_XCD | SVAR_PIN>(p, w_split, w_unscale, st);
-    case 16: return launch_split<2, 2, 2, 1, 32, SVAR_XCD | SVAR_PIN>(p, w_split, w_unscale, st);  // 128 x 64 x 32, 2 waves
-    case 17: return launch_split<2, 2, 4, 1, 32, SVAR_XCD | SVAR_PIN>(p, w_split, w_unscale, st);  // 256 x 64 x 32, 4 waves
+    case 41: return launch_split<2, 2, 2, 4, 16, SVAR_XCD | SVAR_PIN | SVAR_LDSEPI>(p, w_split, w_unscale, st);  // 128 x 256 x 16, 8 waves
+    case 50: return launch_split<2, 2, 2, 2, 32, SVAR_XCD | SVAR_PIN | SVAR_LDSEPI>(p, w_split, w_unscale, st);  // 128 x 128 x 32, 4 waves
+    case 51: return launch_split<2, 2, 2, 2, 16, SVAR_XCD | SVAR_PIN | SVAR_LDSEPI>(p, w_split, w_unscale, st);  // 128 x 128 x 16, 4 waves
+    case 52: return launch_split<2, 2, 4, 1, 16, SVAR_XCD | SVAR_PIN | SVAR_LDSEPI>(p, w_split, w_unscale, st);  // 256 x 64 x 16, 4 waves
+    case 53: return launch_split<2, 2, 2, 1, 16, SVAR_XCD | SVAR_PIN | SVAR_LDSEPI>(p, w_split, w_unscale, st);  // 128 x 64 x 16, 2 waves
+    // prefetch distance 2 (two staging register sets; only the BK = 32 plain kernel holds them without spilling)
+    case 55: return launch_split<2, 2, 2, 2, 32, SVAR_XCD | SVAR_PF2 | SVAR_LDSEPI>(p, w_split, w_unscale, st);
     default: return WD_ERR_UNSUPPORTED;
   }
 }

@@ -88,7 +88,7 @@ def _load():
     lib.wd_split_weights.argtypes = [vp, i32, i32, f32, vp, vp]
     lib.wd_conv_gemm_split.argtypes = [C.POINTER(ConvGemm), vp, f32, i32, vp]
     lib.wd_conv_gemm_split_config.restype = C.c_char_p
-    lib.wd_conv_gemm_split_config.argtypes = [i32, i32, i32]
+    lib.wd_conv_gemm_split_config.argtypes = [i32, i32, i32, i32]
     if lib.wd_sizeof_conv_gemm() != C.sizeof(ConvGemm):
         raise WedetectHipMissing("struct WdConvGemm layout differs between the library and lib.ConvGemm; rebuild")
     if lib.wd_abi_version() != ABI_VERSION:
@@ -164,8 +164,10 @@ def split_weights(w: torch.Tensor):
     return out, 1.0 / scale
 
 
-def gemm_config(m: int, n: int, k: int, split: bool = False) -> str:
-    return (LIB.wd_conv_gemm_split_config if split else LIB.wd_conv_gemm_config)(m, n, k).decode()
+def gemm_config(m: int, n: int, k: int, split: bool = False, conv: bool = False) -> str:
+    if split:
+        return LIB.wd_conv_gemm_split_config(m, n, k, int(conv)).decode()
+    return LIB.wd_conv_gemm_config(m, n, k).decode()
 
 
 def stem_patchify(img_u8: torch.Tensor, out: torch.Tensor) -> None:
