@@ -47,6 +47,7 @@ KERNEL_SYMBOL = {
     "fp16x3 128x128x32/4w/plain": "split_gemm_kernel<2, 2, 2, 2, 32, false, 770>",
     "fp16x3 128x128x32/4w/conv": "split_gemm_kernel<2, 2, 2, 2, 32, true, 770>",
     "fp16x3 128x128x32/4w/pf2/plain": "split_gemm_kernel<2, 2, 2, 2, 32, false, 896>",
+    "fp16x3 128x128x16/4w/glds/plain": "split_gemm_glds_kernel<16, 0>",
 }
 
 
@@ -105,7 +106,8 @@ class GemmTimer:
             wout = (win + 2 * pad - kw_) // stride + 1
             m, n, k = kw["batch"] * hout * wout, kw["n"], kh * kw_ * kw["cin"]
             plain = kh == 1 and kw_ == 1 and stride == 1 and pad == 0
-            tag = lib.gemm_config(m, n, k, split=kw.get("w_split") is not None, conv=not plain) + ("/plain" if plain else "/conv")
+            tag = lib.gemm_config(m, n, k, split=kw.get("w_split") is not None, conv=not plain,
+                                  presplit=bool(kw.get("split_flags", 0))) + ("/plain" if plain else "/conv")
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             orig(a, w, bias, c, **kw)

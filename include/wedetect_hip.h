@@ -119,10 +119,24 @@ int wd_conv_gemm_tuned(const WdConvGemm* p, int32_t cfg, void* stream);
  * cfg < 0 picks the production tile; cfg >= 0 selects a tile for A/B runs (split_gemm.hip). */
 int64_t wd_split_weights_bytes(int32_t n, int32_t k);
 int wd_split_weights(const float* w, int32_t n, int32_t k, float scale, void* out, void* stream);
-int wd_conv_gemm_split(const WdConvGemm* p, const void* w_split, float w_unscale, int32_t cfg, void* stream);
+int wd_conv_gemm_split(const WdConvGemm* p, const void* w_split, float w_unscale, int32_t flags, int32_t cfg,
+                       void* stream);
+/* flags: operands that are stored as fp16 (hi, lo) groups instead of fp32 — per row, per 8
+ * consecutive elements: [8 x fp16 hi | 8 x fp16 lo] in the 32 bytes the 8 floats would occupy
+ * (so buffers, row strides and lda / ldc keep their fp32 meaning).
+ *   WD_SPLIT_A: p->a was written by wd_layernorm_rows_split or by a WD_SPLIT_C layer (k % 8 == 0)
+ *   WD_SPLIT_C: write p->c in that format for a following WD_SPLIT_A layer (plain rows, no
+ *               residual, n % 8 == 0; needs WD_SPLIT_A)
+ * Results are bit-identical to the flags = 0 path (the same halves, produced earlier). */
+#define WD_SPLIT_A 1
+#define WD_SPLIT_C 2
 /* Name of the tile wd_conv_gemm_split picks with cfg < 0 for an (m, n, k) problem; is_conv != 0:
  * not a 1x1 / stride 1 / pad 0 layer (diagnostic). */
 const char* wd_conv_gemm_split_config(int32_t m, int32_t n, int32_t k, int32_t is_conv);
+
+/* wd_layernorm_rows with the output written as fp16 (hi, lo) groups (see WD_SPLIT_A); c % 8 == 0. */
+int wd_layernorm_rows_split(const float* x, void* y, const float* gamma, const float* beta, int64_t rows, int32_t c,
+                            int32_t ldx, int32_t ldy, float eps, void* stream);
 
 /* sizeof(WdConvGemm) as compiled into the library, so a binding can verify its mirror. */
 int wd_sizeof_conv_gemm(void);

@@ -156,3 +156,82 @@ def test_split_gemm_rejects_bad_arguments():
         L.conv_gemm(a, None, None, c, batch=1, hin=1, win=64, cin=32, lda=32, n=32, ldc=32, w_split=ws, split_cfg=99)
     with pytest.raises(L.WedetectHipError):
         L.conv_gemm(a, None, None, c, batch=1, hin=1, win=64, cin=32, lda=32, n=32, ldc=16, w_split=ws)
+
+
+def _decode_split(buf_f32_view, rows, c):
+    """fp16 hi/lo groups ([8 x hi | 8 x lo] per 8 elements, stored in a float32-typed buffer) -> (hi, lo) float64."""
+    raw = to_np(buf_f32_view).reshape(rows, c).view(np.float16).reshape(rows, c // 8, 2, 8)
+    return raw[:, :, 0, :].reshape(rows, c).astype(np.float64), raw[:, :, 1, :].reshape(rows, c).astype(np.float64)
+
+
+def _expect_halves(y32):
+    hi = y32.astype(np.float16)
+    lo = (y32 - hi.astype(np.float32)).astype(np.float16)
+    return hi.astype(np.float64), lo.astype(np.float64)
+
+
+@pytest.mark.parametrize("rows,c", [(1000, 128), (77, 512), (33, 1024), (5, 96)])
+def test_layernorm_split_output_is_the_split_of_the_fp32_output(rows, c):
+    from wedetect_amd import lib as L
+    x, g, b = _rand((rows, c), 51, 3.0), _rand((c,), 52), _rand((c,), 53)
+    y32 = torch.empty(rows, c, device="cuda")
+    ys = torch.empty(rows, c, device="cuda")
+    L.layernorm_rows(x, y32, g, b, rows, c)
+    L.layernorm_rows(x, ys, g, b, rows, c, split=True)
+    hi, lo = _decode_split(ys, rows, c)
+    ehi, elo = _expect_halves(to_np(y32))
+    assert np.array_equal(hi, ehi) and np.array_equal(lo, elo)
+    # in place, as the engine uses it
+    xi = x.clone()
+    L.layernorm_rows(xi, xi, g, b, rows, c, split=True)
+    assert torch.equal(xi.view(torch.int32), ys.view(torch.int32))
+
+
+@pytest.mark.parametrize("cfg", [-1, 50, 51, 55, 60, 61])
+def test_presplit_operands_give_bit_identical_results(cfg):
+    """LN(split) -> GEMM(A split, C split, GELU) -> GEMM(A split, residual) == the same chain with
+    fp32 buffers and the loader-side split, bit for bit; the split C is the split of the fp32 C."""
+    from wedetect_amd import lib as L
+    m, c = 1000, 128
+    x, g, b = _rand((m, c), 61, 2.0), _rand((c,), 62), _rand((c,), 63, 0.1)
+    w1, b1 = _rand((4 * c, c), 64, c ** -0.5), _rand((4 * c,), 65, 0.1)
+    w2, b2 = _rand((c, 4 * c), 66, (4 * c) ** -0.5), _rand((c,), 67, 0.1)
+    ws1, ws2 = L.split_weights(w1), L.split_weights(w2)
+    res = _rand((m, c), 68)
+    # reference chain: fp32 intermediates
+    t32, h32, o32 = torch.empty(m, c, device="cuda"), torch.empty(m, 4 * c, device="cuda"), torch.empty(m, c, device="cuda")
+    L.layernorm_rows(x, t32, g, b, m, c)
+    kw1 = dict(batch=1, hin=1, win=m, cin=c, lda=c, n=4 * c, ldc=4 * c, act=L.ACT_GELU)
+    kw2 = dict(batch=1, hin=1, win=m, cin=4 * c, lda=4 * c, n=c, ldc=c, res=res, ldres=c)
+    c1 = cfg if cfg != 55 else 50
+    ref1 = {60: 51, 61: 50}.get(c1, c1)          # the direct-to-LDS kernels sum k in the order of the BK 16 / 32 tiles
+    ref2 = {60: 51, 61: 50}.get(cfg, cfg)
+    L.conv_gemm(t32, None, b1, h32, w_split=ws1, split_cfg=ref1, **kw1)
+    L.conv_gemm(h32, None, b2, o32, w_split=ws2, split_cfg=ref2, **kw2)
+    # pre-split chain
+    ts, hs, os_ = torch.empty(m, c, device="cuda"), torch.empty(m, 4 * c, device="cuda"), torch.empty(m, c, device="cuda")
+    L.layernorm_rows(x, ts, g, b, m, c, split=True)
+    L.conv_gemm(ts, None, b1, hs, w_split=ws1, split_cfg=c1, split_flags=L.SPLIT_A | L.SPLIT_C, **kw1)
+    L.conv_gemm(hs, None, b2, os_, w_split=ws2, split_cfg=cfg, split_flags=L.SPLIT_A, **kw2)
+    hi, lo = _decode_split(hs, m, 4 * c)
+    ehi, elo = _expect_halves(to_np(h32))
+    assert np.array_equal(hi, ehi) and np.array_equal(lo, elo), "split C must be the split of the fp32 C"
+    assert torch.equal(os_, o32), "pre-split operands must not change a single bit of the result"
+
+
+def test_presplit_downsample_conv_bit_identical():
+    """LN(split) -> 2x2 stride-2 conv with the implicit-im2col loader reading fp16 hi/lo groups."""
+    from wedetect_amd import lib as L
+    b_, h, w_, ci, co = 2, 12, 10, 64, 128
+    x, g, b = _rand((b_ * h * w_, ci), 71, 2.0), _rand((ci,), 72), _rand((ci,), 73, 0.1)
+    wt, bias = _rand((co, 4 * ci), 74, (4 * ci) ** -0.5), _rand((co,), 75, 0.1)
+    ws = L.split_weights(wt)
+    t32, ts = torch.empty_like(x), torch.empty_like(x)
+    L.layernorm_rows(x, t32, g, b, x.shape[0], ci)
+    L.layernorm_rows(x, ts, g, b, x.shape[0], ci, split=True)
+    kw = dict(batch=b_, hin=h, win=w_, cin=ci, lda=ci, kh=2, kw=2, stride=2, pad=0, n=co, ldc=co)
+    o32 = torch.empty(b_ * (h // 2) * (w_ // 2), co, device="cuda")
+    os_ = torch.empty_like(o32)
+    L.conv_gemm(t32, None, bias, o32, w_split=ws, **kw)
+    L.conv_gemm(ts, None, bias, os_, w_split=ws, split_flags=L.SPLIT_A, **kw)
+    assert torch.equal(os_, o32)

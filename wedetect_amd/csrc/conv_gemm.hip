@@ -522,7 +522,7 @@ extern "C" int wd_conv_gemm(const WdConvGemm* pp, void* stream) {
       return use_small_tile(p.m, p.n) ? launch_cfg<2, 4, 2, 2, 16, VAR_XCD>(p, st)
                                       : launch_cfg<2, 4, 4, 2, 16, VAR_XCD>(p, st);
     case 96: return launch_cfg<1, 6, 8, 1, 16, VAR_XCD>(p, st);
-    case 80: return launch_cfg<1, 5, 8, 1, 16, VAR_XCD>(p, st);
+    case 80: return launch_cfg<1, 5, 8, 1, 16, VAR_XCD | VAR_PIN>(p, st);   // the similarity GEMM: pinned order +2..5 % (profiles/r01_gemm_ab.txt)
     case 64: return launch_cfg<1, 4, 8, 1, 16, VAR_XCD>(p, st);
     default: return launch_cfg<1, 3, 8, 1, 16, VAR_XCD>(p, st);
   }

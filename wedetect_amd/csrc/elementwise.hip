@@ -188,7 +188,9 @@ __global__ void __launch_bounds__(256) dwconv7_tiled_kernel(const float* __restr
 // LayerNorm over the channel axis of each row.  A group of G lanes (power of two, 8..64)
 // owns one row; each lane holds NV float4.  Two-pass (mean, then centred variance), fp32.
 // ---------------------------------------------------------------------------------------
-template <int NV>
+// SPLIT: the output row is written as fp16 (hi, lo) groups — per 8 channels [8 x hi | 8 x lo] in
+// the 32 bytes the 8 floats would occupy — for a wd_conv_gemm_split(WD_SPLIT_A) consumer.
+template <int NV, bool SPLIT>
 __global__ void __launch_bounds__(256) layernorm_rows_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, long long rows, int c,
@@ -227,7 +229,22 @@ __global__ void __launch_bounds__(256) layernorm_rows_kernel(const float* __rest
     if (q < nq) {
       const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + q * 4);
       const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + q * 4);
-      *reinterpret_cast<f32x4*>(y + row * ldy + q * 4) = (v[i] - mean) * rstd * gm + bt;
+      const f32x4 o = (v[i] - mean) * rstd * gm + bt;
+      if (SPLIT) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 a = {o[0], o[1]}, b = {o[2], o[3]};
+        const h2 ha = __builtin_convertvector(a, h2), hb = __builtin_convertvector(b, h2);
+        const h2 la = __builtin_convertvector(a - __builtin_convertvector(ha, f32x2), h2);
+        const h2 lb = __builtin_convertvector(b - __builtin_convertvector(hb, f32x2), h2);
+        // chunk q = channels 4q..4q+3: half (q & 1) of group q >> 1; hi at +0, lo at +16 bytes
+        unsigned char* gp = reinterpret_cast<unsigned char*>(y + row * ldy) + (size_t)(q >> 1) * 32 + (q & 1) * 8;
+        *reinterpret_cast<u32x2*>(gp) = u32x2{__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)};
+        *reinterpret_cast<u32x2*>(gp + 16) = u32x2{__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)};
+      } else {
+        *reinterpret_cast<f32x4*>(y + row * ldy + q * 4) = o;
+      }
     }
   }
 }
@@ -324,10 +341,12 @@ extern "C" int wd_dwconv7(const float* x, const float* w7, const float* bias, fl
   return wd_launch_status();
 }
 
-extern "C" int wd_layernorm_rows(const float* x, float* y, const float* gamma, const float* beta, int64_t rows,
-                                 int32_t c, int32_t ldx, int32_t ldy, float eps, void* stream) {
+template <bool SPLIT>
+static int launch_layernorm(const float* x, float* y, const float* gamma, const float* beta, int64_t rows, int32_t c,
+                            int32_t ldx, int32_t ldy, float eps, void* stream) {
   if (!x || !y || !gamma || !beta || rows <= 0 || c <= 0 || (c & 3) || c > 2048) return WD_ERR_BAD_ARG;
   if (ldx < c || ldy < c || (ldx & 3) || (ldy & 3)) return WD_ERR_BAD_ARG;
+  if (SPLIT && ((c & 7) || (ldy & 7))) return WD_ERR_BAD_ARG;
   if (!wd_aligned16(x) || !wd_aligned16(y) || !wd_aligned16(gamma) || !wd_aligned16(beta)) return WD_ERR_BAD_ARG;
   const int nq = c / 4;
   int g = 8;
@@ -339,8 +358,8 @@ extern "C" int wd_layernorm_rows(const float* x, float* y, const float* gamma, c
   hipStream_t st = static_cast<hipStream_t>(stream);
 #define WD_LN_CASE(NV)                                                                                              \
   case NV:                                                                                                          \
-    hipLaunchKernelGGL(layernorm_rows_kernel<NV>, dim3((unsigned)grid), dim3(256), 0, st, x, y, gamma, beta,        \
-                       (long long)rows, c, ldx, ldy, eps, g);                                                       \
+    hipLaunchKernelGGL((layernorm_rows_kernel<NV, SPLIT>), dim3((unsigned)grid), dim3(256), 0, st, x, y, gamma,     \
+                       beta, (long long)rows, c, ldx, ldy, eps, g);                                                 \
     break;
   switch (nv) {
     WD_LN_CASE(1) WD_LN_CASE(2) WD_LN_CASE(3) WD_LN_CASE(4) WD_LN_CASE(5) WD_LN_CASE(6) WD_LN_CASE(7) WD_LN_CASE(8)
@@ -348,6 +367,16 @@ extern "C" int wd_layernorm_rows(const float* x, float* y, const float* gamma, c
   }
 #undef WD_LN_CASE
   return wd_launch_status();
+}
+
+extern "C" int wd_layernorm_rows(const float* x, float* y, const float* gamma, const float* beta, int64_t rows,
+                                 int32_t c, int32_t ldx, int32_t ldy, float eps, void* stream) {
+  return launch_layernorm<false>(x, y, gamma, beta, rows, c, ldx, ldy, eps, stream);
+}
+
+extern "C" int wd_layernorm_rows_split(const float* x, void* y, const float* gamma, const float* beta, int64_t rows,
+                                       int32_t c, int32_t ldx, int32_t ldy, float eps, void* stream) {
+  return launch_layernorm<true>(x, static_cast<float*>(y), gamma, beta, rows, c, ldx, ldy, eps, stream);
 }
 
 extern "C" int wd_l2norm_rows(const float* x, float* y, int64_t rows, int32_t c, void* stream) {

@@ -1,0 +1,230 @@
+// split_gemm_pre.hip — fp16x3 GEMM instantiations whose activation operand is already stored as
+// fp16 hi/lo groups by its producer (wd_layernorm_rows_split, or a preceding wd_conv_gemm_split
+// with WD_SPLIT_C): the K loop then moves both operands as plain 16-byte copies — no conversion
+// work is repeated by every column tile that re-reads the same activation rows.
+// Layers on this path in the ConvNeXt tower (mm_backbone.py:112-125, 185-198):
+//   LayerNorm -> pwconv1 (+GELU, output written split) -> pwconv2 (+residual, fp32 output),
+//   LayerNorm -> 2x2 stride-2 downsample conv.
+#include "split_gemm_impl.h"
+
+namespace {
+constexpr int VA = SVAR_XCD | SVAR_PIN | SVAR_LDSEPI | SVAR_ASPLIT;
+constexpr int VAC = VA | SVAR_CSPLIT;
+constexpr int VA_PF2 = SVAR_XCD | SVAR_PF2 | SVAR_LDSEPI | SVAR_ASPLIT;
+
+// ---------------------------------------------------------------------------------------
+// Direct-to-LDS variant for plain (1x1) layers with both operands pre-split: every operand byte
+// goes global -> LDS with global_load_lds_dwordx4 (no staging registers, no ds_write, no VALU in
+// the K loop).  An LDS-DMA instruction writes 64 lanes x 16 B to CONSECUTIVE LDS addresses, so
+// rows are unpadded (BK*4 bytes) and bank conflicts are avoided by an XOR swizzle of the 16-byte
+// slot index, applied on the GLOBAL side (each lane picks the chunk that belongs in its slot):
+//   physical slot = logical slot ^ f(row),  f(row) = (row / (16 / CH)) & (CH - 1),  CH = slots per row
+// (for the 16 lanes of a ds_read_b128 group that gives 16 distinct bank quads).
+// Logical slots per 16 k: [hi k0-7 | hi k8-15 | lo k0-7 | lo k8-15]; memory chunks per 16 k:
+// [hi k0-7 | lo k0-7 | hi k8-15 | lo k8-15].  128 x 128 tile, 4 waves of 64 x 64, K % BK == 0.
+// ---------------------------------------------------------------------------------------
+template <int BK, int VAR>
+__global__ void __launch_bounds__(256, BK == 16 ? 4 : 3)
+split_gemm_glds_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, const float* __restrict__ zero,
+                       int k16, float unscale, int nbn, int vec_c, int vec_res, int vec_bias) {
+  constexpr int TM = 2, TN = 2, WN = 2, BM = 128, BN = 128, KS = BK / 16;
+  constexpr int ROWB = BK * 4, CH = ROWB / 16, RPI = 64 / CH, NI = (BM / RPI) / 4, STAGE = (BM + BN) * ROWB;
+  constexpr int FDIV = 16 / CH;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  int tile = blockIdx.x;
+  {
+    const int nwg = gridDim.x, xcd = tile & 7, idx = tile >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int bn = tile % nbn, bm = tile / nbn;
+  const int m0 = bm * BM, n0 = bn * BN;
+  const int nk = p.k / BK;
+
+  // per-lane DMA sources: instruction j of this wave fills rows [(wave*NI + j)*RPI, +RPI) of the operand
+  const unsigned char* pa[NI];
+  const unsigned char* pb[NI];
+  int sa[NI], sb[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int row = (wave * NI + j) * RPI + lane / CH;
+    const int logical = (lane % CH) ^ ((row / FDIV) & (CH - 1));
+    const int memchunk = (logical & ~3) | ((logical & 1) << 1) | ((logical >> 1) & 1);
+    const bool aok = m0 + row < p.m, bok = n0 + row < p.n;
+    pa[j] = aok ? reinterpret_cast<const unsigned char*>(p.a) + (size_t)(m0 + row) * p.lda * 4 + memchunk * 16
+                : reinterpret_cast<const unsigned char*>(zero);
+    pb[j] = bok ? wsp + (size_t)(n0 + row) * k16 * 4 + memchunk * 16 : reinterpret_cast<const unsigned char*>(zero);
+    sa[j] = aok ? ROWB : 0;
+    sb[j] = bok ? ROWB : 0;
+  }
+  auto issue = [&](int buf) {
+    unsigned char* abase = smem_raw + buf * STAGE + wave * NI * RPI * ROWB;
+    unsigned char* bbase = abase + BM * ROWB;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pa[j],
+                                       (__attribute__((address_space(3))) void*)(abase + j * RPI * ROWB), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pb[j],
+                                       (__attribute__((address_space(3))) void*)(bbase + j * RPI * ROWB), 16, 0, 0);
+      pa[j] += sa[j];
+      pb[j] += sb[j];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  // fragment addresses: row r of the operand, logical slot ks*4 + 2*plane + (lane >> 5)
+  int arow[TM], brow[TN], af[TM], bf[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    arow[i] = wm * TM * 32 + i * 32 + (lane & 31);
+    af[i] = (arow[i] / FDIV) & (CH - 1);
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    brow[j] = wn * TN * 32 + j * 32 + (lane & 31);
+    bf[j] = (brow[j] / FDIV) & (CH - 1);
+  }
+  const int hsel = lane >> 5;
+
+  issue(0);
+  __syncthreads();
+  for (int s = 0; s < nk; ++s) {
+    const unsigned char* as = smem_raw + (s & 1) * STAGE;
+    const unsigned char* bs = as + BM * ROWB;
+    h8 xh[KS][TM], xl[KS][TM], wh[KS][TN], wl[KS][TN];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        xh[ks][i] = *reinterpret_cast<const h8*>(as + arow[i] * ROWB + (((ks * 4 + hsel) ^ af[i]) << 4));
+        xl[ks][i] = *reinterpret_cast<const h8*>(as + arow[i] * ROWB + (((ks * 4 + 2 + hsel) ^ af[i]) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        wh[ks][j] = *reinterpret_cast<const h8*>(bs + brow[j] * ROWB + (((ks * 4 + hsel) ^ bf[j]) << 4));
+        wl[ks][j] = *reinterpret_cast<const h8*>(bs + brow[j] * ROWB + (((ks * 4 + 2 + hsel) ^ bf[j]) << 4));
+      }
+    }
+    if (s + 1 < nk) issue((s + 1) & 1);               // lands during this stage's MFMAs
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks][j], xh[ks][i], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks][j], xl[ks][i], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks][j], xh[ks][i], acc[i][j], 0, 0, 0);
+    }
+    // keep the MFMAs ahead of the wait: hipcc otherwise hoists "s_waitcnt vmcnt(0); s_barrier" above
+    // them (they touch no memory) and the DMA latency is exposed instead of hidden under the matrix work
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                                   // DMA of stage s+1 landed (vmcnt 0), stage s fully read
+  }
+
+  const EpiVec ev{vec_c, vec_res, vec_bias, unscale};
+  const int mw = m0 + wm * TM * 32, nw = n0 + wn * TN * 32;
+  float* patch = reinterpret_cast<float*>(smem_raw) + wave * 32 * EPI_LDT;
+  static_assert(2 * STAGE >= 4 * 32 * EPI_LDT * 4, "operand LDS must hold one patch per wave");
+  if (VAR & SVAR_CSPLIT) {
+    switch (p.act) {
+      case WD_ACT_RELU: EpiCsplitWalk<0, TM, TN, WD_ACT_RELU>::run(p, ev, mw, nw, lane, acc, patch); break;
+      case WD_ACT_SILU: EpiCsplitWalk<0, TM, TN, WD_ACT_SILU>::run(p, ev, mw, nw, lane, acc, patch); break;
+      case WD_ACT_GELU: EpiCsplitWalk<0, TM, TN, WD_ACT_GELU>::run(p, ev, mw, nw, lane, acc, patch); break;
+      default: EpiCsplitWalk<0, TM, TN, WD_ACT_NONE>::run(p, ev, mw, nw, lane, acc, patch); break;
+    }
+  } else {
+    switch (p.act) {
+      case WD_ACT_RELU: split_epilogue_lds<TM, TN, WD_ACT_RELU, false>(p, ev, mw, nw, lane, acc, patch); break;
+      case WD_ACT_SILU: split_epilogue_lds<TM, TN, WD_ACT_SILU, false>(p, ev, mw, nw, lane, acc, patch); break;
+      case WD_ACT_GELU: split_epilogue_lds<TM, TN, WD_ACT_GELU, false>(p, ev, mw, nw, lane, acc, patch); break;
+      default: split_epilogue_lds<TM, TN, WD_ACT_NONE, false>(p, ev, mw, nw, lane, acc, patch); break;
+    }
+  }
+}
+
+template <int BK, int VAR>
+int launch_glds(const WdConvGemm& p, const void* wsp, float unscale, hipStream_t st) {
+  constexpr int STAGE = 256 * BK * 4, LDS = 2 * STAGE;
+  const int nbm = (p.m + 127) / 128, nbn = (p.n + 127) / 128;
+  const long long nblk = (long long)nbm * nbn;
+  if (nblk <= 0 || nblk > 0x7fffffffLL) return WD_ERR_BAD_ARG;
+  const int k16 = (p.k + 15) / 16 * 16;
+  const int vec_c = (p.ldc % 4 == 0) && wd_aligned16(p.c);
+  const int vec_res = p.res ? ((p.ldres % 4 == 0) && wd_aligned16(p.res)) : 0;
+  const int vec_bias = p.bias ? wd_aligned16(p.bias) : 0;
+  static const float* zero = nullptr;
+  if (!zero) {
+    void* zp = nullptr;
+    if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero4)) != hipSuccess || !zp) return WD_ERR_LAUNCH;
+    zero = static_cast<const float*>(zp);
+  }
+  auto k = split_gemm_glds_kernel<BK, VAR>;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
+        hipSuccess) return WD_ERR_LAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), LDS, st, p, static_cast<const unsigned char*>(wsp), zero, k16,
+                     unscale, nbn, vec_c, vec_res, vec_bias);
+  return wd_launch_status();
+}
+
+// plain layer, rows output, no per-level affine: what the direct-to-LDS kernel's epilogue covers
+bool glds_ok(const WdConvGemm& p, int bk) {
+  const bool plain = p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0;
+  const bool special = p.out_mode != WD_OUT_ROWS || p.c_batch_stride > 0 || p.seg_rows > 0 || p.sigmoid ||
+                       p.out_scale != 1.0f || p.out_bias != 0.0f;
+  return plain && !special && p.k % bk == 0;
+}
+}  // namespace
+
+int wd_launch_presplit(const WdConvGemm& p, const void* w, float unscale, int cfg, int flags, hipStream_t st) {
+  const bool csplit = (flags & WD_SPLIT_C) != 0;
+  if (!(flags & WD_SPLIT_A)) return WD_ERR_UNSUPPORTED;            // C-only split: not needed by any layer yet
+  if (p.k % 8 || p.cin % 8 || p.lda % 8) return WD_ERR_BAD_ARG;
+  if (cfg >= 60) {                       // direct-to-LDS kernels: 60 = BK 16, 61 = BK 32
+    const int bk = cfg == 60 ? 16 : 32;
+    if (cfg > 61 || !glds_ok(p, bk)) return WD_ERR_UNSUPPORTED;
+    if (csplit) {
+      if (p.res || p.n % 8 || p.ldc % 8 || (p.bias && !wd_aligned16(p.bias)) || !wd_aligned16(p.c)) return WD_ERR_BAD_ARG;
+      return bk == 16 ? launch_glds<16, SVAR_CSPLIT>(p, w, unscale, st) : launch_glds<32, SVAR_CSPLIT>(p, w, unscale, st);
+    }
+    return bk == 16 ? launch_glds<16, 0>(p, w, unscale, st) : launch_glds<32, 0>(p, w, unscale, st);
+  }
+  if (csplit) {
+    const bool special = p.out_mode != WD_OUT_ROWS || p.c_batch_stride > 0 || p.seg_rows > 0 || p.sigmoid ||
+                         p.out_scale != 1.0f || p.out_bias != 0.0f;
+    if (special || p.res || p.n % 8 || p.ldc % 8 || (p.bias && !wd_aligned16(p.bias)) || !wd_aligned16(p.c))
+      return WD_ERR_BAD_ARG;
+    switch (cfg) {
+      case 50: return launch_split<2, 2, 2, 2, 32, VAC, 1>(p, w, unscale, st);
+      case 51: return launch_split<2, 2, 2, 2, 16, VAC, 1>(p, w, unscale, st);
+      default: return WD_ERR_UNSUPPORTED;
+    }
+  }
+  switch (cfg) {
+    case 50: return launch_split<2, 2, 2, 2, 32, VA, 0>(p, w, unscale, st);
+    case 51: return launch_split<2, 2, 2, 2, 16, VA, 0>(p, w, unscale, st);
+    case 55: return launch_split<2, 2, 2, 2, 32, VA_PF2, 1>(p, w, unscale, st);
+    default: return WD_ERR_UNSUPPORTED;
+  }
+}

@@ -150,22 +150,26 @@ class ImageTower:
         for i in range(4):
             c = a.dims[i]
             h, w = self.hw[i]
+            # fp16x3: LayerNorm and pwconv1 write their outputs as fp16 hi/lo groups, so the GEMMs that
+            # consume them copy both operands (no per-column-tile conversion of the same rows)
+            pre = self.precision == "fp16x3" and c % 8 == 0 and (i == 0 or a.dims[i - 1] % 8 == 0)
+            fa = L.SPLIT_A if pre else 0
             if i > 0:
                 cp = a.dims[i - 1]
                 hp, wp = self.hw[i - 1]
                 L.layernorm_rows(self.x[i - 1], self.tmp, self.P[f"down{i}.ln_w"], self.P[f"down{i}.ln_b"],
-                                 self.M[i - 1], cp)
+                                 self.M[i - 1], cp, split=pre)
                 self._gemm(self.tmp, f"down{i}.w", f"down{i}.b", self.x[i], hin=hp, win=wp, cin=cp, lda=cp, kh=2, kw=2,
-                           stride=2, pad=0, n=c, ldc=c)
+                           stride=2, pad=0, n=c, ldc=c, split_flags=fa)
             for j in range(a.depths[i]):
                 q = f"s{i}.{j}."
                 L.dwconv7(self.x[i], self.P[q + "dw_w"], self.P[q + "dw_b"], self.tmp, B, h, w, c)
-                L.layernorm_rows(self.tmp, self.tmp, self.P[q + "ln_w"], self.P[q + "ln_b"], self.M[i], c)
+                L.layernorm_rows(self.tmp, self.tmp, self.P[q + "ln_w"], self.P[q + "ln_b"], self.M[i], c, split=pre)
                 self._conv(self.tmp, q + "w1", q + "b1", self.hid, hin=h, win=w, cin=c, lda=c, n=4 * c, ldc=4 * c,
-                           act=L.ACT_GELU)
+                           act=L.ACT_GELU, split_flags=(L.SPLIT_A | L.SPLIT_C) if pre else 0)
                 # x <- x + (gamma*W2) hid + gamma*b2   (in place: each element is read then written by one lane)
                 self._conv(self.hid, q + "w2", q + "b2", self.x[i], hin=h, win=w, cin=4 * c, lda=4 * c, n=c, ldc=c,
-                           res=self.x[i], ldres=c)
+                           res=self.x[i], ldres=c, split_flags=fa)
         return self.x
 
     # ------------------------------------------------------------------ neck

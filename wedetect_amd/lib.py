@@ -18,13 +18,14 @@ LIB_PATH = os.path.join(_HERE, "libwedetect_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU = 0, 1, 2, 3
 OUT_ROWS, OUT_DECONV2X2 = 0, 1
-ABI_VERSION = 2
+SPLIT_A, SPLIT_C = 1, 2
+ABI_VERSION = 3
 
 EXPORTS = (
     "wd_abi_version", "wd_strerror", "wd_sizeof_conv_gemm", "wd_conv_gemm", "wd_conv_gemm_tuned", "wd_conv_gemm_config", "wd_stem_patchify", "wd_dwconv7",
     "wd_layernorm_rows", "wd_l2norm_rows", "wd_dfl_decode", "wd_topk_workspace_bytes", "wd_topk_capacity",
     "wd_topk_candidates", "wd_nms_gather", "wd_retrieval_max",
-    "wd_split_weights_bytes", "wd_split_weights", "wd_conv_gemm_split", "wd_conv_gemm_split_config",
+    "wd_split_weights_bytes", "wd_split_weights", "wd_conv_gemm_split", "wd_conv_gemm_split_config", "wd_layernorm_rows_split",
 )
 
 
@@ -86,7 +87,8 @@ def _load():
     lib.wd_split_weights_bytes.restype = i64
     lib.wd_split_weights_bytes.argtypes = [i32, i32]
     lib.wd_split_weights.argtypes = [vp, i32, i32, f32, vp, vp]
-    lib.wd_conv_gemm_split.argtypes = [C.POINTER(ConvGemm), vp, f32, i32, vp]
+    lib.wd_conv_gemm_split.argtypes = [C.POINTER(ConvGemm), vp, f32, i32, i32, vp]
+    lib.wd_layernorm_rows_split.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, f32, vp]
     lib.wd_conv_gemm_split_config.restype = C.c_char_p
     lib.wd_conv_gemm_split_config.argtypes = [i32, i32, i32, i32]
     if lib.wd_sizeof_conv_gemm() != C.sizeof(ConvGemm):
@@ -124,9 +126,10 @@ def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
 def conv_gemm(a, w, bias, c, *, batch, hin, win, cin, lda, kh=1, kw=1, stride=1, pad=0, hout=None, wout=None,
               n, ldc, act=ACT_NONE, res=None, ldres=0, res_alpha=1.0, out_mode=OUT_ROWS,
               out_scale=1.0, out_bias=0.0, sigmoid=False, c_batch_stride=0, seg=None, tuned_cfg=None,
-              w_split=None, split_cfg=-1) -> None:
+              w_split=None, split_cfg=-1, split_flags=0) -> None:
     """``seg`` = (seg_rows, seg_end0, seg_end1, (s0, s1, s2), (b0, b1, b2)) or None.
-    ``w_split`` = (split weight buffer, unscale) from :func:`split_weights` selects the fp16x3 kernel."""
+    ``w_split`` = (split weight buffer, unscale) from :func:`split_weights` selects the fp16x3 kernel;
+    ``split_flags`` = SPLIT_A / SPLIT_C: activations / output stored as fp16 hi/lo groups."""
     hout = (hin + 2 * pad - kh) // stride + 1 if hout is None else hout
     wout = (win + 2 * pad - kw) // stride + 1 if wout is None else wout
     p = ConvGemm(a=_p(a), w=_p(w), bias=_p(bias), res=_p(res), c=_p(c), batch=batch, hin=hin, win=win, cin=cin,
@@ -139,7 +142,8 @@ def conv_gemm(a, w, bias, c, *, batch, hin, win, cin, lda, kh=1, kw=1, stride=1,
         p.seg_scale = (C.c_float * 3)(*[float(v) for v in seg[3]])
         p.seg_bias = (C.c_float * 3)(*[float(v) for v in seg[4]])
     if w_split is not None:
-        check(LIB.wd_conv_gemm_split(C.byref(p), _p(w_split[0]), float(w_split[1]), int(split_cfg), stream_ptr()),
+        check(LIB.wd_conv_gemm_split(C.byref(p), _p(w_split[0]), float(w_split[1]), int(split_flags), int(split_cfg),
+                                     stream_ptr()),
               f"wd_conv_gemm_split[{split_cfg}]")
         return
     if tuned_cfg is not None:
@@ -164,9 +168,9 @@ def split_weights(w: torch.Tensor):
     return out, 1.0 / scale
 
 
-def gemm_config(m: int, n: int, k: int, split: bool = False, conv: bool = False) -> str:
+def gemm_config(m: int, n: int, k: int, split: bool = False, conv: bool = False, presplit: bool = False) -> str:
     if split:
-        return LIB.wd_conv_gemm_split_config(m, n, k, int(conv)).decode()
+        return LIB.wd_conv_gemm_split_config(m, n, k, 1 if conv else (2 if presplit else 0)).decode()
     return LIB.wd_conv_gemm_config(m, n, k).decode()
 
 
@@ -179,9 +183,11 @@ def dwconv7(x, w7, bias, y, batch, h, w, c) -> None:
     check(LIB.wd_dwconv7(_p(x), _p(w7), _p(bias), _p(y), batch, h, w, c, stream_ptr()), "wd_dwconv7")
 
 
-def layernorm_rows(x, y, gamma, beta, rows, c, ldx=None, ldy=None, eps=1e-6) -> None:
-    check(LIB.wd_layernorm_rows(_p(x), _p(y), _p(gamma), _p(beta), rows, c, ldx or c, ldy or c, eps, stream_ptr()),
-          "wd_layernorm_rows")
+def layernorm_rows(x, y, gamma, beta, rows, c, ldx=None, ldy=None, eps=1e-6, split=False) -> None:
+    """``split``: write y as fp16 hi/lo groups for a ``conv_gemm(..., split_flags=SPLIT_A)`` consumer."""
+    fn = LIB.wd_layernorm_rows_split if split else LIB.wd_layernorm_rows
+    check(fn(_p(x), _p(y), _p(gamma), _p(beta), rows, c, ldx or c, ldy or c, eps, stream_ptr()),
+          "wd_layernorm_rows_split" if split else "wd_layernorm_rows")
 
 
 def l2norm_rows(x, y) -> None:
