@@ -47,7 +47,8 @@ KERNEL_SYMBOL = {
     "fp16x3 128x128x32/4w/plain": "split_gemm_kernel<2, 2, 2, 2, 32, false, 770>",
     "fp16x3 128x128x32/4w/conv": "split_gemm_kernel<2, 2, 2, 2, 32, true, 770>",
     "fp16x3 128x128x32/4w/pf2/plain": "split_gemm_kernel<2, 2, 2, 2, 32, false, 896>",
-    "fp16x3 128x128x16/4w/glds/plain": "split_gemm_glds_kernel<16, 0>",
+    # one bench tag, two instantiations: pwconv1 (output written as fp16 hi/lo groups) and pwconv2
+    "fp16x3 128x128x16/4w/glds/plain": ["split_gemm_glds_kernel<16, 2048>", "split_gemm_glds_kernel<16, 0>"],
 }
 
 
@@ -59,7 +60,10 @@ def measured_traffic(tag):
     try:
         name = "r01_fp16x3_traffic.json" if tag.startswith("fp16x3") else "r01_traffic.json"
         rec = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
-        return round(rec[KERNEL_SYMBOL[tag]]["hbm_bytes_per_launch"])
+        syms = KERNEL_SYMBOL[tag]
+        syms = [syms] if isinstance(syms, str) else syms
+        n = sum(rec[s]["launches"] for s in syms)
+        return round(sum(rec[s]["hbm_bytes_per_launch"] * rec[s]["launches"] for s in syms) / n)
     except Exception:
         return None
 HBM_PEAK_GBS = 8000.0
@@ -240,7 +244,7 @@ def main():
         # fp16x3 issues three fp16 MFMA passes per fp32-accurate product: the roof for ALGORITHMIC
         # flops is the fp16 dense peak / 3; the fraction of the raw fp16 peak is reported beside it.
         dom_peak = round(F16_MFMA_PEAK_TFLOPS / SPLIT_PASSES, 1) if dom_split else F32_MFMA_PEAK_TFLOPS
-        dom_kernel = (f"split_gemm_kernel<{dom_tag}> (3 x v_mfma_f32_32x32x16_f16 per product)" if dom_split
+        dom_kernel = (f"split_gemm{'_glds' if 'glds' in dom_tag else ''}_kernel<{dom_tag}> (3 x v_mfma_f32_32x32x16_f16 per product)" if dom_split
                       else f"conv_gemm_kernel<{dom_tag}> (fp32 MFMA 16x16x4)")
         out = {
             "metric": f"images/s at {S}x{S} (WeDetect-{args.arch.capitalize()} image tower + {K}-class similarity + top-k/NMS)",
