@@ -103,7 +103,7 @@ extern "C" int wd_conv_gemm_split(const WdConvGemm* pp, const void* w_split, flo
     const bool special = p.out_mode != WD_OUT_ROWS || p.c_batch_stride > 0 || p.seg_rows > 0 || p.sigmoid ||
                          p.out_scale != 1.0f || p.out_bias != 0.0f;
     if (production && plain && !special && p.k % 16 == 0) cfg = 60;
-    if (cfg != 50 && cfg != 51 && cfg != 55 && cfg != 60 && cfg != 61) cfg = 51;
+    if (cfg != 50 && cfg != 51 && cfg != 55 && cfg != 60) cfg = 51;
     if ((flags & WD_SPLIT_C) && cfg == 55) cfg = 50;
     return wd_launch_presplit(p, w_split, w_unscale, cfg, flags, st);
   }

@@ -188,6 +188,13 @@ int launch_glds(const WdConvGemm& p, const void* wsp, float unscale, hipStream_t
   return wd_launch_status();
 }
 
+
+// Tried on top of this kernel and dropped (profiles/r01_split_gemm_ab.txt): BK = 32 stages (fewer
+// resident waves: -15..-25 %), and a three-stage LDS ring with the DMA issued through inline asm two
+// stages ahead and the next stage's fragments prefetched into a second register set under the
+// current stage's MFMAs (bit-identical, but 218 registers = two waves per SIMD: -10..-15 %; at
+// three waves per SIMD it spills).  As for the fp32 kernel, resident waves beat per-wave pipelining.
+
 // plain layer, rows output, no per-level affine: what the direct-to-LDS kernel's epilogue covers
 bool glds_ok(const WdConvGemm& p, int bk) {
   const bool plain = p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0;
@@ -201,14 +208,13 @@ int wd_launch_presplit(const WdConvGemm& p, const void* w, float unscale, int cf
   const bool csplit = (flags & WD_SPLIT_C) != 0;
   if (!(flags & WD_SPLIT_A)) return WD_ERR_UNSUPPORTED;            // C-only split: not needed by any layer yet
   if (p.k % 8 || p.cin % 8 || p.lda % 8) return WD_ERR_BAD_ARG;
-  if (cfg >= 60) {                       // direct-to-LDS kernels: 60 = BK 16, 61 = BK 32
-    const int bk = cfg == 60 ? 16 : 32;
-    if (cfg > 61 || !glds_ok(p, bk)) return WD_ERR_UNSUPPORTED;
+  if (cfg == 60) {                       // direct-to-LDS kernel
+    if (!glds_ok(p, 16)) return WD_ERR_UNSUPPORTED;
     if (csplit) {
       if (p.res || p.n % 8 || p.ldc % 8 || (p.bias && !wd_aligned16(p.bias)) || !wd_aligned16(p.c)) return WD_ERR_BAD_ARG;
-      return bk == 16 ? launch_glds<16, SVAR_CSPLIT>(p, w, unscale, st) : launch_glds<32, SVAR_CSPLIT>(p, w, unscale, st);
+      return launch_glds<16, SVAR_CSPLIT>(p, w, unscale, st);
     }
-    return bk == 16 ? launch_glds<16, 0>(p, w, unscale, st) : launch_glds<32, 0>(p, w, unscale, st);
+    return launch_glds<16, 0>(p, w, unscale, st);
   }
   if (csplit) {
     const bool special = p.out_mode != WD_OUT_ROWS || p.c_batch_stride > 0 || p.seg_rows > 0 || p.sigmoid ||
