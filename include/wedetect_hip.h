@@ -134,6 +134,19 @@ int wd_conv_gemm_split(const WdConvGemm* p, const void* w_split, float w_unscale
  * not a 1x1 / stride 1 / pad 0 layer (diagnostic). */
 const char* wd_conv_gemm_split_config(int32_t m, int32_t n, int32_t k, int32_t is_conv);
 
+/* ---------------------------------------------------------------------------------------------
+ * wd_letterbox_u8 — keep-ratio resize + centred pad of one uint8 RGB HWC image on the device,
+ * bit-exact with PIL's Image.resize(..., BILINEAR) + paste (generate_proposal.py:17-82 letterbox;
+ * Pillow src/libImaging/Resample.c: two separable int32 passes with 22 fractional bits, uint8
+ * between the passes).  bounds_* [out, 2] = (first input sample, count), kk_* [out, ksize] = int32
+ * weights, both from Pillow's precompute_coeffs / normalize_coeffs_8bpc (wedetect_amd/preprocess.py
+ * computes them on the host); tmp: h * new_w * 3 bytes; dst: the [dst_h, dst_w, 3] canvas, filled
+ * with (fill_r, fill_g, fill_b) outside the pasted new_h x new_w rectangle at (left, top). */
+int wd_letterbox_u8(const uint8_t* src, int32_t h, int32_t w, const int32_t* bounds_h, const int32_t* kk_h,
+                    int32_t ksize_h, const int32_t* bounds_v, const int32_t* kk_v, int32_t ksize_v, uint8_t* tmp,
+                    uint8_t* dst, int32_t dst_h, int32_t dst_w, int32_t new_w, int32_t new_h, int32_t left, int32_t top,
+                    int32_t fill_r, int32_t fill_g, int32_t fill_b, void* stream);
+
 /* wd_layernorm_rows with the output written as fp16 (hi, lo) groups (see WD_SPLIT_A); c % 8 == 0. */
 int wd_layernorm_rows_split(const float* x, void* y, const float* gamma, const float* beta, int64_t rows, int32_t c,
                             int32_t ldx, int32_t ldy, float eps, void* stream);

@@ -420,6 +420,26 @@ def case_mmdet_modules(arch="tiny", hw=64):
     np.savez_compressed(os.path.join(OUT, f"mm_{arch}_b1_{hw}.npz"), **fx)
 
 
+def case_letterbox(gp):
+    """The reference's own ``letterbox`` (generate_proposal.py:17-82, PIL BILINEAR resize + paste) on
+    seeded images: down-scale, up-scale, tall, wide, already-square."""
+    from PIL import Image
+    g = np.random.default_rng(99)
+    fx = {}
+    for i, ((h, w), shape) in enumerate((((150, 200), (96, 96)), ((37, 53), (96, 96)), ((300, 90), (64, 96)),
+                                         ((96, 96), (96, 96)), ((31, 257), (64, 64)))):
+        # smooth + noisy content so that antialiasing weights matter
+        yy, xx = np.mgrid[0:h, 0:w]
+        base = (127 + 100 * np.sin(xx / 7.0 + i) * np.cos(yy / 5.0))[..., None] + g.normal(0, 25, (h, w, 3))
+        img = np.clip(base, 0, 255).astype(np.uint8)
+        out, ratio, (dw, dh) = gp.letterbox(Image.fromarray(img), shape)
+        fx[f"img{i}"] = img
+        fx[f"out{i}"] = np.asarray(out)
+        fx[f"meta{i}"] = np.asarray([shape[0], shape[1], ratio, dw, dh], np.float64)
+    fx["count"] = np.asarray(5)
+    np.savez_compressed(os.path.join(OUT, "letterbox.npz"), **fx)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference tree not present: goldens can only be generated in the build container"
     # transformers probes torchvision at import: the plugin files (which import it) must be
@@ -433,4 +453,5 @@ if __name__ == "__main__":
     case_network(gp, "base", 2, 128)
     case_network(gp, "base", 1, 640)
     case_network(gp, "large", 1, 64, full_predict=False)
+    case_letterbox(gp)
     print("all golden fixtures written to", OUT)

@@ -164,6 +164,33 @@ def test_letterbox_matches_reference_arithmetic():
     assert np.all(a[:14] == 114) and np.all(a[50:] == 114) and not np.all(a[14:50] == 114)
 
 
+def test_resample_oracle_is_pinned_to_pillow_and_reference_letterbox():
+    """oracle/resample.py == PIL.Image.resize(BILINEAR) bit for bit (up / down scaling, odd sizes),
+    == the letterbox goldens produced by the reference's own function, and the product's host-side
+    weight tables (wedetect_amd/preprocess.py) are the oracle's."""
+    from PIL import Image
+    from oracle import resample as R
+    from wedetect_amd import preprocess as P
+    g = np.random.default_rng(5)
+    for (h, w), (nh, nw) in (((75, 100), (96, 128)), ((216, 384), (72, 128)), ((64, 48), (320, 240)), ((133, 277), (61, 128)),
+                             ((400, 300), (128, 96)), ((64, 64), (64, 64)), ((17, 5), (128, 38)), ((9, 301), (3, 96))):
+        a = g.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        ref = np.asarray(Image.fromarray(a).resize((nw, nh), Image.Resampling.BILINEAR))
+        assert np.array_equal(R.resize_bilinear_u8(a, nw, nh), ref), f"{(h, w)} -> {(nh, nw)}"
+        for n_in, n_out in ((w, nw), (h, nh)):
+            ob, ok = R.coeffs(n_in, n_out)
+            pb, pk = P.resample_coeffs(n_in, n_out)
+            assert np.array_equal(ob, pb) and np.array_equal(ok, pk)
+    fx = golden("letterbox.npz")
+    for i in range(int(fx["count"])):
+        th, tw, ratio, dw, dh = fx[f"meta{i}"]
+        out, r, (pw, ph) = R.letterbox_u8(fx[f"img{i}"], (int(th), int(tw)))
+        assert np.array_equal(out, fx[f"out{i}"]) and r == ratio and (pw, ph) == (dw, dh)
+        h, w = fx[f"img{i}"].shape[:2]
+        nw, nh, left, top, r2, pad = P.letterbox_geometry(w, h, (int(th), int(tw)))
+        assert r2 == ratio and pad == (dw, dh) and left == int(dw) and top == int(dh)
+
+
 def test_instance_data_surface():
     from wedetect_amd.detector import InstanceData
     d = InstanceData(bboxes=torch.arange(12.).view(3, 4), scores=torch.tensor([0.9, 0.2, 0.5]), labels=torch.tensor([1, 2, 3]))

@@ -71,7 +71,8 @@ class _IncompatibleKeys:
 
 
 # ------------------------------------------------------------------------------------------
-# host-side letterbox (SURVEY.md §8 row f1 — host pre-processing; device version is "next")
+# host-side letterbox (the reference's arithmetic with PIL; the detectors use the device version,
+# wedetect_amd/preprocess.py, which is bit-exact with it)
 # ------------------------------------------------------------------------------------------
 def letterbox(img, new_shape=(640, 640), color=(114, 114, 114)):
     """Keep-ratio resize + centred pad to ``new_shape`` (h, w) like generate_proposal.py:17-82:
@@ -154,6 +155,7 @@ class SimpleYOLOWorldDetector:
         self.num_proposals = num_proposals
         self.img_size = tuple(img_size) if img_size is not None else _IMG_SIZE[backbone_size]
         self._h = _TowerHolder(backbone_size, num_prompts, self.img_size, max(num_prompts, 1), num_proposals, precision)
+        self._lb = None
         self.training = False
 
     # -- nn.Module-like surface used by the reference scripts
@@ -176,17 +178,23 @@ class SimpleYOLOWorldDetector:
     @torch.no_grad()
     def forward(self, image_paths: Sequence[Union[str, object]], rescale=True) -> List[Dict[str, torch.Tensor]]:
         from PIL import Image
-        arrs, metas = [], []
+        from .preprocess import DeviceLetterbox
+        if self._h.device is None:
+            raise RuntimeError("model is not on a HIP device: call .cuda() (there is no CPU execution path)")
+        imgs, metas = [], []
         for p in image_paths:
-            img = Image.open(p).convert("RGB") if isinstance(p, str) else p
+            imgs.append(Image.open(p).convert("RGB") if isinstance(p, str) else p)
+        # letterbox on the device (wd_letterbox_u8, bit-exact with the PIL resize + paste of the
+        # reference): the host only decodes and uploads
+        if self._lb is None:
+            self._lb = DeviceLetterbox(self.img_size, device=self._h.device)
+        x, ratios, pads = self._lb(imgs)
+        for img, ratio, (dw, dh) in zip(imgs, ratios, pads):
             w, h = img.size
-            lb, ratio, (dw, dh) = letterbox(img, self.img_size)
-            arrs.append(np.asarray(lb, dtype=np.uint8))
             sc = ratio if rescale else 1.0
             metas.append([dw, dh, 0.0, sc, sc, float(w), float(h), 0.0])
-        b = len(arrs)
+        b = len(imgs)
         tower = self._h.tower(b)
-        x = torch.from_numpy(np.stack(arrs)).to(self._h.device)
         meta = torch.tensor(metas, dtype=torch.float32, device=self._h.device)
         res = tower.detect(x, tower.P["prompts"], meta, normalize_text=False, score_thr=0.0, with_embed=True)
         counts = res["count"].tolist()                      # one D2H sync per batch

@@ -25,7 +25,7 @@ EXPORTS = (
     "wd_abi_version", "wd_strerror", "wd_sizeof_conv_gemm", "wd_conv_gemm", "wd_conv_gemm_tuned", "wd_conv_gemm_config", "wd_stem_patchify", "wd_dwconv7",
     "wd_layernorm_rows", "wd_l2norm_rows", "wd_dfl_decode", "wd_topk_workspace_bytes", "wd_topk_capacity",
     "wd_topk_candidates", "wd_nms_gather", "wd_retrieval_max",
-    "wd_split_weights_bytes", "wd_split_weights", "wd_conv_gemm_split", "wd_conv_gemm_split_config", "wd_layernorm_rows_split",
+    "wd_split_weights_bytes", "wd_split_weights", "wd_conv_gemm_split", "wd_conv_gemm_split_config", "wd_layernorm_rows_split", "wd_letterbox_u8",
 )
 
 
@@ -89,6 +89,7 @@ def _load():
     lib.wd_split_weights.argtypes = [vp, i32, i32, f32, vp, vp]
     lib.wd_conv_gemm_split.argtypes = [C.POINTER(ConvGemm), vp, f32, i32, i32, vp]
     lib.wd_layernorm_rows_split.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, f32, vp]
+    lib.wd_letterbox_u8.argtypes = [vp, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.wd_conv_gemm_split_config.restype = C.c_char_p
     lib.wd_conv_gemm_split_config.argtypes = [i32, i32, i32, i32]
     if lib.wd_sizeof_conv_gemm() != C.sizeof(ConvGemm):
@@ -188,6 +189,13 @@ def layernorm_rows(x, y, gamma, beta, rows, c, ldx=None, ldy=None, eps=1e-6, spl
     fn = LIB.wd_layernorm_rows_split if split else LIB.wd_layernorm_rows
     check(fn(_p(x), _p(y), _p(gamma), _p(beta), rows, c, ldx or c, ldy or c, eps, stream_ptr()),
           "wd_layernorm_rows_split" if split else "wd_layernorm_rows")
+
+
+def letterbox_u8(src, h, w, bounds_h, kk_h, ksize_h, bounds_v, kk_v, ksize_v, tmp, dst, dst_h, dst_w, new_w, new_h,
+                 left, top, fill) -> None:
+    check(LIB.wd_letterbox_u8(_p(src), h, w, _p(bounds_h), _p(kk_h), ksize_h, _p(bounds_v), _p(kk_v), ksize_v, _p(tmp),
+                              _p(dst), dst_h, dst_w, new_w, new_h, left, top, int(fill[0]), int(fill[1]), int(fill[2]),
+                              stream_ptr()), "wd_letterbox_u8")
 
 
 def l2norm_rows(x, y) -> None:
