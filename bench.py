@@ -190,7 +190,7 @@ def main():
     from wedetect_amd import weights as W
     from wedetect_amd.engine import ImageTower
     from wedetect_amd.pack import pack
-    from wedetect_amd.parallel import gather_regions
+    from wedetect_amd.parallel import RegionGatherer
 
     B, S, K = args.batch, args.size, args.classes
     tower = ImageTower(args.arch, pack(W.make_state_dict(args.arch), args.arch), B, S, S, max_classes=K,
@@ -205,14 +205,19 @@ def main():
     timer = GemmTimer(L)
     timer.install()
 
+    gatherer = RegionGatherer() if world > 1 else None
+
     def step():
         res = tower.detect(images, text, meta, normalize_text=not uni, score_thr=0.0 if uni else 0.001,
                            with_embed=True)
-        if world > 1:
-            gather_regions(res["embeddings"], res["count"])
+        if gatherer is not None:
+            # the exchange of this batch's kept-region embeddings runs behind the next batch's kernels
+            gatherer.submit(res["embeddings"], res["count"])
         return res
 
     def sync():
+        if gatherer is not None:
+            gatherer.collect()               # every gather started inside the bracket completes inside it
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()

@@ -255,7 +255,20 @@ def _gather_worker(rank, world, port, q):
     cnt = torch.tensor([i % 5 + 1 for i in ids], dtype=torch.int32)
     g = gather_regions(emb, cnt)
     r = gather_results(dict(image_id=torch.tensor(ids, dtype=torch.int64)))
-    q.put((rank, g["embeddings"][:, 0, 0].tolist(), g["count"].tolist(), r["image_id"].tolist()))
+    # pipelined exchange: three steps, result of step i is handed out at submit(i + 1) / collect()
+    from wedetect_amd.parallel import RegionGatherer
+    rg = RegionGatherer()
+    got = []
+    for step in range(3):
+        prev = rg.submit(emb + 10.0 * step, cnt + step)
+        emb_live = emb + 10.0 * step              # "the tower overwrites its buffers" right after submit
+        emb_live.zero_()
+        if prev is not None:
+            got.append((prev["embeddings"][:, 0, 0].tolist(), prev["count"].tolist()))
+    last = rg.collect()
+    got.append((last["embeddings"][:, 0, 0].tolist(), last["count"].tolist()))
+    assert rg.collect() is None
+    q.put((rank, g["embeddings"][:, 0, 0].tolist(), g["count"].tolist(), r["image_id"].tolist(), got))
     dist.destroy_process_group()
 
 
@@ -271,7 +284,10 @@ def test_region_gather_world2_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, e0, cnt, ids in outs:
+    for rank, e0, cnt, ids, piped in outs:
         assert ids == [0, 1, 2, 3, 4, 5], (rank, ids)                # global image order on every rank
         assert e0 == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0]
         assert cnt == [i % 5 + 1 for i in range(6)]
+        assert len(piped) == 3
+        for step, (pe, pc) in enumerate(piped):
+            assert pe == [i + 10.0 * step for i in range(6)] and pc == [i % 5 + 1 + step for i in range(6)]

@@ -41,6 +41,59 @@ def gather_regions(embeddings: torch.Tensor, count: torch.Tensor, group=None) ->
     return dict(embeddings=out_e, count=out_c)
 
 
+class RegionGatherer:
+    """Pipelined form of :func:`gather_regions` for a stream of batches: ``submit`` copies the
+    step's kept-region tensors into one of two staging slots and starts the all-gather
+    asynchronously (RCCL runs it on its own stream, behind the producing kernels); the caller's
+    stream goes straight on to the next batch and picks the result up with ``collect`` — at the
+    next ``submit`` at the latest.  Over xGMI a [32, 300, 768] fp32 block per rank is ~4 ms at 8
+    ranks; overlapped it costs the step nothing.  The tower's output buffers may be overwritten
+    as soon as ``submit`` returns (the staging copy is ordered before it on the same stream)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.slots = [None, None]
+        self.turn = 0
+        self.pending = None               # (work handles, out_e, out_c)
+
+    def _slot(self, emb, cnt, world):
+        s = self.slots[self.turn]
+        if s is None or s["emb"].shape != emb.shape or s["emb"].dtype != emb.dtype or s["emb"].device != emb.device:
+            s = dict(emb=torch.empty_like(emb), cnt=torch.empty_like(cnt),
+                     out_e=torch.empty((world * emb.shape[0],) + tuple(emb.shape[1:]), dtype=emb.dtype, device=emb.device),
+                     out_c=torch.empty(world * cnt.shape[0], dtype=cnt.dtype, device=cnt.device))
+            self.slots[self.turn] = s
+        return s
+
+    def submit(self, embeddings: torch.Tensor, count: torch.Tensor) -> Optional[Dict[str, torch.Tensor]]:
+        """Starts the exchange of this step; returns the PREVIOUS step's gathered result (or None)."""
+        prev = self.collect()
+        if not dist.is_available() or not dist.is_initialized():
+            self.pending = (None, embeddings, count)
+            return prev
+        world = dist.get_world_size(self.group)
+        s = self._slot(embeddings, count, world)
+        s["emb"].copy_(embeddings, non_blocking=True)
+        s["cnt"].copy_(count, non_blocking=True)
+        h1 = dist.all_gather_into_tensor(s["out_e"], s["emb"], group=self.group, async_op=True)
+        h2 = dist.all_gather_into_tensor(s["out_c"], s["cnt"], group=self.group, async_op=True)
+        self.pending = ((h1, h2), s["out_e"], s["out_c"])
+        self.turn ^= 1
+        return prev
+
+    def collect(self) -> Optional[Dict[str, torch.Tensor]]:
+        """Waits (stream-side on GPUs) for the exchange in flight; its tensors stay valid until the
+        second ``submit`` after this call."""
+        if self.pending is None:
+            return None
+        handles, e, c = self.pending
+        self.pending = None
+        if handles is not None:
+            for h in handles:
+                h.wait()
+        return dict(embeddings=e, count=c)
+
+
 def gather_results(fields: Dict[str, torch.Tensor], group=None) -> Dict[str, torch.Tensor]:
     """Same exchange for any dict of per-image tensors with a leading B_local axis (image ids,
     scales, bias ... — the four lists of extract_embedding.py:1753-1756 in one place)."""
