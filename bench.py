@@ -184,6 +184,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # the image exports NCCL_DEBUG=VERSION, which makes RCCL print a version banner on STDOUT
+        # (next to the one JSON line this script owes the driver): keep warnings, drop the banner
+        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+            os.environ["NCCL_DEBUG"] = "WARN"
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)
 
     from wedetect_amd import lib as L

@@ -1,4 +1,5 @@
-"""Time the CPU oracle (Base@640, one image) at several thread counts on this host."""
+"""Probe tool (not collected by pytest): time the CPU oracle (Base@640, one image) at several thread counts on this host.
+    python -m tests.probe_cpu_threads   (output kept in profiles/r01_cpu_threads_probe.txt)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
