@@ -235,3 +235,26 @@ def test_presplit_downsample_conv_bit_identical():
     L.conv_gemm(t32, None, bias, o32, w_split=ws, **kw)
     L.conv_gemm(ts, None, bias, os_, w_split=ws, split_flags=L.SPLIT_A, **kw)
     assert torch.equal(os_, o32)
+
+
+def test_presplit_flags_are_validated():
+    from wedetect_amd import lib as L
+    m, k, n = 256, 128, 128
+    a, w = _rand((m, k), 81), _rand((n, k), 82, 0.1)
+    ws = L.split_weights(w)
+    c = torch.empty(m, n, device="cuda")
+    base = dict(batch=1, hin=1, win=m, cin=k, lda=k, n=n, ldc=n, w_split=ws)
+    with pytest.raises(L.WedetectHipError):                       # unknown flag bit
+        L.conv_gemm(a, None, None, c, split_flags=4, **base)
+    with pytest.raises(L.WedetectHipError):                       # C split without a split A
+        L.conv_gemm(a, None, None, c, split_flags=L.SPLIT_C, **base)
+    with pytest.raises(L.WedetectHipError):                       # C split cannot carry a residual
+        L.conv_gemm(a, None, None, c, split_flags=L.SPLIT_A | L.SPLIT_C, res=c, ldres=n, **base)
+    a12, w12 = _rand((m, 12), 83), _rand((n, 12), 84)
+    with pytest.raises(L.WedetectHipError):                       # groups of 8 need k % 8 == 0
+        L.conv_gemm(a12, None, None, c, batch=1, hin=1, win=m, cin=12, lda=12, n=n, ldc=n, w_split=L.split_weights(w12),
+                    split_flags=L.SPLIT_A)
+    x = _rand((8, 12), 85)
+    with pytest.raises(L.WedetectHipError):                       # LayerNorm split output needs c % 8 == 0
+        L.layernorm_rows(x, torch.empty_like(x), torch.ones(12, device="cuda"), torch.zeros(12, device="cuda"), 8, 12,
+                         split=True)
