@@ -187,7 +187,7 @@ def test_layernorm_split_output_is_the_split_of_the_fp32_output(rows, c):
     assert torch.equal(xi.view(torch.int32), ys.view(torch.int32))
 
 
-@pytest.mark.parametrize("cfg", [-1, 50, 51, 55, 60])
+@pytest.mark.parametrize("cfg", [-1, 50, 51, 55, 60, 63])
 def test_presplit_operands_give_bit_identical_results(cfg):
     """LN(split) -> GEMM(A split, C split, GELU) -> GEMM(A split, residual) == the same chain with
     fp32 buffers and the loader-side split, bit for bit; the split C is the split of the fp32 C."""
@@ -204,8 +204,8 @@ def test_presplit_operands_give_bit_identical_results(cfg):
     kw1 = dict(batch=1, hin=1, win=m, cin=c, lda=c, n=4 * c, ldc=4 * c, act=L.ACT_GELU)
     kw2 = dict(batch=1, hin=1, win=m, cin=4 * c, lda=4 * c, n=c, ldc=c, res=res, ldres=c)
     c1 = cfg if cfg != 55 else 50
-    ref1 = {60: 51}.get(c1, c1)          # the direct-to-LDS kernel sums k in the order of the BK 16 tile
-    ref2 = {60: 51}.get(cfg, cfg)
+    ref1 = {60: 51, 63: 51}.get(c1, c1)          # the direct-to-LDS kernel sums k in the order of the BK 16 tile
+    ref2 = {60: 51, 63: 51}.get(cfg, cfg)
     L.conv_gemm(t32, None, b1, h32, w_split=ws1, split_cfg=ref1, **kw1)
     L.conv_gemm(h32, None, b2, o32, w_split=ws2, split_cfg=ref2, **kw2)
     # pre-split chain

@@ -71,7 +71,7 @@ static int pick_split_cfg(const WdConvGemm& p) {
 
 // is_conv: 0 = plain, 1 = conv, 2 = plain with pre-split operands (direct-to-LDS kernel)
 extern "C" const char* wd_conv_gemm_split_config(int32_t m, int32_t n, int32_t k, int32_t is_conv) {
-  if (is_conv == 2 && k % 16 == 0) return "fp16x3 128x128x16/4w/glds";
+  if (is_conv == 2 && k % 16 == 0) return m >= 131072 ? "fp16x3 256x128x16/8w/pingpong" : "fp16x3 128x128x16/4w/glds";
   WdConvGemm q{};
   q.m = m; q.n = n; q.k = k; q.kh = q.kw = q.stride = 1;
   if (is_conv) q.kh = q.kw = 3;                                      // any non-1x1 geometry selects the conv loader
@@ -102,8 +102,9 @@ extern "C" int wd_conv_gemm_split(const WdConvGemm* pp, const void* w_split, flo
     const bool plain = p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0;
     const bool special = p.out_mode != WD_OUT_ROWS || p.c_batch_stride > 0 || p.seg_rows > 0 || p.sigmoid ||
                          p.out_scale != 1.0f || p.out_bias != 0.0f;
-    if (production && plain && !special && p.k % 16 == 0) cfg = 60;
-    if (cfg != 50 && cfg != 51 && cfg != 55 && cfg != 60) cfg = 51;
+    // long-m layers (ConvNeXt stages 1-2): the ping-pong 256 x 128 kernel, else 128 x 128
+    if (production && plain && !special && p.k % 16 == 0) cfg = p.m >= 131072 ? 63 : 60;
+    if (cfg != 50 && cfg != 51 && cfg != 55 && cfg != 60 && cfg != 63) cfg = 51;
     if ((flags & WD_SPLIT_C) && cfg == 55) cfg = 50;
     return wd_launch_presplit(p, w_split, w_unscale, cfg, flags, st);
   }

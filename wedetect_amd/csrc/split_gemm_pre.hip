@@ -194,6 +194,239 @@ int launch_glds(const WdConvGemm& p, const void* wsp, float unscale, hipStream_t
 // stages ahead and the next stage's fragments prefetched into a second register set under the
 // current stage's MFMAs (bit-identical, but 218 registers = two waves per SIMD: -10..-15 %; at
 // three waves per SIMD it spills).  As for the fp32 kernel, resident waves beat per-wave pipelining.
+// The ping-pong kernel below (kept: it wins 3-14 % on the long-m stage-1/2 shapes) was also run with
+// four LDS stages / DMA three stages ahead (one workgroup per CU: -18 %), with 256 x 256 tiles
+// (64 x 128 wave tiles, one workgroup per CU: -5..-10 %) and with s_setprio around the MFMA slot (0 %).
+// All structures end between 250 and 300 TFLOP/s on the stage-3/4 shapes.
+
+// ---------------------------------------------------------------------------------------
+// Ping-pong variant: 256 x 128 tile, 8 waves in two groups of four (group g owns activation rows
+// [128 g, 128 g + 128) of the tile, both share the weight columns).  Waves w and w + 4 sit on the
+// same SIMD, one from each group, and the groups run half an iteration apart:
+//     slot 2s    : group 0 issues the 12 MFMAs of stage s   | group 1 DMAs its share of stage s+2, reads its stage-s fragments
+//     slot 2s+1  : group 0 DMAs its share of stage s+2, reads its stage-(s+1) fragments | group 1 issues the MFMAs of stage s
+// with one workgroup barrier between slots, so every SIMD's matrix pipe always has exactly one wave of
+// the workgroup feeding it while the partner wave does the memory work (one fragment register set is
+// enough: a wave's read slot and MFMA slot never overlap).  Three LDS stages of 24 KB (unpadded,
+// XOR-swizzled rows as above); the DMA goes through inline asm so that hipcc does not wait for it
+// at the next ds_read; a wave waits for its own DMAs (vmcnt 0) at the end of its MFMA slot, one
+// full slot after issuing them, which is before any wave reads that stage.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void dma16(unsigned lds_addr, const unsigned char* src) {
+  asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(src) : "memory", "m0");
+}
+
+template <int N, int NI>
+__device__ __forceinline__ void wait_dma_groups(int groups_in_flight) {
+  // wave-uniform: allow the newest `groups_in_flight` DMA groups (NI instructions each) to stay outstanding
+  static_assert(NI == 3 || NI == 4, "vmcnt immediates below");
+  if (groups_in_flight <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if (groups_in_flight == 1 || N == 1) { if (NI == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+  else { if (NI == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+}
+
+template <int VAR, int NBUF, int TN>
+__global__ void __launch_bounds__(512, (NBUF == 3 && TN == 2) ? 4 : 2)
+split_gemm_pingpong_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, const float* __restrict__ zero,
+                           int k16, float unscale, int nbn, int vec_c, int vec_res, int vec_bias) {
+  constexpr int TM = 2, BM = 256, BN = 64 * TN, BK = 16, ROWB = 64, DIST = NBUF - 1;   // DMA runs DIST stages ahead
+  constexpr int STAGE = (BM + BN) * ROWB, NI = (BM + BN) / 16 / 8;   // one-KB DMA instructions per stage and wave: 3 or 4
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int group = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+  int tile = blockIdx.x;
+  {
+    const int nwg = gridDim.x, xcd = tile & 7, idx = tile >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int bn = tile % nbn, bm = tile / nbn;
+  const int m0 = bm * BM, n0 = bn * BN;
+  const int nk = p.k / BK;
+
+  // DMA sources: instruction j of this wave fills combined rows [(wave*3 + j)*16, +16) of a stage
+  // (rows 0..255 = activations, 256..383 = weights); lane = (row in the group of 16, 16-byte slot)
+  const unsigned char* ps[NI];
+  int st[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int row = (wave * NI + j) * 16 + (lane >> 2);
+    const int logical = (lane & 3) ^ ((row >> 2) & 3);
+    const int memchunk = ((logical & 1) << 1) | ((logical >> 1) & 1);
+    const bool is_a = row < BM;
+    const bool ok = is_a ? (m0 + row < p.m) : (n0 + row - BM < p.n);
+    const unsigned char* src = is_a ? reinterpret_cast<const unsigned char*>(p.a) + (size_t)(m0 + row) * p.lda * 4
+                                    : wsp + (size_t)(n0 + row - BM) * k16 * 4;
+    ps[j] = ok ? src + memchunk * 16 : reinterpret_cast<const unsigned char*>(zero);
+    st[j] = ok ? ROWB : 0;
+  }
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_raw;
+  auto issue = [&](int buf) {
+    const unsigned base = lds0 + buf * STAGE + wave * NI * 1024;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      dma16(__builtin_amdgcn_readfirstlane(base + j * 1024), ps[j]);
+      ps[j] += st[j];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  int aoff_h[TM], aoff_l[TM], boff_h[TN], boff_l[TN];
+  const int hsel = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int row = group * 128 + wm * 64 + i * 32 + (lane & 31), f = (row >> 2) & 3;
+    aoff_h[i] = row * ROWB + ((hsel ^ f) << 4);
+    aoff_l[i] = row * ROWB + (((2 + hsel) ^ f) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int row = wn * 32 * TN + j * 32 + (lane & 31), f = (row >> 2) & 3;
+    boff_h[j] = BM * ROWB + row * ROWB + ((hsel ^ f) << 4);
+    boff_l[j] = BM * ROWB + row * ROWB + (((2 + hsel) ^ f) << 4);
+  }
+  h8 xh[TM], xl[TM], wh[TN], wl[TN];
+  auto read = [&](int buf) {
+    const unsigned char* sp = smem_raw + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      xh[i] = *reinterpret_cast<const h8*>(sp + aoff_h[i]);
+      xl[i] = *reinterpret_cast<const h8*>(sp + aoff_l[i]);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      wh[j] = *reinterpret_cast<const h8*>(sp + boff_h[j]);
+      wl[j] = *reinterpret_cast<const h8*>(sp + boff_l[j]);
+    }
+  };
+  auto mfma = [&]() {
+    __builtin_amdgcn_s_setprio(1);            // the wave feeding the matrix pipe goes first; its partner only moves data
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[j], xh[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], xl[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], xh[i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // prologue: stages 0 .. DIST-1 in flight, all landed before anyone reads
+#pragma unroll
+  for (int d = 0; d < DIST; ++d)
+    if (d < nk) issue(d);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // ring: stage t lives in buffer t % NBUF
+  int bcur = 0, bnext = 1, bfill = DIST % NBUF;
+  auto advance = [&]() {
+    bcur = bcur == NBUF - 1 ? 0 : bcur + 1;
+    bnext = bnext == NBUF - 1 ? 0 : bnext + 1;
+    bfill = bfill == NBUF - 1 ? 0 : bfill + 1;
+  };
+  // slot boundary: nothing (not even an MFMA, which touches no memory) may be scheduled across it
+#define WD_SLOT_BARRIER()                 \
+  __builtin_amdgcn_sched_barrier(0);      \
+  __syncthreads();                        \
+  __builtin_amdgcn_sched_barrier(0)
+  // Before the barrier that ends slot 2s every wave's share of stage s+1 must have landed (group 0
+  // reads it in slot 2s+1); DMA groups issued after it may stay in flight.
+  if (group == 0) {
+    read(0);                                   // fragments of stage 0 for the first MFMA slot
+    for (int s = 0; s < nk; ++s) {
+      mfma();                                  // slot 2s
+      __builtin_amdgcn_sched_barrier(0);
+      {                                        // issued so far: up to stage s+DIST-1
+        const int last = s + DIST - 1 < nk - 1 ? s + DIST - 1 : nk - 1;
+        wait_dma_groups<DIST - 2, NI>(last - (s + 1));
+      }
+      WD_SLOT_BARRIER();
+      if (s + DIST < nk) issue(bfill);         // slot 2s+1
+      if (s + 1 < nk) read(bnext);
+      WD_SLOT_BARRIER();
+      advance();
+    }
+  } else {
+    for (int s = 0; s < nk; ++s) {
+      if (s + DIST < nk) issue(bfill);         // slot 2s
+      read(bcur);
+      __builtin_amdgcn_sched_barrier(0);
+      {                                        // issued so far: up to stage s+DIST
+        const int last = s + DIST < nk - 1 ? s + DIST : nk - 1;
+        wait_dma_groups<DIST - 1, NI>(last - (s + 1));
+      }
+      WD_SLOT_BARRIER();
+      mfma();                                  // slot 2s+1
+      WD_SLOT_BARRIER();
+      advance();
+    }
+  }
+#undef WD_SLOT_BARRIER
+  __syncthreads();
+
+  const EpiVec ev{vec_c, vec_res, vec_bias, unscale};
+  const int mw = m0 + group * 128 + wm * 64, nw = n0 + wn * 32 * TN;
+  float* patch = reinterpret_cast<float*>(smem_raw) + wave * 32 * EPI_LDT;
+  static_assert(NBUF * STAGE >= 8 * 32 * EPI_LDT * 4, "operand LDS must hold one patch per wave");
+  if (VAR & SVAR_CSPLIT) {
+    switch (p.act) {
+      case WD_ACT_RELU: EpiCsplitWalk<0, TM, TN, WD_ACT_RELU>::run(p, ev, mw, nw, lane, acc, patch); break;
+      case WD_ACT_SILU: EpiCsplitWalk<0, TM, TN, WD_ACT_SILU>::run(p, ev, mw, nw, lane, acc, patch); break;
+      case WD_ACT_GELU: EpiCsplitWalk<0, TM, TN, WD_ACT_GELU>::run(p, ev, mw, nw, lane, acc, patch); break;
+      default: EpiCsplitWalk<0, TM, TN, WD_ACT_NONE>::run(p, ev, mw, nw, lane, acc, patch); break;
+    }
+  } else {
+    switch (p.act) {
+      case WD_ACT_RELU: split_epilogue_lds<TM, TN, WD_ACT_RELU, false>(p, ev, mw, nw, lane, acc, patch); break;
+      case WD_ACT_SILU: split_epilogue_lds<TM, TN, WD_ACT_SILU, false>(p, ev, mw, nw, lane, acc, patch); break;
+      case WD_ACT_GELU: split_epilogue_lds<TM, TN, WD_ACT_GELU, false>(p, ev, mw, nw, lane, acc, patch); break;
+      default: split_epilogue_lds<TM, TN, WD_ACT_NONE, false>(p, ev, mw, nw, lane, acc, patch); break;
+    }
+  }
+}
+
+template <int VAR, int NBUF, int TN>
+int launch_pingpong(const WdConvGemm& p, const void* wsp, float unscale, hipStream_t st) {
+  constexpr int BN = 64 * TN, LDS = NBUF * (256 + BN) * 64;
+  const int nbm = (p.m + 255) / 256, nbn = (p.n + BN - 1) / BN;
+  const long long nblk = (long long)nbm * nbn;
+  if (nblk <= 0 || nblk > 0x7fffffffLL) return WD_ERR_BAD_ARG;
+  const int k16 = (p.k + 15) / 16 * 16;
+  const int vec_c = (p.ldc % 4 == 0) && wd_aligned16(p.c);
+  const int vec_res = p.res ? ((p.ldres % 4 == 0) && wd_aligned16(p.res)) : 0;
+  const int vec_bias = p.bias ? wd_aligned16(p.bias) : 0;
+  static const float* zero = nullptr;
+  if (!zero) {
+    void* zp = nullptr;
+    if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero4)) != hipSuccess || !zp) return WD_ERR_LAUNCH;
+    zero = static_cast<const float*>(zp);
+  }
+  auto k = split_gemm_pingpong_kernel<VAR, NBUF, TN>;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
+        hipSuccess) return WD_ERR_LAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(512), LDS, st, p, static_cast<const unsigned char*>(wsp), zero, k16,
+                     unscale, nbn, vec_c, vec_res, vec_bias);
+  return wd_launch_status();
+}
 
 // plain layer, rows output, no per-level affine: what the direct-to-LDS kernel's epilogue covers
 bool glds_ok(const WdConvGemm& p, int bk) {
@@ -208,6 +441,14 @@ int wd_launch_presplit(const WdConvGemm& p, const void* w, float unscale, int cf
   const bool csplit = (flags & WD_SPLIT_C) != 0;
   if (!(flags & WD_SPLIT_A)) return WD_ERR_UNSUPPORTED;            // C-only split: not needed by any layer yet
   if (p.k % 8 || p.cin % 8 || p.lda % 8) return WD_ERR_BAD_ARG;
+  if (cfg == 63) {                       // direct-to-LDS, ping-pong wave groups, 256 x 128 tiles
+    if (!glds_ok(p, 16)) return WD_ERR_UNSUPPORTED;
+    if (csplit) {
+      if (p.res || p.n % 8 || p.ldc % 8 || (p.bias && !wd_aligned16(p.bias)) || !wd_aligned16(p.c)) return WD_ERR_BAD_ARG;
+      return launch_pingpong<SVAR_CSPLIT, 3, 2>(p, w, unscale, st);
+    }
+    return launch_pingpong<0, 3, 2>(p, w, unscale, st);
+  }
   if (cfg == 60) {                       // direct-to-LDS kernel
     if (!glds_ok(p, 16)) return WD_ERR_UNSUPPORTED;
     if (csplit) {
