@@ -26,18 +26,6 @@ SHAPES = {
     "conv3 512->256 @20 silu": dict(conv=(32, 20, 20, 512, 256)),
 }
 GROUPS = {"big": [3, 22, 13, 3, 22], "sim": [10, 10], "conv": [3, 13]}
-import ctypes
-_old_path = os.path.join(os.path.dirname(L.LIB_PATH), "libwedetect_old_gemm.so")
-OLD = ctypes.CDLL(_old_path) if os.path.exists(_old_path) else None
-if OLD is not None:
-    OLD.wd_conv_gemm.argtypes = [ctypes.POINTER(L.ConvGemm), ctypes.c_void_p]
-    _orig_check = L.LIB.wd_conv_gemm_tuned
-
-    class _Shim:
-        """route tuned_cfg="old" to the round-1 first-cut kernel kept for A/B"""
-    def _old_call(p, cfg, stream):
-        return OLD.wd_conv_gemm(p, stream)
-
 reps = int(os.environ.get("REPS", "8"))
 only = os.environ.get("ONLY")
 for name, sh in SHAPES.items():
@@ -62,16 +50,7 @@ for name, sh in SHAPES.items():
     if sh.get("sim"):
         kw.update(sigmoid=True, seg=(8400, 6400, 8000, (0.7, 0.58, 0.82), (-2.6, -2.2, -1.9)))
     def run(cfg, c):
-        if cfg == "old":
-            if OLD is None:
-                raise RuntimeError("old lib not present")
-            saved = L.LIB.wd_conv_gemm
-            L.LIB.__dict__["wd_conv_gemm"] = OLD.wd_conv_gemm
-            try:
-                L.conv_gemm(a, w, b, c, **kw)
-            finally:
-                L.LIB.__dict__["wd_conv_gemm"] = saved
-        elif cfg is None:
+        if cfg is None:
             L.conv_gemm(a, w, b, c, **kw)
         else:
             L.conv_gemm(a, w, b, c, tuned_cfg=cfg, **kw)
