@@ -147,6 +147,15 @@ int wd_letterbox_u8(const uint8_t* src, int32_t h, int32_t w, const int32_t* bou
                     uint8_t* dst, int32_t dst_h, int32_t dst_w, int32_t new_w, int32_t new_h, int32_t left, int32_t top,
                     int32_t fill_r, int32_t fill_g, int32_t fill_b, void* stream);
 
+/* wd_retrieval_max in fp16x3 arithmetic (2-3x the fp32 kernel at large banks): both operands as fp16
+ * (hi, lo) groups from wd_split_weights — e_split: the [n_img * rows_per_img, dim] region rows with
+ * scale 1, t_split: the [n_cls, dim] bank with a power-of-two scale = 1 / t_unscale.  Same result
+ * definition as wd_retrieval_max (retrieval_metric.py:367-377); out is zeroed, then max-reduced with
+ * atomics (deterministic: max is order independent).  dim % 16 == 0. */
+int wd_retrieval_max_split(const void* e_split, const void* t_split, float t_unscale, const float* scale,
+                           const float* bias, const int32_t* count, float* out, int32_t n_img, int32_t rows_per_img,
+                           int32_t n_cls, int32_t dim, void* stream);
+
 /* wd_layernorm_rows with the output written as fp16 (hi, lo) groups (see WD_SPLIT_A); c % 8 == 0. */
 int wd_layernorm_rows_split(const float* x, void* y, const float* gamma, const float* beta, int64_t rows, int32_t c,
                             int32_t ldx, int32_t ldy, float eps, void* stream);

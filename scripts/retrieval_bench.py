@@ -22,3 +22,14 @@ for k in (125_000, 1_000_000):
     fl = 2.0 * n_img * rows * dim * k
     print(f"retrieval_max {n_img} img x {rows} regions x {k} classes: {ms:.2f} ms  {fl/ms/1e9:.1f} TF  "
           f"({n_img/ms*1e3:.1f} img/s; bank read {k*dim*4/1e9:.2f} GB x {n_img} images)", flush=True)
+    ts = L.split_weights(t)
+    out2 = torch.empty(n_img, k, device="cuda")
+    for _ in range(2):
+        L.retrieval_max_split(e, ts, scale, bias, cnt, out2, n_img, rows, k, dim)
+    s.record()
+    for _ in range(reps):
+        L.retrieval_max_split(e, ts, scale, bias, cnt, out2, n_img, rows, k, dim)
+    f.record(); torch.cuda.synchronize()
+    ms = s.elapsed_time(f) / reps
+    print(f"retrieval_max_split (fp16x3) same problem: {ms:.2f} ms  {fl/ms/1e9:.1f} TF  ({n_img/ms*1e3:.1f} img/s)  "
+          f"max|d vs fp32| {float((out2 - out).abs().max()):.2e}", flush=True)

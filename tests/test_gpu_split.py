@@ -258,3 +258,32 @@ def test_presplit_flags_are_validated():
     with pytest.raises(L.WedetectHipError):                       # LayerNorm split output needs c % 8 == 0
         L.layernorm_rows(x, torch.empty_like(x), torch.ones(12, device="cuda"), torch.zeros(12, device="cuda"), 8, 12,
                          split=True)
+
+
+def test_retrieval_max_split_matches_fp32_kernel_and_shards():
+    """fp16x3 retrieval (ping-pong GEMM + segmented max + atomic max) == the fp32 kernel within 2e-6 on
+    ragged counts (rows of one MFMA tile belonging to two images), and class-sharded == whole bank bit for bit."""
+    from wedetect_amd import lib as L
+    from wedetect_amd.parallel import shard_range
+    n_img, rows, k, dim = 5, 300, 10_000, 768
+    g = torch.Generator(device="cuda").manual_seed(7)
+    e = torch.randn(n_img, rows, dim, device="cuda", generator=g) * 1.4
+    t = torch.nn.functional.normalize(torch.randn(k, dim, device="cuda", generator=g), dim=-1)
+    scale = torch.randn(n_img, rows, device="cuda", generator=g) * 0.1 - 0.35
+    bias = torch.randn(n_img, rows, device="cuda", generator=g) * 0.2 - 2.6
+    cnt = torch.tensor([300, 211, 0, 1, 299], dtype=torch.int32, device="cuda")
+    ref = torch.empty(n_img, k, device="cuda")
+    L.retrieval_max(e, t, scale, bias, cnt, ref, n_img, rows, k, dim)
+    out = torch.full((n_img, k), -1.0, device="cuda")
+    L.retrieval_max_split(e, L.split_weights(t), scale, bias, cnt, out, n_img, rows, k, dim)
+    assert float(out[2].abs().max()) == 0.0                       # an image without regions scores 0 everywhere
+    assert_close("retrieval fp16x3 vs fp32", out, ref, 2e-6)
+    parts = []
+    for r in range(4):
+        sr = shard_range(k, 4, r)
+        o = torch.empty(n_img, len(sr), device="cuda")
+        L.retrieval_max_split(e, L.split_weights(t[sr.start:sr.stop].contiguous()), scale, bias, cnt, o, n_img, rows,
+                              len(sr), dim)
+        parts.append(o)
+    # every shard picks its own power-of-two weight scale: exact, so the shards reproduce the whole-bank bits
+    assert torch.equal(torch.cat(parts, dim=1), out)

@@ -225,10 +225,62 @@ __device__ __forceinline__ void wait_dma_groups(int groups_in_flight) {
   else { if (NI == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
 }
 
+// Retrieval epilogue of the ping-pong kernel (SVAR_RETRMAX): the GEMM rows are the region rows of all
+// images back to back ([n_img * rows_per_img, dim]); instead of storing logits the tile computes
+// sigmoid(logit * exp(scale[row]) + bias[row]) for the valid rows and folds it into
+// out[image][class] with a max: segmented over the lanes of a wave (rows of a 32-row tile may belong
+// to two images), then one atomicMax per (segment, class) — order-independent, hence deterministic.
+constexpr int SVAR_RETRMAX = 4096;
+struct RetrArgs {
+  const float* scale;
+  const float* bias;
+  const int* count;
+  float* out;
+  int rows_per_img, n_cls;
+};
+
+template <int TM, int TN>
+__device__ __forceinline__ void retrieval_epilogue(const WdConvGemm& p, const RetrArgs& ra, float unscale, int mw, int nw,
+                                                   int lane, const f32x16 (&acc)[TM][TN]) {
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = mw + i * 32 + (lane & 31);
+    const bool in = m < p.m;
+    const int img = in ? m / ra.rows_per_img : -1;
+    const bool valid = in && (m - img * ra.rows_per_img) < ra.count[img];
+    const float es = valid ? expf(ra.scale[m]) * unscale : 0.f;
+    const float b = valid ? ra.bias[m] : 0.f;
+    const int prev_img = __shfl_up(img, 1, 32);
+    const bool head = in && ((lane & 31) == 0 || prev_img != img);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = valid ? wd_sigmoid(fmaf(acc[i][j][r], es, b)) : 0.f;     // sigmoid > 0: 0 is the identity of max
+        // segmented max towards the first lane of each image's run of rows (runs are contiguous in lane order)
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) {
+          const float o = __shfl_down(v, d, 32);
+          const int oi = __shfl_down(img, d, 32);
+          if ((lane & 31) + d < 32 && oi == img) v = fmaxf(v, o);
+        }
+        const int n = nw + j * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+        if (head && n < ra.n_cls)
+          atomicMax(reinterpret_cast<unsigned int*>(ra.out + (size_t)img * ra.n_cls + n), __float_as_uint(v));
+      }
+    }
+  }
+}
+
+__global__ void zero_f32_kernel(float* __restrict__ x, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = 0.f;
+}
+
 template <int VAR, int NBUF, int TN>
 __global__ void __launch_bounds__(512, (NBUF == 3 && TN == 2) ? 4 : 2)
 split_gemm_pingpong_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, const float* __restrict__ zero,
-                           int k16, float unscale, int nbn, int vec_c, int vec_res, int vec_bias) {
+                           int k16, float unscale, int nbn, int vec_c, int vec_res, int vec_bias, const RetrArgs ra) {
   constexpr int TM = 2, BM = 256, BN = 64 * TN, BK = 16, ROWB = 64, DIST = NBUF - 1;   // DMA runs DIST stages ahead
   constexpr int STAGE = (BM + BN) * ROWB, NI = (BM + BN) / 16 / 8;   // one-KB DMA instructions per stage and wave: 3 or 4
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -379,6 +431,10 @@ split_gemm_pingpong_kernel(const WdConvGemm p, const unsigned char* __restrict__
 #undef WD_SLOT_BARRIER
   __syncthreads();
 
+  if (VAR & SVAR_RETRMAX) {
+    retrieval_epilogue<TM, TN>(p, ra, unscale, m0 + group * 128 + wm * 64, n0 + wn * 32 * TN, lane, acc);
+    return;
+  }
   const EpiVec ev{vec_c, vec_res, vec_bias, unscale};
   const int mw = m0 + group * 128 + wm * 64, nw = n0 + wn * 32 * TN;
   float* patch = reinterpret_cast<float*>(smem_raw) + wave * 32 * EPI_LDT;
@@ -401,7 +457,7 @@ split_gemm_pingpong_kernel(const WdConvGemm p, const unsigned char* __restrict__
 }
 
 template <int VAR, int NBUF, int TN>
-int launch_pingpong(const WdConvGemm& p, const void* wsp, float unscale, hipStream_t st) {
+int launch_pingpong(const WdConvGemm& p, const void* wsp, float unscale, hipStream_t st, const RetrArgs& ra = RetrArgs{}) {
   constexpr int BN = 64 * TN, LDS = NBUF * (256 + BN) * 64;
   const int nbm = (p.m + 255) / 256, nbn = (p.n + BN - 1) / BN;
   const long long nblk = (long long)nbm * nbn;
@@ -424,7 +480,7 @@ int launch_pingpong(const WdConvGemm& p, const void* wsp, float unscale, hipStre
     attr = true;
   }
   hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(512), LDS, st, p, static_cast<const unsigned char*>(wsp), zero, k16,
-                     unscale, nbn, vec_c, vec_res, vec_bias);
+                     unscale, nbn, vec_c, vec_res, vec_bias, ra);
   return wd_launch_status();
 }
 
@@ -474,4 +530,28 @@ int wd_launch_presplit(const WdConvGemm& p, const void* w, float unscale, int cf
     case 55: return launch_split<2, 2, 2, 2, 32, VA_PF2, 1>(p, w, unscale, st);
     default: return WD_ERR_UNSUPPORTED;
   }
+}
+
+// wd_retrieval_max with fp16x3 arithmetic: e_split = region embeddings [n_img * rows_per_img, dim] and
+// t_split = text bank [n_cls, dim], both as fp16 hi/lo groups (wd_split_weights; the bank pre-scaled
+// by 1 / t_unscale).  out is zeroed here, then filled by atomic max.
+extern "C" int wd_retrieval_max_split(const void* e_split, const void* t_split, float t_unscale, const float* scale,
+                                      const float* bias, const int32_t* count, float* out, int32_t n_img,
+                                      int32_t rows_per_img, int32_t n_cls, int32_t dim, void* stream) {
+  if (!e_split || !t_split || !scale || !bias || !count || !out) return WD_ERR_BAD_ARG;
+  if (n_img <= 0 || n_cls <= 0 || rows_per_img <= 0 || dim <= 0 || dim % 16 || !(t_unscale > 0.f)) return WD_ERR_BAD_ARG;
+  if ((long long)n_img * rows_per_img > 0x7fffffffLL) return WD_ERR_BAD_ARG;
+  if (!wd_aligned16(e_split) || !wd_aligned16(t_split)) return WD_ERR_BAD_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long long total = (long long)n_img * n_cls;
+  hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, out, total);
+  WdConvGemm p{};
+  p.a = static_cast<const float*>(e_split);
+  p.c = out;
+  p.batch = 1; p.hin = 1; p.win = n_img * rows_per_img; p.cin = dim; p.lda = dim;
+  p.kh = p.kw = p.stride = 1; p.hout = 1; p.wout = p.win;
+  p.m = n_img * rows_per_img; p.n = n_cls; p.k = dim; p.ldc = n_cls;
+  p.out_scale = 1.0f;
+  const RetrArgs ra{scale, bias, count, out, rows_per_img, n_cls};
+  return launch_pingpong<SVAR_RETRMAX, 3, 2>(p, t_split, t_unscale, st, ra);
 }

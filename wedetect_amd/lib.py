@@ -25,7 +25,7 @@ EXPORTS = (
     "wd_abi_version", "wd_strerror", "wd_sizeof_conv_gemm", "wd_conv_gemm", "wd_conv_gemm_tuned", "wd_conv_gemm_config", "wd_stem_patchify", "wd_dwconv7",
     "wd_layernorm_rows", "wd_l2norm_rows", "wd_dfl_decode", "wd_topk_workspace_bytes", "wd_topk_capacity",
     "wd_topk_candidates", "wd_nms_gather", "wd_retrieval_max",
-    "wd_split_weights_bytes", "wd_split_weights", "wd_conv_gemm_split", "wd_conv_gemm_split_config", "wd_layernorm_rows_split", "wd_letterbox_u8",
+    "wd_split_weights_bytes", "wd_split_weights", "wd_conv_gemm_split", "wd_conv_gemm_split_config", "wd_layernorm_rows_split", "wd_letterbox_u8", "wd_retrieval_max_split",
 )
 
 
@@ -89,6 +89,7 @@ def _load():
     lib.wd_split_weights.argtypes = [vp, i32, i32, f32, vp, vp]
     lib.wd_conv_gemm_split.argtypes = [C.POINTER(ConvGemm), vp, f32, i32, i32, vp]
     lib.wd_layernorm_rows_split.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, f32, vp]
+    lib.wd_retrieval_max_split.argtypes = [vp, vp, f32, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.wd_letterbox_u8.argtypes = [vp, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.wd_conv_gemm_split_config.restype = C.c_char_p
     lib.wd_conv_gemm_split_config.argtypes = [i32, i32, i32, i32]
@@ -233,3 +234,14 @@ def nms_gather(cand_idx, cand_score, cand_count, cand_stride, boxes, n_anchor, k
 def retrieval_max(e, t, scale, bias, count, out, n_img, rows_per_img, n_cls, dim) -> None:
     check(LIB.wd_retrieval_max(_p(e), _p(t), _p(scale), _p(bias), _p(count), _p(out), n_img, rows_per_img, n_cls, dim,
                                stream_ptr()), "wd_retrieval_max")
+
+
+def retrieval_max_split(e, t_split, scale, bias, count, out, n_img, rows_per_img, n_cls, dim) -> None:
+    """fp16x3 variant of :func:`retrieval_max`.  ``e``: fp32 region rows [n_img, rows, dim] (split here, scale
+    1: a few MB); ``t_split``: ``split_weights(bank)`` prepared once for the (possibly class-sharded) bank."""
+    _f32(e, "e")
+    rows = e.reshape(-1, dim).contiguous()
+    es = torch.empty(LIB.wd_split_weights_bytes(rows.shape[0], dim), dtype=torch.uint8, device=e.device)
+    check(LIB.wd_split_weights(_p(rows), rows.shape[0], dim, 1.0, _p(es), stream_ptr()), "wd_split_weights")
+    check(LIB.wd_retrieval_max_split(_p(es), _p(t_split[0]), float(t_split[1]), _p(scale), _p(bias), _p(count), _p(out),
+                                     n_img, rows_per_img, n_cls, dim, stream_ptr()), "wd_retrieval_max_split")
