@@ -23,6 +23,10 @@ SHAPES = {
     "conv3 256->256 @80 silu": dict(conv=(32, 80, 80, 256, 256)),
     "conv3 128->128 @40 silu": dict(conv=(32, 40, 40, 128, 128)),
     "conv3 256->256 @20 silu": dict(conv=(32, 20, 20, 256, 256)),
+    "small conv3 512->256 @20 silu": dict(conv=(32, 20, 20, 512, 256)),
+    "small conv3 256->128 @40 silu": dict(conv=(32, 40, 40, 256, 128)),
+    "small plain 12800x256x768 silu": dict(m=12800, n=256, k=768, act=L.ACT_SILU),
+    "small plain 51200x128x384 silu": dict(m=51200, n=128, k=384, act=L.ACT_SILU),
     "n64 conv3 64->64 @80 silu": dict(conv=(32, 80, 80, 64, 64)),
     "n64 conv3 128->64 @80 silu": dict(conv=(32, 80, 80, 128, 64)),
     "n64 plain 204800x64x128 silu": dict(m=204800, n=64, k=128, act=L.ACT_SILU),
