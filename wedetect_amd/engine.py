@@ -119,10 +119,13 @@ class ImageTower:
         self.topk_ws = self.topk_ws[off:off + nbytes]
 
     # ------------------------------------------------------------------ helpers
-    def _gemm(self, a, w: str, b: Optional[str], c, **kw):
-        """One dense layer with packed weight ``w`` / bias ``b`` in the tower's precision."""
+    def _gemm(self, a, w: str, b: Optional[str], c, *, fp32: bool = False, **kw):
+        """One dense layer with packed weight ``w`` / bias ``b`` in the tower's precision.
+        ``fp32=True`` pins the layer to the fp32 MFMA kernel: the neck layers that read the ConvNeXt
+        residual streams c1..c4 directly — the only GEMM inputs that are neither LayerNorm outputs nor
+        activations of a BN-folded conv, hence not bounded by construction (fp16 halves overflow at 65504)."""
         ws = None
-        if self.precision == "fp16x3":
+        if self.precision == "fp16x3" and not fp32:
             ws = self.Ws.get(w)
             if ws is None:                      # first use: split once, keep resident
                 wt = self.P[w]
@@ -206,9 +209,9 @@ class ImageTower:
         self._gemm(top, name + ".up.w", name + ".up.b", cat, hin=ht, win=wt, cin=cout, lda=ld_top, n=4 * cout,
                    ldc=3 * cout, out_mode=L.OUT_DECONV2X2)
         self._conv(mid, name + ".cv1.w", name + ".cv1.b", cat[:, cout:], hin=hm, win=wm, cin=c_mid, lda=c_mid, n=cout,
-                   ldc=3 * cout, act=L.ACT_RELU)
+                   ldc=3 * cout, act=L.ACT_RELU, fp32=True)          # mid / low are backbone residual streams
         self._conv(low, name + ".cv2.w", name + ".cv2.b", tbuf, hin=hl, win=wl, cin=c_low, lda=c_low, n=cout, ldc=cout,
-                   act=L.ACT_RELU)
+                   act=L.ACT_RELU, fp32=True)
         self._conv(tbuf, name + ".downsample.w", name + ".downsample.b", cat[:, 2 * cout:], hin=hl, win=wl, cin=cout,
                    lda=cout, n=cout, ldc=3 * cout, k=3, stride=2, act=L.ACT_RELU)
         self._conv(cat, name + ".cv3.w", name + ".cv3.b", out, hin=hm, win=wm, cin=3 * cout, lda=3 * cout, n=cout,
@@ -223,7 +226,7 @@ class ImageTower:
         ld3 = nc["d2"] + nc["p4r"]
         fpn_out0 = self.cat_n4[:, nc["d1"]:]
         self._conv(c4, "reduce_layer0.w", "reduce_layer0.b", fpn_out0, hin=hw5[0], win=hw5[1], cin=nc["c4"],
-                   lda=nc["c4"], n=nc["p5r"], ldc=ld4, act=L.ACT_RELU)
+                   lda=nc["c4"], n=nc["p5r"], ldc=ld4, act=L.ACT_RELU, fp32=True)
         self._bifusion("Bifusion0", fpn_out0, ld4, hw5, c3, nc["c3"], hw4, c2, nc["c2"], hw3, self.cat_b0, self.b0_t,
                        self.f0, nc["p5r"])
         self._bepc3("Rep_p4", self.f0, nc["p5r"], nc["p5r"], hw4, self.f_out0, nc["p5r"])
