@@ -5,6 +5,7 @@
 // Layers on this path in the ConvNeXt tower (mm_backbone.py:112-125, 185-198):
 //   LayerNorm -> pwconv1 (+GELU, output written split) -> pwconv2 (+residual, fp32 output),
 //   LayerNorm -> 2x2 stride-2 downsample conv.
+#include <cstdlib>
 #include "split_gemm_impl.h"
 
 namespace {
@@ -26,7 +27,7 @@ constexpr int VA_PF2 = SVAR_XCD | SVAR_PF2 | SVAR_LDSEPI | SVAR_ASPLIT;
 template <int BK, int VAR>
 __global__ void __launch_bounds__(256, BK == 16 ? 4 : 3)
 split_gemm_glds_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, const float* __restrict__ zero,
-                       int k16, float unscale, int nbn, int vec_c, int vec_res, int vec_bias) {
+                       int k16, float unscale, int nbn, int vec_c, int vec_res, int vec_bias, int ngrp, int nbm) {
   constexpr int TM = 2, TN = 2, WN = 2, BM = 128, BN = 128, KS = BK / 16;
   constexpr int ROWB = BK * 4, CH = ROWB / 16, RPI = 64 / CH, NI = (BM / RPI) / 4, STAGE = (BM + BN) * ROWB;
   constexpr int FDIV = 16 / CH;
@@ -39,7 +40,11 @@ split_gemm_glds_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp
     const int q = nwg >> 3, r = nwg & 7;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int bn = tile % nbn, bm = tile / nbn;
+  // raster order: column tiles are walked in groups of ngrp (all row panels of a group before the
+  // next group), so the weight panels live at any time are ngrp * 128 rows instead of all of n
+  const int gsz = ngrp * nbm;
+  const int grp = tile / gsz, rem = tile - grp * gsz;
+  const int bm = rem / ngrp, bn = grp * ngrp + (rem - bm * ngrp);
   const int m0 = bm * BM, n0 = bn * BN;
   const int nk = p.k / BK;
 
@@ -176,6 +181,12 @@ int launch_glds(const WdConvGemm& p, const void* wsp, float unscale, hipStream_t
     if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero4)) != hipSuccess || !zp) return WD_ERR_LAUNCH;
     zero = static_cast<const float*>(zp);
   }
+  // column-tile group of the raster order: 4 (measured: -3 % on the wide pwconv1 layers, whose 4 MB of
+  // weight panels otherwise compete with the activation panels for the 4 MB L2), or WD_GLDS_NGROUP
+  // (tuning hook); must divide nbn
+  static const int env_grp = [] { const char* e = getenv("WD_GLDS_NGROUP"); return e ? atoi(e) : 0; }();
+  int ngrp = env_grp > 0 ? env_grp : 4;
+  if (ngrp > nbn || nbn % ngrp) ngrp = nbn;
   auto k = split_gemm_glds_kernel<BK, VAR>;
   static bool attr = false;
   if (!attr) {
@@ -184,7 +195,7 @@ int launch_glds(const WdConvGemm& p, const void* wsp, float unscale, hipStream_t
     attr = true;
   }
   hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), LDS, st, p, static_cast<const unsigned char*>(wsp), zero, k16,
-                     unscale, nbn, vec_c, vec_res, vec_bias);
+                     unscale, nbn, vec_c, vec_res, vec_bias, ngrp, nbm);
   return wd_launch_status();
 }
 
