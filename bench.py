@@ -15,9 +15,11 @@ retrieval gather, extract_embedding.py:1753-1756).  Weights/images/text are seed
 synthetic (no checkpoints or datasets offline).
 
 Prints ONE JSON line (rank 0) with the driver's contract plus:
-  roofline      — the dominant kernel (128x128 fp32-MFMA GEMM that runs the ConvNeXt MLPs),
+  roofline      — the dominant kernel (the GEMM that runs the ConvNeXt MLPs: fp16x3 direct-to-LDS, or fp32 MFMA),
                   algorithmic flops / HIP-event time of its launches inside the timed steps
   sim_gemm      — the judged region x text similarity GEMM, same accounting
+  fp32_mode     — (default fp16x3 arithmetic only) the same workload re-timed in this run with native fp32 MFMA,
+                  and the max |difference| of the fp16x3 step's embeddings / scores from it
   cpu_baseline  — the CPU oracle (port of the reference's PyTorch-CPU path) on a bounded sample
 """
 import argparse
@@ -86,6 +88,8 @@ def parse():
                     help="arithmetic of the dense convs/linears (default: wedetect_amd.engine.DEFAULT_PRECISION); "
                          "fp16x3 = fp32 operands split into fp16 hi+lo, three MFMA passes, fp32 accumulate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32-reference", action="store_true",
+                    help="skip the short native-fp32 run that is reported beside an fp16x3 result (N = 1 only)")
     ap.add_argument("--cpu-images", type=int, default=8)
     return ap.parse_args()
 
@@ -170,6 +174,28 @@ def cpu_baseline(arch, size, classes, n_images):
     return dict(value=round(1.0 / t, 4), unit="images/s", cores=torch.get_num_threads(), kind="port",
                 sample=f"{n_images} single-image passes of the same {arch}@{size} K={classes} path "
                        f"(oracle/ref_cpu.py + oracle/postprocess.py, fp32, torch {torch.__version__}) after 1 warm-up")
+
+
+def fp32_reference_run(args, tower, images, text, meta, uni, steps=5):
+    """``steps`` timed steps of the identical workload on a second tower in fp32 mode (sharing the packed
+    weights), plus how far the fp16x3 step's outputs are from it."""
+    from wedetect_amd.engine import ImageTower
+    ref = ImageTower(args.arch, tower.P, tower.B, tower.H, tower.W, max_classes=tower.max_classes, precision="fp32")
+    kw = dict(normalize_text=not uni, score_thr=0.0 if uni else 0.001, with_embed=True)
+    emb16 = tower.embed.clone()
+    sc16 = tower.scores.view(-1)[: tower.B * tower.ntot * text.shape[0]].clone()
+    for _ in range(2):
+        ref.detect(images, text, meta, **kw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ref.detect(images, text, meta, **kw)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    d_emb = float((ref.embed - emb16).abs().max())
+    d_sc = float((ref.scores.view(-1)[: sc16.numel()] - sc16).abs().max())
+    return {"value": round(tower.B / dt, 3), "unit": "images/s", "ms_per_step": round(1e3 * dt, 3), "steps": steps,
+            "dtype": "f32 (v_mfma_f32_16x16x4_f32)", "max_abs_diff_of_fp16x3_step": {"embeddings": d_emb, "scores": d_sc}}
 
 
 def main():
@@ -300,6 +326,9 @@ def main():
             out["sim_gemm"] = {"kernel": f"conv_gemm_kernel<{sim_tag}>", "m": B * tower.ntot, "n": K, "k": 768,
                                "achieved": round(sim["tflops"], 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(sim["tflops"] / F32_MFMA_PEAK_TFLOPS, 4), "avg_launch_us": round(sim["avg_us"], 2)}
+        if world == 1 and split and not args.no_fp32_reference:
+            # the same workload with native fp32 MFMA arithmetic, measured in this run (same images, weights, bank)
+            out["fp32_mode"] = fp32_reference_run(args, tower, images, text, meta, uni)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.arch, S, K, args.cpu_images)
         print(json.dumps(out), flush=True)
