@@ -206,6 +206,10 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE {world}")
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    # dry-run hooks for a single-GPU box: WEDETECT_BENCH_SHARE_GPU=1 puts every rank on device 0 and
+    # WEDETECT_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device)
+    if os.environ.get("WEDETECT_BENCH_SHARE_GPU") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
@@ -215,7 +219,7 @@ def main():
         # (next to the one JSON line this script owes the driver): keep warnings, drop the banner
         if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
             os.environ["NCCL_DEBUG"] = "WARN"
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend=os.environ.get("WEDETECT_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
 
     from wedetect_amd import lib as L
     from wedetect_amd import weights as W
