@@ -156,6 +156,19 @@ int wd_retrieval_max_split(const void* e_split, const void* t_split, float t_uns
                            const float* bias, const int32_t* count, float* out, int32_t n_img, int32_t rows_per_img,
                            int32_t n_cls, int32_t dim, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Text tower pieces (mm_backbone.py:341-390, HF XLMRobertaModel): the embedding
+ * sum before the embedding LayerNorm, and self-attention for short sequences.  Everything else of
+ * the encoder is wd_conv_gemm(_split) / wd_layernorm_rows / wd_l2norm_rows.
+ *   wd_text_embed: out[t] = word[ids[t]] + pos[pos_ids[t]] + type0                 (dim % 4 == 0)
+ *   wd_attention_small: qkv rows [n_seq * seq_len, >= 3 * heads * head_dim] = (Q | K | V), mask
+ *     [n_seq, seq_len] (0 = padded key); out rows [n_seq * seq_len, heads * head_dim] =
+ *     softmax(Q K^T / sqrt(head_dim)) V per head.  seq_len <= 64, head_dim in {16, 32, 64}. */
+int wd_text_embed(const int32_t* ids, const int32_t* pos_ids, const float* word, const float* pos, const float* type0,
+                  float* out, int64_t n_tok, int32_t dim, void* stream);
+int wd_attention_small(const float* qkv, const int32_t* mask, float* out, int32_t n_seq, int32_t seq_len, int32_t heads,
+                       int32_t head_dim, int32_t ld_qkv, int32_t ld_out, void* stream);
+
 /* wd_layernorm_rows with the output written as fp16 (hi, lo) groups (see WD_SPLIT_A); c % 8 == 0. */
 int wd_layernorm_rows_split(const float* x, void* y, const float* gamma, const float* beta, int64_t rows, int32_t c,
                             int32_t ldx, int32_t ldy, float eps, void* stream);

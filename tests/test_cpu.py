@@ -191,6 +191,17 @@ def test_resample_oracle_is_pinned_to_pillow_and_reference_letterbox():
         assert r2 == ratio and pad == (dw, dh) and left == int(dw) and top == int(dh)
 
 
+def test_text_position_ids_match_huggingface():
+    from transformers.models.xlm_roberta.modeling_xlm_roberta import XLMRobertaEmbeddings
+    from wedetect_amd.text import position_ids
+    g = np.random.default_rng(8)
+    ids = torch.from_numpy(g.integers(0, 50, (9, 14)))
+    ids[:, 0] = 0
+    ids[3, 5:] = 1
+    ids[7, 2:] = 1
+    assert torch.equal(position_ids(ids, 1).long(), XLMRobertaEmbeddings.create_position_ids_from_input_ids(ids, 1))
+
+
 def test_instance_data_surface():
     from wedetect_amd.detector import InstanceData
     d = InstanceData(bboxes=torch.arange(12.).view(3, 4), scores=torch.tensor([0.9, 0.2, 0.5]), labels=torch.tensor([1, 2, 3]))

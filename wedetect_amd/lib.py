@@ -25,7 +25,7 @@ EXPORTS = (
     "wd_abi_version", "wd_strerror", "wd_sizeof_conv_gemm", "wd_conv_gemm", "wd_conv_gemm_tuned", "wd_conv_gemm_config", "wd_stem_patchify", "wd_dwconv7",
     "wd_layernorm_rows", "wd_l2norm_rows", "wd_dfl_decode", "wd_topk_workspace_bytes", "wd_topk_capacity",
     "wd_topk_candidates", "wd_nms_gather", "wd_retrieval_max",
-    "wd_split_weights_bytes", "wd_split_weights", "wd_conv_gemm_split", "wd_conv_gemm_split_config", "wd_layernorm_rows_split", "wd_letterbox_u8", "wd_retrieval_max_split",
+    "wd_split_weights_bytes", "wd_split_weights", "wd_conv_gemm_split", "wd_conv_gemm_split_config", "wd_layernorm_rows_split", "wd_letterbox_u8", "wd_retrieval_max_split", "wd_text_embed", "wd_attention_small",
 )
 
 
@@ -90,6 +90,8 @@ def _load():
     lib.wd_conv_gemm_split.argtypes = [C.POINTER(ConvGemm), vp, f32, i32, i32, vp]
     lib.wd_layernorm_rows_split.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, f32, vp]
     lib.wd_retrieval_max_split.argtypes = [vp, vp, f32, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.wd_text_embed.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, vp]
+    lib.wd_attention_small.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.wd_letterbox_u8.argtypes = [vp, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.wd_conv_gemm_split_config.restype = C.c_char_p
     lib.wd_conv_gemm_split_config.argtypes = [i32, i32, i32, i32]
@@ -245,3 +247,13 @@ def retrieval_max_split(e, t_split, scale, bias, count, out, n_img, rows_per_img
     check(LIB.wd_split_weights(_p(rows), rows.shape[0], dim, 1.0, _p(es), stream_ptr()), "wd_split_weights")
     check(LIB.wd_retrieval_max_split(_p(es), _p(t_split[0]), float(t_split[1]), _p(scale), _p(bias), _p(count), _p(out),
                                      n_img, rows_per_img, n_cls, dim, stream_ptr()), "wd_retrieval_max_split")
+
+
+def text_embed(ids, pos_ids, word, pos, type0, out) -> None:
+    check(LIB.wd_text_embed(_p(ids), _p(pos_ids), _p(word), _p(pos), _p(type0), _p(out), ids.numel(), word.shape[1],
+                            stream_ptr()), "wd_text_embed")
+
+
+def attention_small(qkv, mask, out, n_seq, seq_len, heads, head_dim) -> None:
+    check(LIB.wd_attention_small(_p(qkv), _p(mask), _p(out), n_seq, seq_len, heads, head_dim, qkv.shape[1], out.shape[1],
+                                 stream_ptr()), "wd_attention_small")
