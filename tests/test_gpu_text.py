@@ -103,6 +103,7 @@ def test_language_backbone_surface_feeds_the_detector():
         ref = torch.nn.functional.normalize(head(hs), dim=-1).reshape(2, 3, 768)
     assert_close("language backbone", feats, ref, 2e-5)
     assert_close("unit norm", feats.norm(dim=-1), torch.ones(2, 3), 1e-5)
+    assert torch.equal(tb.encode_classes(texts[0]), feats[0])
     with pytest.raises(AssertionError):
         tb([["a", "b"], ["c"]])
     with pytest.raises(RuntimeError):

@@ -257,10 +257,10 @@ class InstanceData:
 class YOLOWorldDetector:
     """Drop-in for the configured ``YOLOWorldDetector`` (mm_neck=False, use_bn_head=True).
 
-    ``test_cfg`` keeps the reference's keys (config/wedetect_base.py:18-25).  The XLM-R text
-    tower is outside the hot path: pass ``text_encoder`` (callable
-    List[str] -> [K, D_text->768] tensor) or set the class bank with
-    ``set_text_embeddings``; ``reparameterize`` without either raises."""
+    ``test_cfg`` keeps the reference's keys (config/wedetect_base.py:18-25).  The class bank comes
+    from a text tower: pass ``text_encoder`` (callable List[str] -> [K, 768] tensor, e.g.
+    ``wedetect_amd.text.XLMRobertaLanguageBackbone(...).encode_classes``) or set the bank directly
+    with ``set_text_embeddings``; ``reparameterize`` without either raises."""
 
     def __init__(self, model_size="base", img_scale=None, test_cfg=None, text_encoder: Optional[Callable] = None,
                  max_classes: int = 1203, precision: Optional[str] = None):
@@ -309,8 +309,8 @@ class YOLOWorldDetector:
     def reparameterize(self, texts: List[List[str]]) -> None:
         """yolo_world.py:58-61.  Needs the text tower, which is supplied by the caller."""
         if self.text_encoder is None:
-            raise NotImplementedError("reparameterize(texts) needs text_encoder=...; the XLM-RoBERTa tower is outside "
-                                      "the accelerated hot path — use set_text_embeddings(bank) with its output")
+            raise NotImplementedError("reparameterize(texts) needs text_encoder=... (wedetect_amd.text.XLMRobertaLanguageBackbone"
+                                      " with a tokenizer) or set_text_embeddings(bank)")
         self.set_text_embeddings(self.text_encoder([t[0] if isinstance(t, (list, tuple)) else t for t in texts]), texts)
 
     # -- image side -----------------------------------------------------------------------

@@ -149,3 +149,7 @@ class XLMRobertaLanguageBackbone:
         return feats.reshape(-1, num[0], feats.shape[-1])
 
     __call__ = forward
+
+    def encode_classes(self, names) -> torch.Tensor:
+        """List[str] -> [K, D]: the callable ``YOLOWorldDetector(text_encoder=...)`` expects."""
+        return self.forward([list(names)])[0]
