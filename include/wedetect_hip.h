@@ -169,6 +169,19 @@ int wd_text_embed(const int32_t* ids, const int32_t* pos_ids, const float* word,
 int wd_attention_small(const float* qkv, const int32_t* mask, float* out, int32_t n_seq, int32_t seq_len, int32_t heads,
                        int32_t head_dim, int32_t ld_qkv, int32_t ld_out, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * wd_recall_match — proposal-recall matching (eval_recall/recall.py:6-100): for
+ * every image i and every proposal budget budgets[b], the greedy one-to-one assignment of the
+ * reference over the fp32 IoU matrix of gts[gt_off[i]:gt_off[i+1]] x the first min(budget, count)
+ * proposals of the image (already sorted by the caller as the reference does); out[b][gt_off[i] + j]
+ * = IoU of the j-th assignment (the reference's gt_ious order).  Boxes xyxy fp32; scratch: one
+ * slice of scratch_floats_per_block >= max gts x max budget floats per (image, budget); < 65536
+ * gts / proposals per image.  legacy: the "+1" width/height convention. */
+int64_t wd_recall_scratch_floats(int32_t max_gt, int32_t max_budget);
+int wd_recall_match(const float* gts, const int32_t* gt_off, const float* props, const int32_t* prop_off, int32_t n_img,
+                    const int32_t* budgets, int32_t n_budget, float* scratch, int64_t scratch_floats_per_block, float* out,
+                    int32_t total_gt, int32_t legacy, void* stream);
+
 /* wd_layernorm_rows with the output written as fp16 (hi, lo) groups (see WD_SPLIT_A); c % 8 == 0. */
 int wd_layernorm_rows_split(const float* x, void* y, const float* gamma, const float* beta, int64_t rows, int32_t c,
                             int32_t ldx, int32_t ldy, float eps, void* stream);

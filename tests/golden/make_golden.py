@@ -440,6 +440,74 @@ def case_letterbox(gp):
     np.savez_compressed(os.path.join(OUT, "letterbox.npz"), **fx)
 
 
+def import_recall():
+    """eval_recall/recall.py as a module; its only non-numpy import is the table pretty-printer."""
+    import importlib.util
+    import types
+    sys.modules.setdefault("terminaltables", types.SimpleNamespace(AsciiTable=lambda *a, **k: types.SimpleNamespace(table="", inner_footing_row_border=False)))
+    spec = importlib.util.spec_from_file_location("ref_recall", os.path.join(REF, "eval_recall", "recall.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.print_recall_summary = lambda *a, **k: None
+    return mod
+
+
+def case_recall():
+    """Seeded ground truths / scored proposals (some images empty, some with more gts than proposals, exact
+    duplicates for IoU ties) through the reference's eval_recalls; the unsorted matched IoUs are recorded too."""
+    rc = import_recall()
+    g = np.random.default_rng(123)
+    gts, props = [], []
+    for i in range(9):
+        ng = int(g.integers(0, 9)) if i != 4 else 12
+        npr = int(g.integers(0, 40)) if i not in (4, 6) else (5 if i == 4 else 0)
+        gt = g.uniform(0, 300, (ng, 2)); gt = np.concatenate([gt, gt + g.uniform(10, 200, (ng, 2))], 1).astype(np.float32)
+        pr = g.uniform(0, 300, (npr, 2)); pr = np.concatenate([pr, pr + g.uniform(10, 200, (npr, 2))], 1).astype(np.float32)
+        if ng and npr > 3:
+            pr[1] = gt[0]                                   # an exact hit
+            pr[2] = pr[1]                                   # and a duplicate proposal: IoU tie
+            pr[3, :2] = gt[ng - 1, :2] + 3; pr[3, 2:] = gt[ng - 1, 2:] + 3
+        sc = g.uniform(0, 1, (npr, 1)).astype(np.float32)
+        gts.append(gt if ng else (None if i % 2 else gt))
+        props.append(np.concatenate([pr, sc], 1))
+    nums, thrs = np.array([1, 5, 20, 100]), np.arange(0.5, 0.96, 0.05)
+    fx = {"count": np.asarray(len(gts)), "nums": nums, "thrs": thrs}
+    for i, (a, b) in enumerate(zip(gts, props)):
+        fx[f"gt{i}"] = np.zeros((0, 4), np.float32) if a is None else a
+        fx[f"gt{i}_none"] = np.asarray(a is None)
+        fx[f"prop{i}"] = b
+    for legacy in (False, True):
+        fx[f"recalls_legacy{int(legacy)}"] = rc.eval_recalls(gts, props, nums, thrs, use_legacy_coordinate=legacy)
+        # the intermediate the device computes: _recalls' tmp_ious per budget, re-derived through the reference's functions
+        sorted_props = [p[np.argsort(p[:, 4])[::-1], :] for p in props]
+        all_ious = []
+        for a, b in zip(gts, sorted_props):
+            pn = min(b.shape[0], nums[-1])
+            all_ious.append(np.zeros((0, b.shape[0]), np.float32) if a is None or a.shape[0] == 0
+                            else rc.bbox_overlaps(a, b[:pn, :4], use_legacy_coordinate=legacy))
+        fx[f"iou0_legacy{int(legacy)}"] = all_ious[0] if all_ious[0].size else np.zeros((0, 0), np.float32)
+    np.savez_compressed(os.path.join(OUT, "recall.npz"), **fx)
+
+
+def case_retrieval_metric():
+    """evaluate_retrieval_per_class (retrieval_metric.py:14-47) lifted out of its script (the module body parses
+    argv and loads datasets at import) with ast, run on seeded prediction / ground-truth id sets."""
+    import ast
+    import json
+    src = open(os.path.join(REF, "eval_retrieval", "retrieval_metric.py")).read()
+    fn = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "evaluate_retrieval_per_class")
+    ns = {"tqdm": lambda it, **k: it}
+    exec(compile(ast.Module(body=[ast.parse("from typing import Dict, List, Set").body[0], fn], type_ignores=[]),
+                 "retrieval_metric_fn", "exec"), ns)
+    g = np.random.default_rng(31)
+    cats = [f"class_{i}" for i in range(12)]
+    gt = {c: set(int(v) for v in g.choice(200, int(g.integers(0, 30)), replace=False)) for c in cats}
+    pred = {c: [int(v) for v in g.choice(200, int(g.integers(0, 40)), replace=True)] for c in cats[:-2]}
+    res = ns["evaluate_retrieval_per_class"](pred, gt)
+    blob = json.dumps({"gt": {c: sorted(v) for c, v in gt.items()}, "pred": pred, "result": res}, sort_keys=True)
+    np.savez_compressed(os.path.join(OUT, "retrieval_metric.npz"), blob=np.asarray(blob))
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference tree not present: goldens can only be generated in the build container"
     # transformers probes torchvision at import: the plugin files (which import it) must be
@@ -454,4 +522,6 @@ if __name__ == "__main__":
     case_network(gp, "base", 1, 640)
     case_network(gp, "large", 1, 64, full_predict=False)
     case_letterbox(gp)
+    case_recall()
+    case_retrieval_metric()
     print("all golden fixtures written to", OUT)

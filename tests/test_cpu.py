@@ -202,6 +202,26 @@ def test_text_position_ids_match_huggingface():
     assert torch.equal(position_ids(ids, 1).long(), XLMRobertaEmbeddings.create_position_ids_from_input_ids(ids, 1))
 
 
+def test_recall_oracle_and_retrieval_metric_match_reference_goldens():
+    """oracle/evaluate.py == eval_recall/recall.py outputs (both coordinate conventions, incl. the IoU matrix),
+    and the host-side PRF evaluator == retrieval_metric.py's function on the recorded sets."""
+    import json
+    from oracle import evaluate as oe
+    from wedetect_amd.evaluate import evaluate_retrieval_per_class
+    fx = golden("recall.npz")
+    n = int(fx["count"])
+    gts = [None if bool(fx[f"gt{i}_none"]) else fx[f"gt{i}"] for i in range(n)]
+    props = [fx[f"prop{i}"] for i in range(n)]
+    for leg in (False, True):
+        assert np.array_equal(oe.eval_recalls(gts, props, fx["nums"], fx["thrs"], legacy=leg), fx[f"recalls_legacy{int(leg)}"])
+        p0 = props[0][np.argsort(props[0][:, 4])[::-1]]
+        if gts[0] is not None and gts[0].shape[0]:
+            assert np.array_equal(oe.bbox_overlaps(gts[0], p0[:, :4], legacy=leg), fx[f"iou0_legacy{int(leg)}"])
+    rec = json.loads(str(golden("retrieval_metric.npz")["blob"]))
+    got = evaluate_retrieval_per_class(rec["pred"], {c: set(v) for c, v in rec["gt"].items()})
+    assert got == rec["result"]
+
+
 def test_instance_data_surface():
     from wedetect_amd.detector import InstanceData
     d = InstanceData(bboxes=torch.arange(12.).view(3, 4), scores=torch.tensor([0.9, 0.2, 0.5]), labels=torch.tensor([1, 2, 3]))

@@ -355,3 +355,34 @@ def test_retrieval_max_golden(L, k):
     assert_close(f"retrieval max k{k} (golden from the reference's lines)", o[0], fx[f"k{k}.max_scores"], 2e-6, 1e-5)
     assert np.all(o[1] == 0.0), "image without regions must give zeros"
     assert_close("partial count", o[2], opp.retrieval_scores(e[:137], t, scale[:137], bias[:137]), 2e-6, 1e-5)
+
+
+def test_nms_iou_is_exactly_the_fp32_formula_near_the_threshold(L):
+    """4000 two-box images whose IoU sits within a few fp32 ulps of the 0.7 threshold: the keep decision must be
+    the one the fp32 formula inter / (a_i + a_j - inter) gives with every operation rounded separately (numpy) —
+    an fma-contracted union is off by up to 2 ulps and flips some of these."""
+    g = np.random.default_rng(404)
+    n = 4000
+    boxes, expect = [], []
+    f = np.float32
+    thr = f(0.7)
+    while len(boxes) < n:
+        w, h = f(g.uniform(20, 200)), f(g.uniform(20, 200))
+        x, y = f(g.uniform(0, 300)), f(g.uniform(0, 300))
+        a = np.array([x, y, x + w, y + h], f)
+        # shift along x so that IoU ~ 0.7: inter = (w - d) h, union = (w + d) h  ->  d = w (1 - t) / (1 + t)
+        d = f(w * (1 - 0.7) / (1 + 0.7)) + f(g.uniform(-2e-4, 2e-4))
+        b = np.array([a[0] + d, a[1], a[2] + d, a[3]], f)
+        ai, aj = (a[2] - a[0]) * (a[3] - a[1]), (b[2] - b[0]) * (b[3] - b[1])
+        iw = max(f(0), min(a[2], b[2]) - max(a[0], b[0])); ih = max(f(0), min(a[3], b[3]) - max(a[1], b[1]))
+        inter = f(iw * ih)
+        iou = inter / f(f(ai + aj) - inter)
+        if abs(float(iou) - 0.7) < 3e-6:
+            boxes.append(np.stack([a, b]))
+            expect.append(1 if iou > thr else 2)
+    sc = [np.array([0.9, 0.8], f)] * n
+    lb = [np.zeros(2, np.int64)] * n
+    _, _, _, _, oc, _ = run_nms(L, boxes, sc, lb, 1, 0.7, 4, [IDENT] * n)
+    expect = np.asarray(expect)
+    assert 0.2 < np.mean(expect == 1) < 0.8, "the construction must straddle the threshold"
+    assert np.array_equal(oc, expect), f"{int(np.sum(oc != expect))} of {n} near-threshold decisions differ"

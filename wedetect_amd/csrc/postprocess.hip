@@ -321,25 +321,29 @@ __global__ void __launch_bounds__(256) topk_unpack_kernel(const unsigned long lo
 // NMS
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ bool iou_gt(const f32x4 bi, const f32x4 bj, float thr) {
-  // inter / (area_i + area_j - inter) > thr, every operation individually rounded (fp32)
-  const float area_i = __fmul_rn(__fsub_rn(bi[2], bi[0]), __fsub_rn(bi[3], bi[1]));
-  const float area_j = __fmul_rn(__fsub_rn(bj[2], bj[0]), __fsub_rn(bj[3], bj[1]));
+  // inter / (area_i + area_j - inter) > thr, every operation individually rounded (fp32).  Plain
+  // operators under "fp contract(off)": HIP's __fmul_rn / __fsub_rn are header functions compiled with
+  // the default contraction, and (area_i + area_j) - w * h written with them is fused into an fma.
+#pragma clang fp contract(off)
+  const float area_i = (bi[2] - bi[0]) * (bi[3] - bi[1]);
+  const float area_j = (bj[2] - bj[0]) * (bj[3] - bj[1]);
   const float xx1 = fmaxf(bi[0], bj[0]), yy1 = fmaxf(bi[1], bj[1]);
   const float xx2 = fminf(bi[2], bj[2]), yy2 = fminf(bi[3], bj[3]);
-  const float w = fmaxf(0.f, __fsub_rn(xx2, xx1)), h = fmaxf(0.f, __fsub_rn(yy2, yy1));
-  const float inter = __fmul_rn(w, h);
-  const float ovr = __fdiv_rn(inter, __fsub_rn(__fadd_rn(area_i, area_j), inter));
+  const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
+  const float inter = w * h;
+  const float ovr = inter / (area_i + area_j - inter);
   return ovr > thr;
 }
 
 __device__ __forceinline__ f32x4 rescale_box(f32x4 bx, const float* mt) {
   // (box - pad) / scale, the mmdet order (yolo_world_head.py:728-734) and the Uni order
   // (generate_proposal.py:1108-1113) share the arithmetic
+#pragma clang fp contract(off)
   f32x4 r;
-  r[0] = __fdiv_rn(__fsub_rn(bx[0], mt[0]), mt[3]);
-  r[1] = __fdiv_rn(__fsub_rn(bx[1], mt[1]), mt[4]);
-  r[2] = __fdiv_rn(__fsub_rn(bx[2], mt[0]), mt[3]);
-  r[3] = __fdiv_rn(__fsub_rn(bx[3], mt[1]), mt[4]);
+  r[0] = (bx[0] - mt[0]) / mt[3];
+  r[1] = (bx[1] - mt[1]) / mt[4];
+  r[2] = (bx[2] - mt[0]) / mt[3];
+  r[3] = (bx[3] - mt[1]) / mt[4];
   return r;
 }
 __device__ __forceinline__ f32x4 clamp_box(f32x4 bx, const float* mt) {

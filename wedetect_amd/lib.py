@@ -25,7 +25,7 @@ EXPORTS = (
     "wd_abi_version", "wd_strerror", "wd_sizeof_conv_gemm", "wd_conv_gemm", "wd_conv_gemm_tuned", "wd_conv_gemm_config", "wd_stem_patchify", "wd_dwconv7",
     "wd_layernorm_rows", "wd_l2norm_rows", "wd_dfl_decode", "wd_topk_workspace_bytes", "wd_topk_capacity",
     "wd_topk_candidates", "wd_nms_gather", "wd_retrieval_max",
-    "wd_split_weights_bytes", "wd_split_weights", "wd_conv_gemm_split", "wd_conv_gemm_split_config", "wd_layernorm_rows_split", "wd_letterbox_u8", "wd_retrieval_max_split", "wd_text_embed", "wd_attention_small",
+    "wd_split_weights_bytes", "wd_split_weights", "wd_conv_gemm_split", "wd_conv_gemm_split_config", "wd_layernorm_rows_split", "wd_letterbox_u8", "wd_retrieval_max_split", "wd_text_embed", "wd_attention_small", "wd_recall_scratch_floats", "wd_recall_match",
 )
 
 
@@ -90,6 +90,9 @@ def _load():
     lib.wd_conv_gemm_split.argtypes = [C.POINTER(ConvGemm), vp, f32, i32, i32, vp]
     lib.wd_layernorm_rows_split.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, f32, vp]
     lib.wd_retrieval_max_split.argtypes = [vp, vp, f32, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.wd_recall_scratch_floats.restype = i64
+    lib.wd_recall_scratch_floats.argtypes = [i32, i32]
+    lib.wd_recall_match.argtypes = [vp, vp, vp, vp, i32, vp, i32, vp, i64, vp, i32, i32, vp]
     lib.wd_text_embed.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, vp]
     lib.wd_attention_small.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.wd_letterbox_u8.argtypes = [vp, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
