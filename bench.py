@@ -43,7 +43,7 @@ KERNEL_SYMBOL = {
     "128x128x16/8w/conv": "conv_gemm_kernel<2, 4, 4, 2, true, 16, 256>",
     "64x128x16/4w/plain": "conv_gemm_kernel<2, 4, 2, 2, false, 16, 256>",
     "64x128x16/4w/conv": "conv_gemm_kernel<2, 4, 2, 2, true, 16, 256>",
-    "128x80x16/8w/plain": "conv_gemm_kernel<1, 5, 8, 1, false, 16, 256>",
+    "128x80x32/8w/plain": "conv_gemm_kernel<1, 5, 8, 1, false, 32, 258>",
     "fp16x3 128x128x16/4w/plain": "split_gemm_kernel<2, 2, 2, 2, 16, false, 770>",
     "fp16x3 128x128x16/4w/conv": "split_gemm_kernel<2, 2, 2, 2, 16, true, 770>",
     "fp16x3 128x128x32/4w/plain": "split_gemm_kernel<2, 2, 2, 2, 32, false, 770>",

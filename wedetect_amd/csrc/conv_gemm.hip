@@ -486,7 +486,7 @@ extern "C" const char* wd_conv_gemm_config(int32_t m, int32_t n, int32_t k) {
   switch (pick_bn(n)) {
     case 128: return use_small_tile(m, n) ? "64x128x16/4w" : "128x128x16/8w";
     case 96: return "128x96x16/8w";
-    case 80: return "128x80x16/8w";
+    case 80: return "128x80x32/8w";
     case 64: return "128x64x16/8w";
     default: return "128x48x16/8w";
   }
@@ -522,7 +522,7 @@ extern "C" int wd_conv_gemm(const WdConvGemm* pp, void* stream) {
       return use_small_tile(p.m, p.n) ? launch_cfg<2, 4, 2, 2, 16, VAR_XCD>(p, st)
                                       : launch_cfg<2, 4, 4, 2, 16, VAR_XCD>(p, st);
     case 96: return launch_cfg<1, 6, 8, 1, 16, VAR_XCD>(p, st);
-    case 80: return launch_cfg<1, 5, 8, 1, 16, VAR_XCD | VAR_PIN>(p, st);   // the similarity GEMM: pinned order +2..5 % (profiles/r01_gemm_ab.txt)
+    case 80: return launch_cfg<1, 5, 8, 1, 32, VAR_XCD | VAR_PIN>(p, st);   // the similarity GEMM: pinned order +2..5 %, K step 32 +3 % (profiles/r01_gemm_ab.txt)
     case 64: return launch_cfg<1, 4, 8, 1, 16, VAR_XCD>(p, st);
     default: return launch_cfg<1, 3, 8, 1, 16, VAR_XCD>(p, st);
   }
@@ -553,6 +553,9 @@ extern "C" int wd_conv_gemm_tuned(const WdConvGemm* pp, int32_t cfg, void* strea
     case 15: return launch_cfg<2, 4, 2, 2, 16, VAR_XCD | VAR_PIN>(p, st);
     case 16: return launch_cfg<1, 5, 8, 1, 16, VAR_XCD | VAR_PIN>(p, st);
     case 17: return launch_cfg<1, 4, 8, 1, 16, VAR_XCD | VAR_PIN>(p, st);
+    case 18: return launch_cfg<1, 5, 4, 1, 16, VAR_XCD | VAR_PIN>(p, st);  // 64x80x16, 4 waves
+    case 19: return launch_cfg<1, 5, 8, 1, 32, VAR_XCD | VAR_PIN>(p, st);  // 128x80x32, 8 waves
+    case 25: return launch_cfg<1, 5, 16, 1, 16, VAR_XCD | VAR_PIN>(p, st); // 256x80x16, 16 waves
     case 20: return launch_cfg<2, 4, 4, 2, 16, VAR_XCD | ABL_NOLOAD>(p, st);
     case 21: return launch_cfg<2, 4, 4, 2, 16, VAR_XCD | ABL_NOBAR>(p, st);
     case 22: return launch_cfg<2, 4, 4, 2, 16, VAR_XCD | ABL_NOEPI>(p, st);
