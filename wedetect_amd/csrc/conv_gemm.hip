@@ -253,7 +253,7 @@ __device__ __forceinline__ void epilogue(const WdConvGemm& p, const EpiCtx& ec, 
         float x = act_fast<ACT>(v[r] + b4[r]);
         if (SPECIAL) {
           x = x * oscale + obias;
-          if (p.sigmoid) x = wd_sigmoid(x);
+          if (p.sigmoid) x = wd_sigmoid_fast(x);
         }
         o[r] = x;
       }

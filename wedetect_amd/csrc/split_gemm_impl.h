@@ -118,7 +118,7 @@ __device__ __forceinline__ void epi_quad(const WdConvGemm& p, const EpiRow& er, 
     float x = sact<ACT>(fmaf(v[r], ev.unscale, b4[r]));     // unscale is a power of two: exact
     if (SPECIAL) {
       x = x * er.oscale + er.obias;
-      if (p.sigmoid) x = wd_sigmoid(x);
+      if (p.sigmoid) x = wd_sigmoid_fast(x);
     }
     o[r] = x;
   }
