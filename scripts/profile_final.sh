@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 TAG=${1:-final}; shift
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
-CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline $*"
+CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fp32-reference $*"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o p -- $CMD > $OUT/trace_bench.json 2> $OUT/trace.err
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $OUT/pmc_sq -o p -- $CMD > /dev/null 2> $OUT/pmc_sq.err
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- $CMD > /dev/null 2> $OUT/pmc_fetch.err
