@@ -553,9 +553,7 @@ extern "C" int wd_conv_gemm_tuned(const WdConvGemm* pp, int32_t cfg, void* strea
     case 15: return launch_cfg<2, 4, 2, 2, 16, VAR_XCD | VAR_PIN>(p, st);
     case 16: return launch_cfg<1, 5, 8, 1, 16, VAR_XCD | VAR_PIN>(p, st);
     case 17: return launch_cfg<1, 4, 8, 1, 16, VAR_XCD | VAR_PIN>(p, st);
-    case 18: return launch_cfg<1, 5, 4, 1, 16, VAR_XCD | VAR_PIN>(p, st);  // 64x80x16, 4 waves
-    case 19: return launch_cfg<1, 5, 8, 1, 32, VAR_XCD | VAR_PIN>(p, st);  // 128x80x32, 8 waves
-    case 25: return launch_cfg<1, 5, 16, 1, 16, VAR_XCD | VAR_PIN>(p, st); // 256x80x16, 16 waves
+    case 19: return launch_cfg<1, 5, 8, 1, 32, VAR_XCD | VAR_PIN>(p, st);  // 128x80x32, 8 waves (production, n = 80)
     case 20: return launch_cfg<2, 4, 4, 2, 16, VAR_XCD | ABL_NOLOAD>(p, st);
     case 21: return launch_cfg<2, 4, 4, 2, 16, VAR_XCD | ABL_NOBAR>(p, st);
     case 22: return launch_cfg<2, 4, 4, 2, 16, VAR_XCD | ABL_NOEPI>(p, st);
