@@ -87,6 +87,8 @@ def parse():
     ap.add_argument("--precision", choices=["fp32", "fp16x3"], default=None,
                     help="arithmetic of the dense convs/linears (default: wedetect_amd.engine.DEFAULT_PRECISION); "
                          "fp16x3 = fp32 operands split into fp16 hi+lo, three MFMA passes, fp32 accumulate")
+    ap.add_argument("--split-k", action="store_true",
+                    help="latency mode: let under-filled fp16x3 launches split K (helps small batches; see engine.ImageTower)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-reference", action="store_true",
                     help="skip the short native-fp32 run that is reported beside an fp16x3 result (N = 1 only)")
@@ -229,7 +231,7 @@ def main():
 
     B, S, K = args.batch, args.size, args.classes
     tower = ImageTower(args.arch, pack(W.make_state_dict(args.arch), args.arch), B, S, S, max_classes=K,
-                       precision=args.precision)
+                       precision=args.precision, split_k=args.split_k or None)
     split = tower.precision == "fp16x3"
     images = torch.from_numpy(W.make_images(B, S, S, seed=1234 + rank)).cuda()
     text = torch.from_numpy(W.make_text_bank(K)).cuda()

@@ -130,6 +130,14 @@ int wd_conv_gemm_split(const WdConvGemm* p, const void* w_split, float w_unscale
  * Results are bit-identical to the flags = 0 path (the same halves, produced earlier). */
 #define WD_SPLIT_A 1
 #define WD_SPLIT_C 2
+/* wd_conv_gemm_split with a caller-owned workspace (16-byte aligned): when a launch has few tiles and a long
+ * K loop (batch-1 inference, the 20 x 20 maps) K is split over `splits` workgroups per tile, partial sums go
+ * to the workspace ([splits][m][n] fp32) and a second kernel adds them in split order and applies the
+ * epilogue (deterministic; the summation order differs from the unsplit kernel's, so the last bits may).
+ * splits = 0: decided by the library (1 if the launch already fills the chip or the workspace is too small);
+ * splits > 0: forced. */
+int wd_conv_gemm_split_ws(const WdConvGemm* p, const void* w_split, float w_unscale, int32_t flags, int32_t cfg,
+                          void* workspace, int64_t workspace_bytes, int32_t splits, void* stream);
 /* Name of the tile wd_conv_gemm_split picks with cfg < 0 for an (m, n, k) problem; is_conv != 0:
  * not a 1x1 / stride 1 / pad 0 layer (diagnostic). */
 const char* wd_conv_gemm_split_config(int32_t m, int32_t n, int32_t k, int32_t is_conv);

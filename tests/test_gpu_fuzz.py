@@ -82,3 +82,73 @@ def test_conv_random_geometry_fp16x3(seed):
     L.conv_gemm(x, None, bias, c, batch=bsz, hin=h, win=w_, cin=ci, lda=ci, kh=kk, kw=kk, stride=stride, pad=pad, n=co,
                 ldc=co, act=L.ACT_RELU, w_split=L.split_weights(wrow))
     assert_close(f"conv k{kk}s{stride} {bsz}x{h}x{w_}x{ci}->{co}", c, ref, 8e-6 * max(1.0, float(ref.abs().max())), 2e-6)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_split_k_random_shapes(seed):
+    """Forced and library-chosen K splits (partial sums in a workspace + ordered reduce with the full epilogue)
+    on loader-split, pre-split staged and direct-to-LDS kernels, plain and conv, vs float64."""
+    from wedetect_amd import lib as L
+    g = np.random.default_rng(3000 + seed)
+    m = int(g.integers(1, 500))
+    n = int(g.integers(1, 40)) * 8
+    k = int(g.integers(8, 80)) * 16
+    act = int(g.integers(0, 4))
+    use_res = bool(g.integers(0, 2))
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    a = torch.randn(m, k, device="cuda", generator=gen)
+    w = torch.randn(n, k, device="cuda", generator=gen) * k ** -0.5
+    b = torch.randn(n, device="cuda", generator=gen) * 0.3
+    res = torch.randn(m, n, device="cuda", generator=gen) if use_res else None
+    ref = _ref(a, w, b, act, res)
+    tol = dict(atol=8e-6 * max(1.0, float(ref.abs().max())), rtol=2e-6)
+    kw = dict(batch=1, hin=1, win=m, cin=k, lda=k, n=n, ldc=n, act=act)
+    if use_res:
+        kw.update(res=res, ldres=n)
+    ws = L.split_weights(w)
+    wsp = torch.empty(8 * m * n + 64, device="cuda")
+    c = torch.empty(m, n, device="cuda")
+    for splits in (0, 2, 3, 7):
+        for cfg in (-1, 50, 51):
+            c.fill_(float("nan"))
+            L.conv_gemm(a, None, b, c, w_split=ws, split_cfg=cfg, workspace=wsp, k_splits=splits, **kw)
+            assert_close(f"split-K {splits} cfg {cfg} m{m} n{n} k{k}", c, ref, **tol)
+    buf = torch.empty(L.LIB.wd_split_weights_bytes(m, k), dtype=torch.uint8, device="cuda")
+    L.check(L.LIB.wd_split_weights(a.data_ptr(), m, k, 1.0, buf.data_ptr(), L.stream_ptr()), "split a")
+    a_split = buf.view(torch.float32).view(m, k)
+    for splits in (0, 2, 5):
+        for cfg in (51, 60):
+            c.fill_(float("nan"))
+            L.conv_gemm(a_split, None, b, c, w_split=ws, split_cfg=cfg, split_flags=L.SPLIT_A, workspace=wsp, k_splits=splits, **kw)
+            assert_close(f"pre-split split-K {splits} cfg {cfg}", c, ref, **tol)
+    with pytest.raises(L.WedetectHipError):                     # workspace too small for a forced split
+        L.conv_gemm(a, None, b, c, w_split=ws, workspace=torch.empty(16, device="cuda"), k_splits=2, **kw)
+
+
+def test_split_k_conv_and_special_epilogue():
+    from wedetect_amd import lib as L
+    g = torch.Generator(device="cuda").manual_seed(5)
+    bsz, h, w_, ci, co = 1, 10, 12, 64, 96
+    x = torch.randn(bsz, h, w_, ci, device="cuda", generator=g)
+    wt = torch.randn(co, ci, 3, 3, device="cuda", generator=g) * (ci * 9) ** -0.5
+    bias = torch.randn(co, device="cuda", generator=g)
+    wrow = wt.permute(0, 2, 3, 1).reshape(co, 9 * ci).contiguous()
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), wt.double(), bias.double(), padding=1)
+    ref = (ref * torch.sigmoid(ref)).permute(0, 2, 3, 1).reshape(-1, co)
+    c = torch.empty(bsz * h * w_, co, device="cuda")
+    wsp = torch.empty(6 * c.numel(), device="cuda")
+    for splits in (0, 3, 6):
+        c.fill_(float("nan"))
+        L.conv_gemm(x, None, bias, c, batch=bsz, hin=h, win=w_, cin=ci, lda=ci, kh=3, kw=3, stride=1, pad=1, n=co, ldc=co,
+                    act=L.ACT_SILU, w_split=L.split_weights(wrow), workspace=wsp, k_splits=splits)
+        assert_close(f"conv split-K {splits}", c, ref, 8e-6 * max(1.0, float(ref.abs().max())), 2e-6)
+    # per-level affine + sigmoid + batch-strided rows through the reduce kernel
+    m, n, k = 2 * 84, 80, 768
+    a = torch.randn(m, k, device="cuda", generator=g)
+    w = torch.nn.functional.normalize(torch.randn(n, k, device="cuda", generator=g), dim=-1)
+    seg = (84, 64, 80, (0.7, 0.58, 0.82), (-2.6, -2.2, -1.9))
+    kw = dict(batch=2, hin=1, win=84, cin=k, lda=k, n=n, ldc=n, sigmoid=True, seg=seg)
+    c0, c1 = torch.zeros(m, n, device="cuda"), torch.zeros(m, n, device="cuda")
+    L.conv_gemm(a, w, None, c0, **kw)
+    L.conv_gemm(a, None, None, c1, w_split=L.split_weights(w), workspace=torch.empty(4 * m * n, device="cuda"), k_splits=4, **kw)
+    assert_close("split-K seg + sigmoid", c1, c0, 2e-6)

@@ -242,6 +242,27 @@ def test_full_size_properties_base_640():
         assert torch.equal(ra[k][0], r1[k][0]), f"image 0 differs between batch 1 and batch 4 in {k}"
 
 
+def test_split_k_latency_mode_matches_default_path():
+    """Opt-in split-K (batch-1 latency mode): same detections as the default path up to fp32 summation-order noise."""
+    if PRECISION["value"] != "fp16x3":
+        pytest.skip("split-K exists for the fp16x3 kernels only")
+    _, t0, imgs = build("base", 1, 320, num_prompts=64)
+    _, t1, _ = build("base", 1, 320, num_prompts=64, split_k=True)
+    assert t0.kws is None and t1.kws is not None
+    x = torch.from_numpy(imgs).cuda()
+    outs = []
+    for t in (t0, t1):
+        r = t.detect(x, t.P["prompts"], t.identity_meta(), normalize_text=False, score_thr=0.0, with_embed=True)
+        torch.cuda.synchronize()
+        outs.append((t.embed.clone(), t.scores.view(-1)[: t.ntot * 64].clone(), {k: v.clone() for k, v in r.items()}))
+    assert_close("split-K embeddings", outs[1][0], outs[0][0], 2e-5, 1e-5)
+    assert_close("split-K scores", outs[1][1], outs[0][1], 5e-6)
+    n0, n1 = int(outs[0][2]["count"][0]), int(outs[1][2]["count"][0])
+    a0 = set(zip(to_np(outs[0][2]["anchors"][0, :n0]).tolist(), to_np(outs[0][2]["labels"][0, :n0]).tolist()))
+    a1 = set(zip(to_np(outs[1][2]["anchors"][0, :n1]).tolist(), to_np(outs[1][2]["labels"][0, :n1]).tolist()))
+    assert n0 == n1 and len(a0 & a1) >= 0.97 * n0
+
+
 def test_hipgraph_replay_equals_eager_and_is_faster_at_batch1():
     """A captured step must reproduce the eager step bit for bit on new inputs, and at batch 1
     (the reference's operating point) it removes the host launch overhead."""

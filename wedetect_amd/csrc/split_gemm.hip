@@ -41,6 +41,38 @@ __global__ void split_weights_kernel(const float* __restrict__ w, int n, int k, 
   o[8] = __builtin_bit_cast(unsigned short, lo);
 }
 
+// split-K second pass: out = epilogue(sum_s ws[s][m][n]) with the partial sums added in split order
+// (deterministic), one thread per 4 consecutive channels of a row.
+template <int ACT, bool SPECIAL>
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const WdConvGemm p, const float* __restrict__ ws, int splits,
+                                                            float unscale, int vec_c, int vec_res, int vec_bias) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nq = p.n >> 2;
+  if (idx >= (long long)p.m * nq) return;
+  const int m = (int)(idx / nq), n = (int)(idx - (long long)m * nq) * 4;
+  const size_t plane = (size_t)p.m * p.n;
+  f32x4 v = *reinterpret_cast<const f32x4*>(ws + (size_t)m * p.n + n);
+  for (int s = 1; s < splits; ++s) v += *reinterpret_cast<const f32x4*>(ws + s * plane + (size_t)m * p.n + n);
+  const EpiVec ev{vec_c, vec_res, vec_bias, unscale};
+  epi_quad<ACT, SPECIAL>(p, epi_row<SPECIAL>(p, m), ev, m, n, v);
+}
+
+template <bool SPECIAL>
+int launch_reduce(const WdConvGemm& p, const float* ws, int splits, float unscale, hipStream_t st) {
+  const long long total = (long long)p.m * (p.n >> 2);
+  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  const int vec_c = (p.ldc % 4 == 0) && wd_aligned16(p.c) && (p.out_mode == WD_OUT_ROWS || (p.n % 16 == 0));
+  const int vec_res = p.res ? ((p.ldres % 4 == 0) && wd_aligned16(p.res)) : 0;
+  const int vec_bias = p.bias ? wd_aligned16(p.bias) : 0;
+  switch (p.act) {
+    case WD_ACT_RELU: hipLaunchKernelGGL((splitk_reduce_kernel<WD_ACT_RELU, SPECIAL>), grid, block, 0, st, p, ws, splits, unscale, vec_c, vec_res, vec_bias); break;
+    case WD_ACT_SILU: hipLaunchKernelGGL((splitk_reduce_kernel<WD_ACT_SILU, SPECIAL>), grid, block, 0, st, p, ws, splits, unscale, vec_c, vec_res, vec_bias); break;
+    case WD_ACT_GELU: hipLaunchKernelGGL((splitk_reduce_kernel<WD_ACT_GELU, SPECIAL>), grid, block, 0, st, p, ws, splits, unscale, vec_c, vec_res, vec_bias); break;
+    default: hipLaunchKernelGGL((splitk_reduce_kernel<WD_ACT_NONE, SPECIAL>), grid, block, 0, st, p, ws, splits, unscale, vec_c, vec_res, vec_bias); break;
+  }
+  return wd_launch_status();
+}
+
 }  // namespace
 
 extern "C" int64_t wd_split_weights_bytes(int32_t n, int32_t k) {
@@ -84,38 +116,83 @@ extern "C" const char* wd_conv_gemm_split_config(int32_t m, int32_t n, int32_t k
   }
 }
 
-// cfg < 0: production choice.  Other values select a tile for on-device A/B runs.
-extern "C" int wd_conv_gemm_split(const WdConvGemm* pp, const void* w_split, float w_unscale, int32_t flags,
-                                  int32_t cfg, void* stream) {
+// K splits for an under-filled launch: few tiles and a long K loop are latency-bound (one workgroup walks
+// K serially); S workgroups per tile walk K / S each and a second pass adds the partial sums.
+static int pick_ksplits(const WdConvGemm& p, int cfg, int flags, long long ws_floats) {
+  if (ws_floats <= 0 || (flags & WD_SPLIT_C) || (p.n & 3) || cfg == 55 || cfg == 63) return 1;
+  const int bm = 128, bn = (cfg == 52 || cfg == 53) ? 64 : 128, bk = (cfg == 50) ? 32 : 16;
+  const long long tiles = (long long)((p.m + (cfg == 52 ? 255 : bm - 1)) / (cfg == 52 ? 256 : bm)) * ((p.n + bn - 1) / bn);
+  const int nk = (p.k + bk - 1) / bk;
+  if (tiles >= 128 || nk < 16) return 1;
+  int s = (int)(512 / tiles);                               // aim at ~512 workgroups (two per CU)
+  if (s > nk / 8) s = nk / 8;                               // at least 8 K stages per workgroup
+  if (s > 16) s = 16;
+  while (s > 1 && (long long)s * p.m * p.n > ws_floats) --s;
+  return s < 2 ? 1 : s;
+}
+
+static int conv_gemm_split_impl(const WdConvGemm* pp, const void* w_split, float w_unscale, int32_t flags, int32_t cfg,
+                                float* ws, int64_t ws_bytes, int32_t force_splits, hipStream_t st) {
   if (!pp) return WD_ERR_BAD_ARG;
   const WdConvGemm& p = *pp;
   const int rc = check_split_args(p, w_split, w_unscale);
   if (rc != WD_OK) return rc;
   if (flags & ~(WD_SPLIT_A | WD_SPLIT_C)) return WD_ERR_BAD_ARG;
-  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (ws && !wd_aligned16(ws)) return WD_ERR_BAD_ARG;
   const bool production = cfg < 0;
   if (cfg < 0) cfg = pick_split_cfg(p);
+  const bool plain = p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0;
+  const bool special = p.out_mode != WD_OUT_ROWS || p.c_batch_stride > 0 || p.seg_rows > 0 || p.sigmoid ||
+                       p.out_scale != 1.0f || p.out_bias != 0.0f;
   if (flags != 0) {
     // pre-split operands: 128-wide tiles only (every layer on that path has n % 128 == 0 in the
     // shipped towers; other widths still work, with padding).  Plain layers go global -> LDS
-    // directly (cfg 60); the 2x2 downsample conv and odd K keep the register-staged kernels.
-    const bool plain = p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0;
-    const bool special = p.out_mode != WD_OUT_ROWS || p.c_batch_stride > 0 || p.seg_rows > 0 || p.sigmoid ||
-                         p.out_scale != 1.0f || p.out_bias != 0.0f;
+    // directly (cfg 60 / 63); the 2x2 downsample conv and odd K keep the register-staged kernels.
     // long-m layers (ConvNeXt stages 1-2): the ping-pong 256 x 128 kernel, else 128 x 128
     if (production && plain && !special && p.k % 16 == 0) cfg = p.m >= 131072 ? 63 : 60;
     if (cfg != 50 && cfg != 51 && cfg != 55 && cfg != 60 && cfg != 63) cfg = 51;
     if ((flags & WD_SPLIT_C) && cfg == 55) cfg = 50;
-    return wd_launch_presplit(p, w_split, w_unscale, cfg, flags, st);
   }
-  switch (cfg) {
-    case 41: return launch_split<2, 2, 2, 4, 16, SVAR_XCD | SVAR_PIN | SVAR_LDSEPI>(p, w_split, w_unscale, st);  // 128 x 256 x 16, 8 waves
-    case 50: return launch_split<2, 2, 2, 2, 32, SVAR_XCD | SVAR_PIN | SVAR_LDSEPI>(p, w_split, w_unscale, st);  // 128 x 128 x 32, 4 waves
-    case 51: return launch_split<2, 2, 2, 2, 16, SVAR_XCD | SVAR_PIN | SVAR_LDSEPI>(p, w_split, w_unscale, st);  // 128 x 128 x 16, 4 waves
-    case 52: return launch_split<2, 2, 4, 1, 16, SVAR_XCD | SVAR_PIN | SVAR_LDSEPI>(p, w_split, w_unscale, st);  // 256 x 64 x 16, 4 waves
-    case 53: return launch_split<2, 2, 2, 1, 16, SVAR_XCD | SVAR_PIN | SVAR_LDSEPI>(p, w_split, w_unscale, st);  // 128 x 64 x 16, 2 waves
-    // prefetch distance 2 (two staging register sets; only the BK = 32 plain kernel holds them without spilling)
-    case 55: return launch_split<2, 2, 2, 2, 32, SVAR_XCD | SVAR_PF2 | SVAR_LDSEPI>(p, w_split, w_unscale, st);
-    default: return WD_ERR_UNSUPPORTED;
+  const long long ws_floats = ws ? ws_bytes / 4 : 0;
+  int splits = force_splits > 0 ? force_splits : pick_ksplits(p, cfg, flags, ws_floats);
+  {
+    const int bk = (cfg == 50) ? 32 : 16, nk = (p.k + bk - 1) / bk;
+    if (splits > nk) splits = nk;                             // never an empty split
   }
+  if (splits > 1) {
+    if ((flags & WD_SPLIT_C) || (p.n & 3) || cfg == 55 || cfg == 63) return WD_ERR_UNSUPPORTED;
+    if ((long long)splits * p.m * p.n > ws_floats) return WD_ERR_WORKSPACE;
+  }
+  int lrc;
+  if (flags != 0) {
+    lrc = wd_launch_presplit(p, w_split, w_unscale, cfg, flags, st, splits, ws);
+  } else {
+    switch (cfg) {
+      case 41: lrc = launch_split<2, 2, 2, 4, 16, SVAR_XCD | SVAR_PIN | SVAR_LDSEPI>(p, w_split, w_unscale, st, splits, ws); break;  // 128 x 256 x 16, 8 waves
+      case 50: lrc = launch_split<2, 2, 2, 2, 32, SVAR_XCD | SVAR_PIN | SVAR_LDSEPI>(p, w_split, w_unscale, st, splits, ws); break;  // 128 x 128 x 32, 4 waves
+      case 51: lrc = launch_split<2, 2, 2, 2, 16, SVAR_XCD | SVAR_PIN | SVAR_LDSEPI>(p, w_split, w_unscale, st, splits, ws); break;  // 128 x 128 x 16, 4 waves
+      case 52: lrc = launch_split<2, 2, 4, 1, 16, SVAR_XCD | SVAR_PIN | SVAR_LDSEPI>(p, w_split, w_unscale, st, splits, ws); break;  // 256 x 64 x 16, 4 waves
+      case 53: lrc = launch_split<2, 2, 2, 1, 16, SVAR_XCD | SVAR_PIN | SVAR_LDSEPI>(p, w_split, w_unscale, st, splits, ws); break;  // 128 x 64 x 16, 2 waves
+      // prefetch distance 2 (two staging register sets; only the BK = 32 plain kernel holds them without spilling)
+      case 55: lrc = launch_split<2, 2, 2, 2, 32, SVAR_XCD | SVAR_PF2 | SVAR_LDSEPI>(p, w_split, w_unscale, st); break;
+      default: return WD_ERR_UNSUPPORTED;
+    }
+  }
+  if (lrc != WD_OK || splits <= 1) return lrc;
+  return special ? launch_reduce<true>(p, ws, splits, w_unscale, st) : launch_reduce<false>(p, ws, splits, w_unscale, st);
+}
+
+// cfg < 0: production choice.  Other values select a tile for on-device A/B runs.
+extern "C" int wd_conv_gemm_split(const WdConvGemm* pp, const void* w_split, float w_unscale, int32_t flags,
+                                  int32_t cfg, void* stream) {
+  return conv_gemm_split_impl(pp, w_split, w_unscale, flags, cfg, nullptr, 0, 0, static_cast<hipStream_t>(stream));
+}
+
+// The same with a caller-owned workspace (>= 16-byte aligned) that lets under-filled launches split K.
+// splits = 0: decided here (1 when the launch already fills the chip); > 0: forced (tests / A/B runs).
+extern "C" int wd_conv_gemm_split_ws(const WdConvGemm* pp, const void* w_split, float w_unscale, int32_t flags,
+                                     int32_t cfg, void* workspace, int64_t workspace_bytes, int32_t splits, void* stream) {
+  if (splits < 0 || workspace_bytes < 0) return WD_ERR_BAD_ARG;
+  return conv_gemm_split_impl(pp, w_split, w_unscale, flags, cfg, static_cast<float*>(workspace), workspace_bytes, splits,
+                              static_cast<hipStream_t>(stream));
 }

@@ -298,7 +298,7 @@ constexpr int split_waves_per_simd(int waves, int lds_bytes, int acc_tiles, bool
 template <int TM, int TN, int WM, int WN, int BKT, bool CONV, int VAR>
 __global__ void __launch_bounds__(64 * WM * WN, split_waves_per_simd(WM * WN, STile<TM, TN, WM, WN, BKT>::LDS_BYTES, TM * TN, (VAR & SVAR_PF2) != 0))
 split_gemm_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, const float* __restrict__ zero,
-                  int k16, float unscale, int nbn, int vec_c, int vec_res, int vec_bias) {
+                  int k16, float unscale, int nbn, int vec_c, int vec_res, int vec_bias, int ksplits, float* __restrict__ ws) {
   using T = STile<TM, TN, WM, WN, BKT>;
   constexpr int BK = T::BK, KS = T::KS, ROWB = T::ROWB, KCH = T::KCH, BM = T::BM, BN = T::BN;
   constexpr int A_PT = T::A_PT, B_PT = T::B_PT, RSTEP = T::RSTEP;
@@ -313,11 +313,20 @@ split_gemm_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, con
     const int q = nwg >> 3, r = nwg & 7;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
+  // split-K (ksplits > 1): workgroup (tile, ks) accumulates K stages [s_begin, s_end) and writes raw partial
+  // sums to ws[ks][m][n]; splitk_reduce_kernel adds them in a fixed order and applies the epilogue
+  const int ntiles = gridDim.x / ksplits;
+  const int ks = tile / ntiles;
+  tile -= ks * ntiles;
   const int bn = tile % nbn, bm = tile / nbn;
   const int m0 = bm * BM, n0 = bn * BN;
   const int kc = t % KCH, r0 = t / KCH;
   const int K = p.k;
-  const int nk = (K + BK - 1) / BK;
+  const int nk_all = (K + BK - 1) / BK;
+  const int per_split = (nk_all + ksplits - 1) / ksplits;
+  const int s_begin = ks * per_split;
+  const int nk = (s_begin + per_split < nk_all ? s_begin + per_split : nk_all) - s_begin;   // stages of this workgroup (may be <= 0)
+  const int kofs = s_begin * BK;
 
   ALoader<A_PT, RSTEP, CONV> al;
   al.init(p, m0, r0, zero);
@@ -419,22 +428,22 @@ split_gemm_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, con
     }
   };
 
-  load(0, Set0{});
+  load(kofs, Set0{});
   store(0, Set0{});
   __syncthreads();
   if (VAR & SVAR_PF2) {
     // stage s is computed from LDS buffer s & 1 while stage s+1 waits in registers and the loads
     // of stage s+2 are issued: a global load has a whole K stage of MFMAs to land
-    load(BK, Set1{});
+    load(kofs + BK, Set1{});
     for (int s = 0; s < nk; s += 2) {
-      load((s + 2) * BK, Set0{});
+      load(kofs + (s + 2) * BK, Set0{});
       if (VAR & SVAR_PIN) __builtin_amdgcn_sched_barrier(0);
       compute(0);
       if (VAR & SVAR_PIN) __builtin_amdgcn_sched_barrier(0);
       store(1, Set1{});
       __syncthreads();
       if (s + 1 >= nk) break;
-      load((s + 3) * BK, Set1{});
+      load(kofs + (s + 3) * BK, Set1{});
       if (VAR & SVAR_PIN) __builtin_amdgcn_sched_barrier(0);
       compute(1);
       if (VAR & SVAR_PIN) __builtin_amdgcn_sched_barrier(0);
@@ -444,7 +453,7 @@ split_gemm_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, con
   } else {
     int cur = 0;
     for (int kt = 1; kt < nk; ++kt) {
-      if (!(VAR & SABL_NOLOAD)) load(kt * BK, Set0{});
+      if (!(VAR & SABL_NOLOAD)) load(kofs + kt * BK, Set0{});
       if (VAR & SVAR_PIN) __builtin_amdgcn_sched_barrier(0);
       compute(cur);
       if (VAR & SVAR_PIN) __builtin_amdgcn_sched_barrier(0);
@@ -452,7 +461,7 @@ split_gemm_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, con
       if (!(VAR & SABL_NOBAR)) __syncthreads();
       cur ^= 1;
     }
-    compute(cur);
+    if (nk > 0) compute(cur);
   }
 
   if (VAR & SABL_NOEPI) {            // keep the accumulators live, store one value per lane
@@ -474,6 +483,13 @@ split_gemm_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, con
     static_assert(T::LDS_BYTES >= WM * WN * 32 * EPI_LDT * 4, "operand LDS must hold one patch per wave");
     __syncthreads();                                   // every wave is done reading the last operand stage
     float* patch = reinterpret_cast<float*>(smem_raw) + wave * 32 * EPI_LDT;
+    if (ksplits > 1) {
+      WdConvGemm pr = p;                               // raw partial sums, plain rows [m][n] of this split
+      pr.bias = nullptr; pr.res = nullptr; pr.c = ws + (size_t)ks * p.m * p.n; pr.ldc = p.n;
+      const EpiVec er{(p.n & 3) == 0, 0, 0, 1.0f};
+      split_epilogue_lds<TM, TN, WD_ACT_NONE, false>(pr, er, mw, nw, lane, acc, patch);
+      return;
+    }
     if (VAR & SVAR_CSPLIT) {          // host side guarantees: plain rows, bias 16-byte aligned, n % 8 == 0, no residual
       switch (p.act) {
         case WD_ACT_RELU: EpiCsplitWalk<0, TM, TN, WD_ACT_RELU>::run(p, ev, mw, nw, lane, acc, patch); break;
@@ -521,12 +537,13 @@ split_gemm_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, con
 
 // WHICH: 0 = instantiate the plain (1x1) and the implicit-im2col kernel, 1 = plain only, 2 = conv only
 template <int TM, int TN, int WM, int WN, int BKT, int VAR, int WHICH = 0>
-int launch_split(const WdConvGemm& p, const void* wsp, float unscale, hipStream_t st) {
+int launch_split(const WdConvGemm& p, const void* wsp, float unscale, hipStream_t st, int ksplits = 1, float* ws = nullptr) {
   using T = STile<TM, TN, WM, WN, BKT>;
   const bool conv = !(p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0);
   if ((WHICH == 1 && conv) || (WHICH == 2 && !conv)) return WD_ERR_UNSUPPORTED;
   const int nbm = (p.m + T::BM - 1) / T::BM, nbn = (p.n + T::BN - 1) / T::BN;
-  const long long nblk = (long long)nbm * nbn;
+  if (ksplits < 1 || (ksplits > 1 && (!ws || !(VAR & SVAR_LDSEPI) || (VAR & (SVAR_PF2 | SVAR_CSPLIT))))) return WD_ERR_BAD_ARG;
+  const long long nblk = (long long)nbm * nbn * ksplits;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return WD_ERR_BAD_ARG;
   const int k16 = (p.k + 15) / 16 * 16;
   const int vec_c = (p.ldc % 4 == 0) && wd_aligned16(p.c) && (p.out_mode == WD_OUT_ROWS || (p.n % 16 == 0));
@@ -548,7 +565,7 @@ int launch_split(const WdConvGemm& p, const void* wsp, float unscale, hipStream_
       attr_conv = true;
     }
     hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(T::NT), T::LDS_BYTES, st, p, w8, zero, k16, unscale, nbn,
-                       vec_c, vec_res, vec_bias);
+                       vec_c, vec_res, vec_bias, ksplits, ws);
     return wd_launch_status();
   }
   if constexpr (WHICH != 2) if (!conv) {
@@ -559,7 +576,7 @@ int launch_split(const WdConvGemm& p, const void* wsp, float unscale, hipStream_
       attr_plain = true;
     }
     hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(T::NT), T::LDS_BYTES, st, p, w8, zero, k16, unscale, nbn,
-                       vec_c, vec_res, vec_bias);
+                       vec_c, vec_res, vec_bias, ksplits, ws);
   }
   return wd_launch_status();
 }
@@ -593,4 +610,5 @@ int check_split_args(const WdConvGemm& p, const void* wsp, float unscale) {
 }  // namespace
 
 // defined in split_gemm_pre.hip: launch with pre-split activations (flags: WD_SPLIT_A / WD_SPLIT_C)
-int wd_launch_presplit(const WdConvGemm& p, const void* w_split, float w_unscale, int cfg, int flags, hipStream_t st);
+int wd_launch_presplit(const WdConvGemm& p, const void* w_split, float w_unscale, int cfg, int flags, hipStream_t st,
+                       int ksplits = 1, float* ws = nullptr);

@@ -27,7 +27,8 @@ constexpr int VA_PF2 = SVAR_XCD | SVAR_PF2 | SVAR_LDSEPI | SVAR_ASPLIT;
 template <int BK, int VAR>
 __global__ void __launch_bounds__(256, BK == 16 ? 4 : 3)
 split_gemm_glds_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, const float* __restrict__ zero,
-                       int k16, float unscale, int nbn, int vec_c, int vec_res, int vec_bias, int ngrp, int nbm) {
+                       int k16, float unscale, int nbn, int vec_c, int vec_res, int vec_bias, int ngrp, int nbm,
+                       int ksplits, float* __restrict__ ws) {
   constexpr int TM = 2, TN = 2, WN = 2, BM = 128, BN = 128, KS = BK / 16;
   constexpr int ROWB = BK * 4, CH = ROWB / 16, RPI = 64 / CH, NI = (BM / RPI) / 4, STAGE = (BM + BN) * ROWB;
   constexpr int FDIV = 16 / CH;
@@ -40,13 +41,20 @@ split_gemm_glds_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp
     const int q = nwg >> 3, r = nwg & 7;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
+  // split-K (ksplits > 1): see split_gemm_kernel
+  const int ntiles = gridDim.x / ksplits;
+  const int ks = tile / ntiles;
+  tile -= ks * ntiles;
   // raster order: column tiles are walked in groups of ngrp (all row panels of a group before the
   // next group), so the weight panels live at any time are ngrp * 128 rows instead of all of n
   const int gsz = ngrp * nbm;
   const int grp = tile / gsz, rem = tile - grp * gsz;
   const int bm = rem / ngrp, bn = grp * ngrp + (rem - bm * ngrp);
   const int m0 = bm * BM, n0 = bn * BN;
-  const int nk = p.k / BK;
+  const int nk_all = p.k / BK;
+  const int per_split = (nk_all + ksplits - 1) / ksplits;
+  const int s_begin = ks * per_split;
+  const int nk = (s_begin + per_split < nk_all ? s_begin + per_split : nk_all) - s_begin;
 
   // per-lane DMA sources: instruction j of this wave fills rows [(wave*NI + j)*RPI, +RPI) of the operand
   const unsigned char* pa[NI];
@@ -63,6 +71,8 @@ split_gemm_glds_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp
     pb[j] = bok ? wsp + (size_t)(n0 + row) * k16 * 4 + memchunk * 16 : reinterpret_cast<const unsigned char*>(zero);
     sa[j] = aok ? ROWB : 0;
     sb[j] = bok ? ROWB : 0;
+    pa[j] += (size_t)sa[j] * s_begin;
+    pb[j] += (size_t)sb[j] * s_begin;
   }
   auto issue = [&](int buf) {
     unsigned char* abase = smem_raw + buf * STAGE + wave * NI * RPI * ROWB;
@@ -100,7 +110,7 @@ split_gemm_glds_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp
   }
   const int hsel = lane >> 5;
 
-  issue(0);
+  if (nk > 0) issue(0);                               // an empty K split (never produced by the host side) writes zeros
   __syncthreads();
   for (int s = 0; s < nk; ++s) {
     const unsigned char* as = smem_raw + (s & 1) * STAGE;
@@ -144,6 +154,14 @@ split_gemm_glds_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp
     __syncthreads();                                   // DMA of stage s+1 landed (vmcnt 0), stage s fully read
   }
 
+  if (ksplits > 1) {
+    WdConvGemm pr = p;
+    pr.bias = nullptr; pr.res = nullptr; pr.c = ws + (size_t)ks * p.m * p.n; pr.ldc = p.n;
+    const EpiVec er{(p.n & 3) == 0, 0, 0, 1.0f};
+    split_epilogue_lds<TM, TN, WD_ACT_NONE, false>(pr, er, m0 + wm * TM * 32, n0 + wn * TN * 32, lane, acc,
+                                                   reinterpret_cast<float*>(smem_raw) + wave * 32 * EPI_LDT);
+    return;
+  }
   const EpiVec ev{vec_c, vec_res, vec_bias, unscale};
   const int mw = m0 + wm * TM * 32, nw = n0 + wn * TN * 32;
   float* patch = reinterpret_cast<float*>(smem_raw) + wave * 32 * EPI_LDT;
@@ -166,10 +184,11 @@ split_gemm_glds_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp
 }
 
 template <int BK, int VAR>
-int launch_glds(const WdConvGemm& p, const void* wsp, float unscale, hipStream_t st) {
+int launch_glds(const WdConvGemm& p, const void* wsp, float unscale, hipStream_t st, int ksplits = 1, float* ws = nullptr) {
   constexpr int STAGE = 256 * BK * 4, LDS = 2 * STAGE;
   const int nbm = (p.m + 127) / 128, nbn = (p.n + 127) / 128;
-  const long long nblk = (long long)nbm * nbn;
+  if (ksplits < 1 || (ksplits > 1 && (!ws || (VAR & SVAR_CSPLIT)))) return WD_ERR_BAD_ARG;
+  const long long nblk = (long long)nbm * nbn * ksplits;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return WD_ERR_BAD_ARG;
   const int k16 = (p.k + 15) / 16 * 16;
   const int vec_c = (p.ldc % 4 == 0) && wd_aligned16(p.c);
@@ -195,7 +214,7 @@ int launch_glds(const WdConvGemm& p, const void* wsp, float unscale, hipStream_t
     attr = true;
   }
   hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), LDS, st, p, static_cast<const unsigned char*>(wsp), zero, k16,
-                     unscale, nbn, vec_c, vec_res, vec_bias, ngrp, nbm);
+                     unscale, nbn, vec_c, vec_res, vec_bias, ngrp, nbm, ksplits, ws);
   return wd_launch_status();
 }
 
@@ -504,7 +523,8 @@ bool glds_ok(const WdConvGemm& p, int bk) {
 }
 }  // namespace
 
-int wd_launch_presplit(const WdConvGemm& p, const void* w, float unscale, int cfg, int flags, hipStream_t st) {
+int wd_launch_presplit(const WdConvGemm& p, const void* w, float unscale, int cfg, int flags, hipStream_t st, int ksplits,
+                       float* ws) {
   const bool csplit = (flags & WD_SPLIT_C) != 0;
   if (!(flags & WD_SPLIT_A)) return WD_ERR_UNSUPPORTED;            // C-only split: not needed by any layer yet
   if (p.k % 8 || p.cin % 8 || p.lda % 8) return WD_ERR_BAD_ARG;
@@ -522,7 +542,7 @@ int wd_launch_presplit(const WdConvGemm& p, const void* w, float unscale, int cf
       if (p.res || p.n % 8 || p.ldc % 8 || (p.bias && !wd_aligned16(p.bias)) || !wd_aligned16(p.c)) return WD_ERR_BAD_ARG;
       return launch_glds<16, SVAR_CSPLIT>(p, w, unscale, st);
     }
-    return launch_glds<16, 0>(p, w, unscale, st);
+    return launch_glds<16, 0>(p, w, unscale, st, ksplits, ws);
   }
   if (csplit) {
     const bool special = p.out_mode != WD_OUT_ROWS || p.c_batch_stride > 0 || p.seg_rows > 0 || p.sigmoid ||
@@ -536,8 +556,8 @@ int wd_launch_presplit(const WdConvGemm& p, const void* w, float unscale, int cf
     }
   }
   switch (cfg) {
-    case 50: return launch_split<2, 2, 2, 2, 32, VA, 0>(p, w, unscale, st);
-    case 51: return launch_split<2, 2, 2, 2, 16, VA, 0>(p, w, unscale, st);
+    case 50: return launch_split<2, 2, 2, 2, 32, VA, 0>(p, w, unscale, st, ksplits, ws);
+    case 51: return launch_split<2, 2, 2, 2, 16, VA, 0>(p, w, unscale, st, ksplits, ws);
     case 55: return launch_split<2, 2, 2, 2, 32, VA_PF2, 1>(p, w, unscale, st);
     default: return WD_ERR_UNSUPPORTED;
   }

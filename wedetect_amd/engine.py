@@ -34,12 +34,17 @@ class ImageTower:
 
     def __init__(self, arch, packed: Packed, batch: int, height: int, width: int, device="cuda",
                  max_classes: int = 256, nms_pre: int = 30000, max_out: int = 300,
-                 precision: Optional[str] = None):
+                 precision: Optional[str] = None, split_k: Optional[bool] = None):
         """``precision``: arithmetic of the dense convs / linears of backbone, neck and head —
         "fp32" = v_mfma_f32_16x16x4_f32 (conv_gemm.hip); "fp16x3" = three fp16 MFMA passes on
         operands split into (hi, lo) halves, fp32-equivalent accuracy at 2-2.5x the speed
         (split_gemm.hip).  The region x text similarity GEMM, depthwise convs, LayerNorm and
-        the post-process are fp32 in both modes.  None = $WEDETECT_PRECISION or DEFAULT_PRECISION."""
+        the post-process are fp32 in both modes.  None = $WEDETECT_PRECISION or DEFAULT_PRECISION.
+        ``split_k`` (fp16x3 only; None = $WEDETECT_SPLIT_K == "1", default off): let under-filled launches —
+        batch-1 inference, the coarsest maps — split their K loop over several workgroups and add the
+        partial sums in a second pass (wd_conv_gemm_split_ws): Base batch 1 10.6 -> 6.3 ms.  Off by default
+        because the split count depends on the batch size, so results are no longer bit-identical ACROSS
+        batch sizes (they stay deterministic, and within 1e-6 of the unsplit ones)."""
         self.a: ArchSpec = get_arch(arch) if isinstance(arch, str) else arch
         self.P = packed
         if precision is None:
@@ -48,6 +53,11 @@ class ImageTower:
             raise ValueError(f"precision must be one of {self.PRECISIONS}")
         self.precision = precision
         self.Ws: Dict[str, tuple] = {}          # weight name -> (split buffer, unscale), fp16x3 mode only
+        # split-K workspace for under-filled fp16x3 launches (small batches, the coarsest maps): partial sums [S][m][n]
+        if split_k is None:
+            split_k = os.environ.get("WEDETECT_SPLIT_K", "0") == "1"
+        self.kws = (torch.empty(16 << 20, dtype=torch.float32, device=torch.device(device))
+                    if precision == "fp16x3" and split_k else None)
         self.B, self.H, self.W = batch, height, width
         self.dev = torch.device(device)
         if height % 32 or width % 32:
@@ -131,7 +141,7 @@ class ImageTower:
                 wt = self.P[w]
                 ws = self.Ws[w] = L.split_weights(wt.view(wt.shape[0], -1))
         L.conv_gemm(a, None if ws is not None else self.P[w], self.P[b] if b else None, c, batch=self.B,
-                    w_split=ws, **kw)
+                    w_split=ws, workspace=self.kws if ws is not None else None, **kw)
 
     def _conv(self, a, w, b, c, *, hin, win, cin, lda, n, ldc, k=1, stride=1, act=L.ACT_NONE, res=None, ldres=0,
               res_alpha=1.0, **kw):

@@ -25,7 +25,7 @@ EXPORTS = (
     "wd_abi_version", "wd_strerror", "wd_sizeof_conv_gemm", "wd_conv_gemm", "wd_conv_gemm_tuned", "wd_conv_gemm_config", "wd_stem_patchify", "wd_dwconv7",
     "wd_layernorm_rows", "wd_l2norm_rows", "wd_dfl_decode", "wd_topk_workspace_bytes", "wd_topk_capacity",
     "wd_topk_candidates", "wd_nms_gather", "wd_retrieval_max",
-    "wd_split_weights_bytes", "wd_split_weights", "wd_conv_gemm_split", "wd_conv_gemm_split_config", "wd_layernorm_rows_split", "wd_letterbox_u8", "wd_retrieval_max_split", "wd_text_embed", "wd_attention_small", "wd_recall_scratch_floats", "wd_recall_match",
+    "wd_split_weights_bytes", "wd_split_weights", "wd_conv_gemm_split", "wd_conv_gemm_split_ws", "wd_conv_gemm_split_config", "wd_layernorm_rows_split", "wd_letterbox_u8", "wd_retrieval_max_split", "wd_text_embed", "wd_attention_small", "wd_recall_scratch_floats", "wd_recall_match",
 )
 
 
@@ -88,6 +88,7 @@ def _load():
     lib.wd_split_weights_bytes.argtypes = [i32, i32]
     lib.wd_split_weights.argtypes = [vp, i32, i32, f32, vp, vp]
     lib.wd_conv_gemm_split.argtypes = [C.POINTER(ConvGemm), vp, f32, i32, i32, vp]
+    lib.wd_conv_gemm_split_ws.argtypes = [C.POINTER(ConvGemm), vp, f32, i32, i32, vp, i64, i32, vp]
     lib.wd_layernorm_rows_split.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, f32, vp]
     lib.wd_retrieval_max_split.argtypes = [vp, vp, f32, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.wd_recall_scratch_floats.restype = i64
@@ -133,10 +134,11 @@ def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
 def conv_gemm(a, w, bias, c, *, batch, hin, win, cin, lda, kh=1, kw=1, stride=1, pad=0, hout=None, wout=None,
               n, ldc, act=ACT_NONE, res=None, ldres=0, res_alpha=1.0, out_mode=OUT_ROWS,
               out_scale=1.0, out_bias=0.0, sigmoid=False, c_batch_stride=0, seg=None, tuned_cfg=None,
-              w_split=None, split_cfg=-1, split_flags=0) -> None:
+              w_split=None, split_cfg=-1, split_flags=0, workspace=None, k_splits=0) -> None:
     """``seg`` = (seg_rows, seg_end0, seg_end1, (s0, s1, s2), (b0, b1, b2)) or None.
     ``w_split`` = (split weight buffer, unscale) from :func:`split_weights` selects the fp16x3 kernel;
-    ``split_flags`` = SPLIT_A / SPLIT_C: activations / output stored as fp16 hi/lo groups."""
+    ``split_flags`` = SPLIT_A / SPLIT_C: activations / output stored as fp16 hi/lo groups; ``workspace`` (a device
+    tensor) lets under-filled launches split K (``k_splits`` = 0: library's choice, > 0: forced)."""
     hout = (hin + 2 * pad - kh) // stride + 1 if hout is None else hout
     wout = (win + 2 * pad - kw) // stride + 1 if wout is None else wout
     p = ConvGemm(a=_p(a), w=_p(w), bias=_p(bias), res=_p(res), c=_p(c), batch=batch, hin=hin, win=win, cin=cin,
@@ -149,6 +151,11 @@ def conv_gemm(a, w, bias, c, *, batch, hin, win, cin, lda, kh=1, kw=1, stride=1,
         p.seg_scale = (C.c_float * 3)(*[float(v) for v in seg[3]])
         p.seg_bias = (C.c_float * 3)(*[float(v) for v in seg[4]])
     if w_split is not None:
+        if workspace is not None:
+            check(LIB.wd_conv_gemm_split_ws(C.byref(p), _p(w_split[0]), float(w_split[1]), int(split_flags), int(split_cfg),
+                                            _p(workspace), workspace.numel() * workspace.element_size(), int(k_splits),
+                                            stream_ptr()), f"wd_conv_gemm_split_ws[{split_cfg}]")
+            return
         check(LIB.wd_conv_gemm_split(C.byref(p), _p(w_split[0]), float(w_split[1]), int(split_flags), int(split_cfg),
                                      stream_ptr()),
               f"wd_conv_gemm_split[{split_cfg}]")
