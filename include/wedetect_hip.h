@@ -178,6 +178,33 @@ int wd_attention_small(const float* qkv, const int32_t* mask, float* out, int32_
                        int32_t head_dim, int32_t ld_qkv, int32_t ld_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Text-guided attention bricks (wedetect/models/layers/yolo_bricks.py).  Their
+ * convolutions / Linear layers / LayerNorms are wd_conv_gemm(_split) and wd_layernorm_rows; these are
+ * the remaining pieces.  All tensors fp32, NHWC rows, leading dimensions in floats (multiples of 4).
+ *   wd_max_sigmoid_attn — MaxSigmoidAttnBlock.forward 214-243 after its two convolutions:
+ *     embed rows [n_img * hw, >= heads * head_channels] (embed_conv output, or the input itself),
+ *     guide [n_img, n_guide, heads * head_channels] (guide_fc output), head_bias [heads], head_scale
+ *     [heads] or NULL (= 1).  For pixel r, head m:
+ *       a = sigmoid(max_n <embed[r, m, :], guide[img, n, m, :]> / sqrt(head_channels) + head_bias[m]) * head_scale[m]
+ *     and x[r, m * out_head_channels : (m + 1) * out_head_channels] (project_conv output) is multiplied by
+ *     a IN PLACE.  head_channels in {8, 16, 32, 64, 128}; out_head_channels % 4 == 0.
+ *   wd_adaptive_maxpool_nhwc — nn.AdaptiveMaxPool2d((pool, pool)) (yolo_bricks.py:609-612, 618-622) of
+ *     x [n_img, h, w, channels]: out[img * out_img_stride + cell * ld_out + c], cell = py * pool + px,
+ *     window [floor(i * H / pool), ceil((i + 1) * H / pool)) per axis.  The caller offsets ``out`` per
+ *     level to build the concatenated [n_img, levels * pool * pool, E] patch table.
+ *   wd_cross_attention_small — 624-646: out[img, r, m, :] = softmax_j(<q[img, r, m, :], k[img, j, m, :]>
+ *     / sqrt(head_dim)) . v[img, j, m, :]; q rows [n_img * n_q, ld_q], k / v rows [n_img * n_k, ld_kv],
+ *     n_k <= 64, head_dim in {8, 16, 32, 64}. */
+int wd_max_sigmoid_attn(const float* embed, int32_t ld_embed, const float* guide, const float* head_bias,
+                        const float* head_scale, float* x, int32_t ld_x, int32_t n_img, int32_t hw, int32_t n_guide,
+                        int32_t heads, int32_t head_channels, int32_t out_head_channels, void* stream);
+int wd_adaptive_maxpool_nhwc(const float* x, int32_t ld_x, float* out, int32_t ld_out, int64_t out_img_stride,
+                             int32_t n_img, int32_t h, int32_t w, int32_t channels, int32_t pool, void* stream);
+int wd_cross_attention_small(const float* q, int32_t ld_q, const float* k, const float* v, int32_t ld_kv, float* out,
+                             int32_t ld_out, int32_t n_img, int32_t n_q, int32_t n_k, int32_t heads, int32_t head_dim,
+                             void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * wd_recall_match — proposal-recall matching (eval_recall/recall.py:6-100): for
  * every image i and every proposal budget budgets[b], the greedy one-to-one assignment of the
  * reference over the fp32 IoU matrix of gts[gt_off[i]:gt_off[i+1]] x the first min(budget, count)

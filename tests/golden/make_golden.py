@@ -134,6 +134,8 @@ class _StubModule(types.ModuleType):
             return lambda t, *a, **k: t
         if item == "ConvModule":
             return _ConvModule
+        if item == "Linear":
+            return torch.nn.Linear
         if item and item[0].isupper():
             return _StubMeta(item, (torch.nn.Module,), {"__init__": lambda self, *a, **k: torch.nn.Module.__init__(self)})
         return lambda *a, **k: None
@@ -147,21 +149,48 @@ class _BaseModule(torch.nn.Module):
 
 
 class _ConvModule(torch.nn.Module):
-    """mmcv.cnn.ConvModule as the head uses it: conv(no bias) + BN + act (keys conv/bn)."""
+    """mmcv.cnn.ConvModule as the reference uses it: conv (bias only without a norm layer) -> BN -> activation
+    (``act_cfg=None`` = none; mmcv's default is ReLU); state-dict keys conv / bn."""
 
-    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, norm_cfg=None, act_cfg=None, **kw):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, norm_cfg=None,
+                 act_cfg=dict(type="ReLU"), **kw):
         super().__init__()
         self.conv = torch.nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, bias=norm_cfg is None)
-        self.bn = torch.nn.BatchNorm2d(out_channels, momentum=norm_cfg.get("momentum", 0.1), eps=norm_cfg.get("eps", 1e-5))
-        self.act = torch.nn.SiLU(inplace=False)
+        self.bn = None if norm_cfg is None else torch.nn.BatchNorm2d(out_channels, momentum=norm_cfg.get("momentum", 0.1),
+                                                                     eps=norm_cfg.get("eps", 1e-5))
+        kind = None if act_cfg is None else act_cfg.get("type")
+        self.act = {None: None, "SiLU": torch.nn.SiLU(inplace=False), "ReLU": torch.nn.ReLU(inplace=False)}[kind]
 
     def forward(self, x):
-        return self.act(self.bn(self.conv(x)))
+        x = self.conv(x)
+        if self.bn is not None:
+            x = self.bn(x)
+        return x if self.act is None else self.act(x)
+
+
+_STUBS_INSTALLED = False
+
+
+def install_stub_finder():
+    global _STUBS_INSTALLED
+    if not _STUBS_INSTALLED:
+        sys.meta_path.insert(0, _StubFinder())
+        _STUBS_INSTALLED = True
+
+
+def import_yolo_bricks():
+    """wedetect/models/layers/yolo_bricks.py with mmcv / mmdet / mmengine replaced by the stand-ins above."""
+    install_stub_finder()
+    spec = importlib.util.spec_from_file_location("refwd_yolo_bricks", os.path.join(REF, "wedetect", "models", "layers", "yolo_bricks.py"))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules["refwd_yolo_bricks"] = m
+    spec.loader.exec_module(m)
+    return m
 
 
 def import_wedetect_models():
     """Import the reference's mmdet-plugin model files with stubbed third parties."""
-    sys.meta_path.insert(0, _StubFinder())
+    install_stub_finder()
     root = os.path.join(REF, "wedetect", "models")
 
     # fake parent packages so that the files' relative imports resolve to stand-ins
@@ -508,8 +537,86 @@ def case_retrieval_metric():
     np.savez_compressed(os.path.join(OUT, "retrieval_metric.npz"), blob=np.asarray(blob))
 
 
+def _seed_module(mod: torch.nn.Module, seed: int):
+    """Deterministic, trained-like parameters for a small reference module (fixture carries them)."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for k, v in mod.state_dict().items():
+        if k.endswith("num_batches_tracked"):
+            continue
+        if k.endswith("running_var"):
+            t = torch.rand(v.shape, generator=g) + 0.5
+        elif k.endswith(("running_mean", "bias")) or k == "bias":
+            t = torch.randn(v.shape, generator=g) * 0.2
+        elif k.endswith("bn.weight") or k.endswith(".0.weight") and v.dim() == 1:
+            t = torch.rand(v.shape, generator=g) + 0.5
+        elif k == "scale":
+            t = torch.rand(v.shape, generator=g) + 0.25
+        else:
+            fan = max(1, v[0].numel()) if v.dim() > 1 else 1
+            t = torch.randn(v.shape, generator=g) / fan ** 0.5
+        out[k] = t.to(torch.float32)
+    missing = mod.load_state_dict(out, strict=False)
+    assert not missing.unexpected_keys and all(k.endswith("num_batches_tracked") for k in missing.missing_keys), missing
+    for m in mod.modules():
+        m.training = False
+    return out
+
+
+def case_bricks():
+    """Text-guided attention bricks (yolo_bricks.py:161-243, 572-648) run as the reference classes; the oracle
+    restatement (oracle/bricks.py) must reproduce them bit for bit.  The fixture carries parameters, inputs and
+    full outputs (all small)."""
+    import json
+    from oracle import bricks as obr
+    yb = import_yolo_bricks()
+    fx = {}
+    g = torch.Generator().manual_seed(77)
+    msa_cases = [
+        dict(in_channels=32, out_channels=64, guide_channels=48, embed_channels=64, num_heads=2, with_scale=False, b=2, h=12, w=9, n=5),
+        dict(in_channels=32, out_channels=32, guide_channels=40, embed_channels=32, num_heads=2, with_scale=True, b=1, h=7, w=16, n=80),
+        dict(in_channels=64, out_channels=64, guide_channels=24, embed_channels=64, num_heads=1, with_scale=True, b=3, h=5, w=5, n=1),
+    ]
+    for j, c in enumerate(msa_cases):
+        kw = {k: c[k] for k in ("in_channels", "out_channels", "guide_channels", "embed_channels", "num_heads", "with_scale")}
+        mod = yb.MaxSigmoidAttnBlock(**kw)
+        p = _seed_module(mod, 100 + j)
+        x = torch.randn(c["b"], c["in_channels"], c["h"], c["w"], generator=g)
+        guide = torch.randn(c["b"], c["n"], c["guide_channels"], generator=g)
+        ref = mod(x, guide)
+        must_equal(f"bricks.msa{j}", ref, obr.max_sigmoid_attn(x, guide, p, c["num_heads"]))
+        fx[f"msa{j}.cfg"] = np.asarray(json.dumps(c))
+        fx[f"msa{j}.x"], fx[f"msa{j}.guide"], fx[f"msa{j}.out"] = x.numpy(), guide.numpy(), ref.numpy()
+        for k, v in p.items():
+            fx[f"msa{j}.p.{k}"] = v.numpy()
+    ipa_cases = [
+        dict(image_channels=[16, 24, 32], text_channels=48, embed_channels=64, num_heads=4, with_scale=False, b=2, n=5,
+             sizes=[[13, 11], [7, 7], [4, 5]]),
+        dict(image_channels=[8, 16, 16], text_channels=64, embed_channels=64, num_heads=2, with_scale=True, b=1, n=80,
+             sizes=[[9, 9], [6, 3], [3, 3]]),
+    ]
+    for j, c in enumerate(ipa_cases):
+        kw = {k: c[k] for k in ("image_channels", "text_channels", "embed_channels", "num_heads", "with_scale")}
+        mod = yb.ImagePoolingAttentionModule(**kw)
+        p = _seed_module(mod, 200 + j)
+        text = torch.randn(c["b"], c["n"], c["text_channels"], generator=g)
+        feats = [torch.randn(c["b"], ch, hh, ww, generator=g) for ch, (hh, ww) in zip(c["image_channels"], c["sizes"])]
+        ref = mod(text, feats)
+        must_equal(f"bricks.ipa{j}", ref, obr.image_pooling_attention(text, feats, p, c["num_heads"]))
+        fx[f"ipa{j}.cfg"] = np.asarray(json.dumps(c))
+        fx[f"ipa{j}.text"], fx[f"ipa{j}.out"] = text.numpy(), ref.numpy()
+        for l, f in enumerate(feats):
+            fx[f"ipa{j}.feat{l}"] = f.numpy()
+        for k, v in p.items():
+            fx[f"ipa{j}.p.{k}"] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "bricks.npz"), **fx)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference tree not present: goldens can only be generated in the build container"
+    if "--only-bricks" in sys.argv:
+        case_bricks()
+        sys.exit(0)
     # transformers probes torchvision at import: the plugin files (which import it) must be
     # loaded BEFORE the bare torchvision stand-in goes into sys.modules (SURVEY.md §8c-i)
     case_mmdet_modules("tiny", 64)
@@ -524,4 +631,5 @@ if __name__ == "__main__":
     case_letterbox(gp)
     case_recall()
     case_retrieval_metric()
+    case_bricks()
     print("all golden fixtures written to", OUT)

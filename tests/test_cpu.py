@@ -222,6 +222,28 @@ def test_recall_oracle_and_retrieval_metric_match_reference_goldens():
     assert got == rec["result"]
 
 
+def test_bricks_oracle_matches_reference_goldens():
+    """oracle/bricks.py vs the outputs of the reference's MaxSigmoidAttnBlock / ImagePoolingAttentionModule
+    (yolo_bricks.py:161-243, 572-648) recorded by make_golden.py (where the match was bit-exact; 1e-6 here allows
+    for a different CPU's conv / matmul kernels)."""
+    import json
+    from oracle import bricks as obr
+    fx = golden("bricks.npz")
+    t = lambda k: torch.from_numpy(fx[k])
+    for j in range(3):
+        c = json.loads(str(fx[f"msa{j}.cfg"]))
+        p = {k[len(f"msa{j}.p."):]: t(k) for k in fx.files if k.startswith(f"msa{j}.p.")}
+        assert ("embed_conv.conv.weight" in p) == (c["embed_channels"] != c["in_channels"])
+        out = obr.max_sigmoid_attn(t(f"msa{j}.x"), t(f"msa{j}.guide"), p, c["num_heads"])
+        assert_close(f"msa{j}", out, fx[f"msa{j}.out"], 1e-6, 1e-6)
+    for j in range(2):
+        c = json.loads(str(fx[f"ipa{j}.cfg"]))
+        p = {k[len(f"ipa{j}.p."):]: t(k) for k in fx.files if k.startswith(f"ipa{j}.p.")}
+        feats = [t(f"ipa{j}.feat{l}") for l in range(len(c["image_channels"]))]
+        out = obr.image_pooling_attention(t(f"ipa{j}.text"), feats, p, c["num_heads"])
+        assert_close(f"ipa{j}", out, fx[f"ipa{j}.out"], 1e-6, 1e-6)
+
+
 def test_instance_data_surface():
     from wedetect_amd.detector import InstanceData
     d = InstanceData(bboxes=torch.arange(12.).view(3, 4), scores=torch.tensor([0.9, 0.2, 0.5]), labels=torch.tensor([1, 2, 3]))

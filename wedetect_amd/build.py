@@ -15,36 +15,52 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwedetect_hip.so")
-SOURCES = ["abi.hip", "conv_gemm.hip", "split_gemm.hip", "split_gemm_pre.hip", "elementwise.hip", "preprocess.hip", "text.hip", "evaluate.hip", "postprocess.hip"]
+SOURCES = ["abi.hip", "conv_gemm.hip", "split_gemm.hip", "split_gemm_pre.hip", "elementwise.hip", "preprocess.hip", "text.hip", "bricks.hip", "evaluate.hip", "postprocess.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-inline-asm",
          "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+
+
+def _headers():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(ROOT, "include", "wedetect_hip.h")]
+
+
+def _obj(src: str) -> str:
+    return os.path.join(CSRC, src.replace(".hip", ".o"))
+
+
+def _obj_stale(src: str) -> bool:
+    obj = _obj(src)
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    return any(os.path.getmtime(d) > t for d in [os.path.join(CSRC, src)] + _headers())
 
 
 def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "wedetect_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(_obj_stale(s) or os.path.getmtime(_obj(s)) > t for s in SOURCES)
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
+    """Recompiles the sources whose object is older than the source or any header (all of them in a fresh
+    checkout: objects are not tracked), in parallel, then links."""
     if not force and not _stale():
         return LIB
-    objs = []
     procs = []
     for src in SOURCES:
-        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        objs.append(obj)
-        cmd = [HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        if not force and not _obj_stale(src):
+            continue
+        cmd = [HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", _obj(src)]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd)))
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *[_obj(s) for s in SOURCES], "-o", LIB]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

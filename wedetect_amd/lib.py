@@ -19,13 +19,14 @@ LIB_PATH = os.path.join(_HERE, "libwedetect_hip.so")
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU = 0, 1, 2, 3
 OUT_ROWS, OUT_DECONV2X2 = 0, 1
 SPLIT_A, SPLIT_C = 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 EXPORTS = (
     "wd_abi_version", "wd_strerror", "wd_sizeof_conv_gemm", "wd_conv_gemm", "wd_conv_gemm_tuned", "wd_conv_gemm_config", "wd_stem_patchify", "wd_dwconv7",
     "wd_layernorm_rows", "wd_l2norm_rows", "wd_dfl_decode", "wd_topk_workspace_bytes", "wd_topk_capacity",
     "wd_topk_candidates", "wd_nms_gather", "wd_retrieval_max",
     "wd_split_weights_bytes", "wd_split_weights", "wd_conv_gemm_split", "wd_conv_gemm_split_ws", "wd_conv_gemm_split_config", "wd_layernorm_rows_split", "wd_letterbox_u8", "wd_retrieval_max_split", "wd_text_embed", "wd_attention_small", "wd_recall_scratch_floats", "wd_recall_match",
+    "wd_max_sigmoid_attn", "wd_adaptive_maxpool_nhwc", "wd_cross_attention_small",
 )
 
 
@@ -96,6 +97,9 @@ def _load():
     lib.wd_recall_match.argtypes = [vp, vp, vp, vp, i32, vp, i32, vp, i64, vp, i32, i32, vp]
     lib.wd_text_embed.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, vp]
     lib.wd_attention_small.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    lib.wd_max_sigmoid_attn.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.wd_adaptive_maxpool_nhwc.argtypes = [vp, i32, vp, i32, i64, i32, i32, i32, i32, i32, vp]
+    lib.wd_cross_attention_small.argtypes = [vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.wd_letterbox_u8.argtypes = [vp, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.wd_conv_gemm_split_config.restype = C.c_char_p
     lib.wd_conv_gemm_split_config.argtypes = [i32, i32, i32, i32]
@@ -267,3 +271,23 @@ def text_embed(ids, pos_ids, word, pos, type0, out) -> None:
 def attention_small(qkv, mask, out, n_seq, seq_len, heads, head_dim) -> None:
     check(LIB.wd_attention_small(_p(qkv), _p(mask), _p(out), n_seq, seq_len, heads, head_dim, qkv.shape[1], out.shape[1],
                                  stream_ptr()), "wd_attention_small")
+
+
+def max_sigmoid_attn(embed, guide, head_bias, head_scale, x, n_img, hw, n_guide, heads, head_channels, out_head_channels) -> None:
+    """``embed`` / ``x``: 2-d row views [n_img * hw, ld]; ``x`` is scaled in place."""
+    check(LIB.wd_max_sigmoid_attn(_p(embed), embed.stride(0), _p(guide), _p(head_bias), _p(head_scale), _p(x), x.stride(0),
+                                  n_img, hw, n_guide, heads, head_channels, out_head_channels, stream_ptr()),
+          "wd_max_sigmoid_attn")
+
+
+def adaptive_maxpool_nhwc(x, out, out_img_stride, n_img, h, w, channels, pool) -> None:
+    """``x``: rows [n_img * h * w, ld]; ``out``: rows of the patch table starting at this level's first cell."""
+    check(LIB.wd_adaptive_maxpool_nhwc(_p(x), x.stride(0), _p(out), out.stride(0), out_img_stride, n_img, h, w, channels, pool,
+                                       stream_ptr()), "wd_adaptive_maxpool_nhwc")
+
+
+def cross_attention_small(q, k, v, out, n_img, n_q, n_k, heads, head_dim) -> None:
+    if k.stride(0) != v.stride(0):
+        raise WedetectHipError("k and v must share their row pitch")
+    check(LIB.wd_cross_attention_small(_p(q), q.stride(0), _p(k), _p(v), k.stride(0), _p(out), out.stride(0), n_img, n_q, n_k,
+                                       heads, head_dim, stream_ptr()), "wd_cross_attention_small")
