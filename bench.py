@@ -43,7 +43,7 @@ KERNEL_SYMBOL = {
     "128x128x16/8w/conv": "conv_gemm_kernel<2, 4, 4, 2, true, 16, 256>",
     "64x128x16/4w/plain": "conv_gemm_kernel<2, 4, 2, 2, false, 16, 256>",
     "64x128x16/4w/conv": "conv_gemm_kernel<2, 4, 2, 2, true, 16, 256>",
-    "128x80x32/8w/plain": "conv_gemm_kernel<1, 5, 8, 1, false, 32, 258>",
+    "64x80x32/4w/plain": "conv_gemm_kernel<1, 5, 4, 1, false, 32, 258>",
     "fp16x3 128x128x16/4w/plain": "split_gemm_kernel<2, 2, 2, 2, 16, false, 770>",
     "fp16x3 128x128x16/4w/conv": "split_gemm_kernel<2, 2, 2, 2, 16, true, 770>",
     "fp16x3 128x128x32/4w/plain": "split_gemm_kernel<2, 2, 2, 2, 32, false, 770>",
@@ -97,19 +97,38 @@ def parse():
 
 
 class GemmTimer:
-    """HIP-event brackets around selected wd_conv_gemm launches on the launch stream."""
+    """Per-launch durations of the wd_conv_gemm launches inside the timed region, without disturbing it: every
+    launch carries a pre-created HIP event pair that the kernel's own dispatch stamps with its begin / end
+    (wd_time_next_gemm -> hipExtLaunchKernelGGL on the launch stream).  An hipEventRecord pair around each launch
+    would add ~5 us of idle per launch — 1.2 ms to this 48 ms step (scripts/step_timer_overhead.py).
+    mode: "off" | "count" (warm-up: how many launches a step makes) | "time"."""
 
     def __init__(self, lib):
         self.lib = lib
-        self.rec = {}          # tag -> list of (start, end, flops)
-        self.on = False
+        self.rec = {}          # tag -> list of (start, end, flops, bytes)
+        self.mode = "off"
+        self.count = 0
+        self.pool = []
         self._orig = lib.conv_gemm
+
+    @staticmethod
+    def _pair():
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()             # creates the underlying hipEvent_t (torch does it lazily)
+        e.record()
+        return s, e
+
+    def prepare(self, n_launches: int):
+        """Event pairs for the timed region, created (and drained from the stream) before it starts."""
+        self.pool = [self._pair() for _ in range(n_launches)]
+        torch.cuda.synchronize()
 
     def install(self):
         orig, rec, lib = self._orig, self.rec, self.lib
 
         def wrapped(a, w, bias, c, **kw):
-            if not self.on:
+            if self.mode != "time":
+                self.count += self.mode == "count"
                 return orig(a, w, bias, c, **kw)
             kh, kw_ = kw.get("kh", 1), kw.get("kw", 1)
             hin, win, stride, pad = kw["hin"], kw["win"], kw.get("stride", 1), kw.get("pad", 0)
@@ -119,10 +138,9 @@ class GemmTimer:
             plain = kh == 1 and kw_ == 1 and stride == 1 and pad == 0
             tag = lib.gemm_config(m, n, k, split=kw.get("w_split") is not None, conv=not plain,
                                   presplit=bool(kw.get("split_flags", 0))) + ("/plain" if plain else "/conv")
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
+            s, e = self.pool.pop() if self.pool else self._pair()
+            lib.time_next_gemm(s, e)
             orig(a, w, bias, c, **kw)
-            e.record()
             # algorithmic HBM bytes: A (or the NHWC input once), W, C, residual — fp32
             a_elems = kw["batch"] * hin * win * kw["cin"]
             nbytes = 4.0 * (a_elems + n * k + m * n * (2 if kw.get("res") is not None else 1))
@@ -259,16 +277,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    timer.mode = "count"
     for _ in range(args.warmup):
         step()
     sync()
-    timer.on = True
+    # per-launch kernel timing covers the LAST n_inst steps of the timed region only: stamping every launch costs the
+    # step ~1.2 ms (2.4 %: scripts/step_timer_overhead.py), so the headline would otherwise measure its own probe
+    n_inst = min(args.steps, 1 if args.steps < 4 else 2)
+    timer.prepare(timer.count // max(1, args.warmup) * n_inst)
+    timer.mode = "off"
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if i == args.steps - n_inst:
+            timer.mode = "time"
         res = step()
     sync()
     dt = time.perf_counter() - t0
-    timer.on = False
+    timer.mode = "off"
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -281,7 +306,7 @@ def main():
         dom = summ[dom_tag]
         sim_tag = L.gemm_config(B * tower.ntot, K, 768) + "/plain"
         sim = summ.get(sim_tag)
-        flops_img = sum(v["flops_total"] for v in summ.values()) / (args.steps * B)
+        flops_img = sum(v["flops_total"] for v in summ.values()) / (n_inst * B)
         dom_split = dom_tag.startswith("fp16x3")
         # fp16x3 issues three fp16 MFMA passes per fp32-accurate product: the roof for ALGORITHMIC
         # flops is the fp16 dense peak / 3; the fraction of the raw fp16 peak is reported beside it.
@@ -322,10 +347,13 @@ def main():
                              "frac_of_fp16_peak": round(SPLIT_PASSES * dom["tflops"] / F16_MFMA_PEAK_TFLOPS, 4)} if dom_split else {}),
                          "traffic": measured_traffic(dom_tag) if (B, S, K, args.arch, args.mode) == (32, 640, 80, "base", "detect") else None,
                          "traffic_unit": "HBM bytes per launch (PMC, separate rocprofv3 passes)",
+                         "timing": "HIP events stamped by each kernel's own dispatch (hipExtLaunchKernelGGL via "
+                                   f"wd_time_next_gemm) on the launch stream, every GEMM launch of the last {n_inst} of the "
+                                   f"{args.steps} timed steps (stamping all steps would slow the step it measures by 2.4 %)",
                          "algorithmic_bytes_per_launch": round(dom["bytes_total"] / dom["launches"]),
-                         "launches_per_step": dom["launches"] // args.steps, "avg_launch_us": round(dom["avg_us"], 2),
+                         "launches_per_step": dom["launches"] // n_inst, "avg_launch_us": round(dom["avg_us"], 2),
                          "algorithmic_gflop_per_launch": round(dom["flops_total"] / dom["launches"] / 1e9, 3)},
-            "gemm_kernels": {k: {"launches_per_step": v["launches"] // args.steps, "avg_us": round(v["avg_us"], 2),
+            "gemm_kernels": {k: {"launches_per_step": v["launches"] // n_inst, "avg_us": round(v["avg_us"], 2),
                                  "tflops": round(v["tflops"], 2)} for k, v in sorted(summ.items())},
         }
         if sim is not None:

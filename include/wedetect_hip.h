@@ -221,6 +221,15 @@ int wd_recall_match(const float* gts, const int32_t* gt_off, const float* props,
 int wd_layernorm_rows_split(const float* x, void* y, const float* gamma, const float* beta, int64_t rows, int32_t c,
                             int32_t ldx, int32_t ldy, float eps, void* stream);
 
+/* Profiling hook.  The next GEMM kernel that wd_conv_gemm / wd_conv_gemm_tuned / wd_conv_gemm_split(_ws) /
+ * wd_retrieval_max_split launches from the CALLING THREAD stamps its own begin and end into the two
+ * hipEvent_t (created with timing enabled): hipEventElapsedTime(start, stop) is then that kernel's
+ * duration as the hardware saw it — hipExtLaunchKernelGGL, so no barrier packets are added to the
+ * stream and the step being measured is not disturbed (an hipEventRecord pair around a launch costs
+ * ~5 us of idle per launch).  One-shot: cleared by the launch it applies to; (NULL, NULL) clears it.
+ * With split K (wd_conv_gemm_split_ws choosing > 1 splits) only the first of the two kernels is stamped. */
+int wd_time_next_gemm(void* start_event, void* stop_event);
+
 /* sizeof(WdConvGemm) as compiled into the library, so a binding can verify its mirror. */
 int wd_sizeof_conv_gemm(void);
 

@@ -25,7 +25,9 @@ SHAPES = {
     "conv3 128->256 @80 silu": dict(conv=(32, 80, 80, 128, 256)),
     "conv3 512->256 @20 silu": dict(conv=(32, 20, 20, 512, 256)),
 }
-GROUPS = {"big": [3, 22, 13, 3, 22], "sim": [10, 10], "conv": [3, 13]}
+GROUPS = {"big": [3, 22, 13, 3, 22], "sim": [10, 19, 19], "conv": [3, 13]}
+if os.environ.get("SIM_CFGS"):
+    GROUPS["sim"] = [int(c) for c in os.environ["SIM_CFGS"].split(",")]
 reps = int(os.environ.get("REPS", "8"))
 only = os.environ.get("ONLY")
 for name, sh in SHAPES.items():

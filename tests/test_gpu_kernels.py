@@ -386,3 +386,39 @@ def test_nms_iou_is_exactly_the_fp32_formula_near_the_threshold(L):
     expect = np.asarray(expect)
     assert 0.2 < np.mean(expect == 1) < 0.8, "the construction must straddle the threshold"
     assert np.array_equal(oc, expect), f"{int(np.sum(oc != expect))} of {n} near-threshold decisions differ"
+
+
+def test_time_next_gemm_stamps_exactly_one_launch():
+    """wd_time_next_gemm: the events carry the kernel's own begin / end (no stream barriers), for one launch only;
+    the reading agrees with (and never exceeds) an event pair recorded around the same launch."""
+    from wedetect_amd import lib as L
+    m, n, k = 65536, 256, 512
+    a = torch.randn(m, k, device="cuda")
+    w = torch.randn(n, k, device="cuda") * k ** -0.5
+    c = torch.empty(m, n, device="cuda")
+    ws = L.split_weights(w)
+    kw = dict(batch=1, hin=1, win=m, cin=k, lda=k, n=n, ldc=n)
+    for split in (None, ws):
+        run = lambda: L.conv_gemm(a, None if split else w, None, c, w_split=split, **kw)
+        for _ in range(3):
+            run()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        for e in ev:
+            e.record()                                     # materialise the hipEvent_t handles
+        torch.cuda.synchronize()
+        ev[0].record()
+        L.time_next_gemm(ev[1], ev[2])
+        run()                                              # stamped
+        ev[3].record()
+        run()                                              # not stamped: the hook is one-shot
+        torch.cuda.synchronize()
+        inner, outer = ev[1].elapsed_time(ev[2]), ev[0].elapsed_time(ev[3])
+        flops = 2.0 * m * n * k
+        assert 0.0 < inner <= outer * 1.02, (inner, outer)
+        assert inner > outer * 0.5, (inner, outer)         # same launch: the bracket adds microseconds, not multiples
+        assert flops / (inner * 1e-3) / 1e12 < (900.0 if split else 160.0)   # below the MFMA roofs: a real duration
+        L.time_next_gemm(ev[4], ev[5])
+        L.check(L.LIB.wd_time_next_gemm(None, None), "clear")
+        run()                                              # cleared: ev[4], ev[5] keep their old stamps
+        torch.cuda.synchronize()
+        assert abs(ev[4].elapsed_time(ev[5])) < 1.0

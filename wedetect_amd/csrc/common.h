@@ -1,6 +1,7 @@
 // Shared device/host helpers for the gfx950 kernels.  CDNA4 only: wave = 64 lanes.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include "wedetect_hip.h"
 
@@ -11,6 +12,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 static inline int wd_launch_status() {
   return hipGetLastError() == hipSuccess ? WD_OK : WD_ERR_LAUNCH;
 }
+
+// wd_time_next_gemm (abi.hip): events the next GEMM launch of this thread stamps with its own begin / end
+struct WdLaunchTiming { hipEvent_t start, stop; };
+extern thread_local WdLaunchTiming wd_launch_timing;
+
+// every GEMM kernel launch goes through this: a plain launch, or — once, after wd_time_next_gemm — one whose
+// dispatch carries the two events (hipExtLaunchKernelGGL: kernel begin / end timestamps, no barrier packets)
+#define WD_LAUNCH_GEMM(kern, grid, block, lds, st, ...)                                      \
+  do {                                                                                       \
+    const WdLaunchTiming wd_t_ = wd_launch_timing;                                           \
+    if (wd_t_.start || wd_t_.stop) {                                                         \
+      wd_launch_timing = WdLaunchTiming{nullptr, nullptr};                                   \
+      hipExtLaunchKernelGGL(kern, grid, block, lds, st, wd_t_.start, wd_t_.stop, 0, __VA_ARGS__); \
+    } else {                                                                                 \
+      hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                           \
+    }                                                                                        \
+  } while (0)
 
 static inline bool wd_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

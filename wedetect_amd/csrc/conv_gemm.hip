@@ -440,7 +440,7 @@ int launch_cfg(const WdConvGemm& p, hipStream_t st) {
                               T::LDS_BYTES) != hipSuccess) return WD_ERR_LAUNCH;
       attr_conv = true;
     }
-    hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(T::NT), T::LDS_BYTES, st, p, nbn, vec_c, vec_res, vec_bias);
+    WD_LAUNCH_GEMM(k, dim3((unsigned)nblk), dim3(T::NT), T::LDS_BYTES, st, p, nbn, vec_c, vec_res, vec_bias);
   } else {
     auto k = conv_gemm_kernel<TM, TN, WM, WN, false, BKT, VAR>;
     if (!attr_plain) {
@@ -448,7 +448,7 @@ int launch_cfg(const WdConvGemm& p, hipStream_t st) {
                               T::LDS_BYTES) != hipSuccess) return WD_ERR_LAUNCH;
       attr_plain = true;
     }
-    hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(T::NT), T::LDS_BYTES, st, p, nbn, vec_c, vec_res, vec_bias);
+    WD_LAUNCH_GEMM(k, dim3((unsigned)nblk), dim3(T::NT), T::LDS_BYTES, st, p, nbn, vec_c, vec_res, vec_bias);
   }
   return wd_launch_status();
 }
@@ -486,7 +486,7 @@ extern "C" const char* wd_conv_gemm_config(int32_t m, int32_t n, int32_t k) {
   switch (pick_bn(n)) {
     case 128: return use_small_tile(m, n) ? "64x128x16/4w" : "128x128x16/8w";
     case 96: return "128x96x16/8w";
-    case 80: return "128x80x32/8w";
+    case 80: return "64x80x32/4w";
     case 64: return "128x64x16/8w";
     default: return "128x48x16/8w";
   }
@@ -522,7 +522,9 @@ extern "C" int wd_conv_gemm(const WdConvGemm* pp, void* stream) {
       return use_small_tile(p.m, p.n) ? launch_cfg<2, 4, 2, 2, 16, VAR_XCD>(p, st)
                                       : launch_cfg<2, 4, 4, 2, 16, VAR_XCD>(p, st);
     case 96: return launch_cfg<1, 6, 8, 1, 16, VAR_XCD>(p, st);
-    case 80: return launch_cfg<1, 5, 8, 1, 32, VAR_XCD | VAR_PIN>(p, st);   // the similarity GEMM: pinned order +2..5 %, K step 32 +3 % (profiles/r01_gemm_ab.txt)
+    // the similarity GEMM: pinned order +2..5 %, K step 32 +3 %, 64-row tiles of 4 waves (4200 instead of 2100
+    // tiles at B = 32: a shorter tail) +2 % inside the step (profiles/r01_gemm_ab.txt)
+    case 80: return launch_cfg<1, 5, 4, 1, 32, VAR_XCD | VAR_PIN>(p, st);
     case 64: return launch_cfg<1, 4, 8, 1, 16, VAR_XCD>(p, st);
     default: return launch_cfg<1, 3, 8, 1, 16, VAR_XCD>(p, st);
   }
@@ -545,7 +547,7 @@ extern "C" int wd_conv_gemm_tuned(const WdConvGemm* pp, int32_t cfg, void* strea
     case 7: return launch_cfg<1, 8, 4, 1, 16, VAR_XCD>(p, st);            // 64x128x16, 4 waves
     case 8: return launch_cfg<1, 4, 4, 1, 16, VAR_XCD>(p, st);            // 64x64x16, 4 waves
     case 9: return launch_cfg<1, 4, 8, 1, 16, VAR_XCD>(p, st);            // 128x64x16, 8 waves (production, n = 64)
-    case 10: return launch_cfg<1, 5, 8, 1, 16, VAR_XCD>(p, st);           // 128x80x16, 8 waves (production, n = 80)
+    case 10: return launch_cfg<1, 5, 8, 1, 16, VAR_XCD>(p, st);           // 128x80x16, 8 waves
     case 11: return launch_cfg<4, 5, 4, 1, 32, 0>(p, st);                 // 256x80x32, 4 waves (first cut)
     case 12: return launch_cfg<2, 5, 8, 1, 16, VAR_XCD>(p, st);           // 256x80x16, 8 waves
     case 13: return launch_cfg<2, 4, 2, 2, 16, VAR_XCD>(p, st);           // 64x128x16, 4 waves (production, small problems)
@@ -553,7 +555,9 @@ extern "C" int wd_conv_gemm_tuned(const WdConvGemm* pp, int32_t cfg, void* strea
     case 15: return launch_cfg<2, 4, 2, 2, 16, VAR_XCD | VAR_PIN>(p, st);
     case 16: return launch_cfg<1, 5, 8, 1, 16, VAR_XCD | VAR_PIN>(p, st);
     case 17: return launch_cfg<1, 4, 8, 1, 16, VAR_XCD | VAR_PIN>(p, st);
-    case 19: return launch_cfg<1, 5, 8, 1, 32, VAR_XCD | VAR_PIN>(p, st);  // 128x80x32, 8 waves (production, n = 80)
+    case 19: return launch_cfg<1, 5, 8, 1, 32, VAR_XCD | VAR_PIN>(p, st);  // 128x80x32, 8 waves
+    case 25: return launch_cfg<1, 5, 4, 1, 32, VAR_XCD | VAR_PIN>(p, st);  // 64x80x32, 4 waves (production, n = 80)
+    case 26: return launch_cfg<2, 5, 4, 1, 32, VAR_XCD | VAR_PIN>(p, st);  // 128x80x32, 4 waves of 32 rows
     case 20: return launch_cfg<2, 4, 4, 2, 16, VAR_XCD | ABL_NOLOAD>(p, st);
     case 21: return launch_cfg<2, 4, 4, 2, 16, VAR_XCD | ABL_NOBAR>(p, st);
     case 22: return launch_cfg<2, 4, 4, 2, 16, VAR_XCD | ABL_NOEPI>(p, st);

@@ -564,7 +564,7 @@ int launch_split(const WdConvGemm& p, const void* wsp, float unscale, hipStream_
                               T::LDS_BYTES) != hipSuccess) return WD_ERR_LAUNCH;
       attr_conv = true;
     }
-    hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(T::NT), T::LDS_BYTES, st, p, w8, zero, k16, unscale, nbn,
+    WD_LAUNCH_GEMM(k, dim3((unsigned)nblk), dim3(T::NT), T::LDS_BYTES, st, p, w8, zero, k16, unscale, nbn,
                        vec_c, vec_res, vec_bias, ksplits, ws);
     return wd_launch_status();
   }
@@ -575,7 +575,7 @@ int launch_split(const WdConvGemm& p, const void* wsp, float unscale, hipStream_
                               T::LDS_BYTES) != hipSuccess) return WD_ERR_LAUNCH;
       attr_plain = true;
     }
-    hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(T::NT), T::LDS_BYTES, st, p, w8, zero, k16, unscale, nbn,
+    WD_LAUNCH_GEMM(k, dim3((unsigned)nblk), dim3(T::NT), T::LDS_BYTES, st, p, w8, zero, k16, unscale, nbn,
                        vec_c, vec_res, vec_bias, ksplits, ws);
   }
   return wd_launch_status();

@@ -213,7 +213,7 @@ int launch_glds(const WdConvGemm& p, const void* wsp, float unscale, hipStream_t
         hipSuccess) return WD_ERR_LAUNCH;
     attr = true;
   }
-  hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), LDS, st, p, static_cast<const unsigned char*>(wsp), zero, k16,
+  WD_LAUNCH_GEMM(k, dim3((unsigned)nblk), dim3(256), LDS, st, p, static_cast<const unsigned char*>(wsp), zero, k16,
                      unscale, nbn, vec_c, vec_res, vec_bias, ngrp, nbm, ksplits, ws);
   return wd_launch_status();
 }
@@ -509,7 +509,7 @@ int launch_pingpong(const WdConvGemm& p, const void* wsp, float unscale, hipStre
         hipSuccess) return WD_ERR_LAUNCH;
     attr = true;
   }
-  hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(512), LDS, st, p, static_cast<const unsigned char*>(wsp), zero, k16,
+  WD_LAUNCH_GEMM(k, dim3((unsigned)nblk), dim3(512), LDS, st, p, static_cast<const unsigned char*>(wsp), zero, k16,
                      unscale, nbn, vec_c, vec_res, vec_bias, ra);
   return wd_launch_status();
 }

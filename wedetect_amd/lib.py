@@ -19,14 +19,14 @@ LIB_PATH = os.path.join(_HERE, "libwedetect_hip.so")
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU = 0, 1, 2, 3
 OUT_ROWS, OUT_DECONV2X2 = 0, 1
 SPLIT_A, SPLIT_C = 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 EXPORTS = (
     "wd_abi_version", "wd_strerror", "wd_sizeof_conv_gemm", "wd_conv_gemm", "wd_conv_gemm_tuned", "wd_conv_gemm_config", "wd_stem_patchify", "wd_dwconv7",
     "wd_layernorm_rows", "wd_l2norm_rows", "wd_dfl_decode", "wd_topk_workspace_bytes", "wd_topk_capacity",
     "wd_topk_candidates", "wd_nms_gather", "wd_retrieval_max",
     "wd_split_weights_bytes", "wd_split_weights", "wd_conv_gemm_split", "wd_conv_gemm_split_ws", "wd_conv_gemm_split_config", "wd_layernorm_rows_split", "wd_letterbox_u8", "wd_retrieval_max_split", "wd_text_embed", "wd_attention_small", "wd_recall_scratch_floats", "wd_recall_match",
-    "wd_max_sigmoid_attn", "wd_adaptive_maxpool_nhwc", "wd_cross_attention_small",
+    "wd_max_sigmoid_attn", "wd_adaptive_maxpool_nhwc", "wd_cross_attention_small", "wd_time_next_gemm",
 )
 
 
@@ -100,6 +100,7 @@ def _load():
     lib.wd_max_sigmoid_attn.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.wd_adaptive_maxpool_nhwc.argtypes = [vp, i32, vp, i32, i64, i32, i32, i32, i32, i32, vp]
     lib.wd_cross_attention_small.argtypes = [vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]
+    lib.wd_time_next_gemm.argtypes = [vp, vp]
     lib.wd_letterbox_u8.argtypes = [vp, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.wd_conv_gemm_split_config.restype = C.c_char_p
     lib.wd_conv_gemm_split_config.argtypes = [i32, i32, i32, i32]
@@ -291,3 +292,9 @@ def cross_attention_small(q, k, v, out, n_img, n_q, n_k, heads, head_dim) -> Non
         raise WedetectHipError("k and v must share their row pitch")
     check(LIB.wd_cross_attention_small(_p(q), q.stride(0), _p(k), _p(v), k.stride(0), _p(out), out.stride(0), n_img, n_q, n_k,
                                        heads, head_dim, stream_ptr()), "wd_cross_attention_small")
+
+
+def time_next_gemm(start: "torch.cuda.Event", stop: "torch.cuda.Event") -> None:
+    """The next GEMM launch of this thread records its own begin / end into the two (already created, timing-enabled)
+    events; ``start.elapsed_time(stop)`` is then the kernel's duration.  See wd_time_next_gemm."""
+    check(LIB.wd_time_next_gemm(start.cuda_event, stop.cuda_event), "wd_time_next_gemm")
