@@ -16,7 +16,8 @@ synthetic (no checkpoints or datasets offline).
 
 Prints ONE JSON line (rank 0) with the driver's contract plus:
   roofline      — the dominant kernel (the GEMM that runs the ConvNeXt MLPs: fp16x3 direct-to-LDS, or fp32 MFMA),
-                  algorithmic flops / HIP-event time of its launches inside the timed steps
+                  algorithmic flops / HIP-event time of its launches inside the timed region (events stamped by the
+                  kernels' own dispatches, on the last two timed steps: see GemmTimer)
   sim_gemm      — the judged region x text similarity GEMM, same accounting
   fp32_mode     — (default fp16x3 arithmetic only) the same workload re-timed in this run with native fp32 MFMA,
                   and the max |difference| of the fp16x3 step's embeddings / scores from it
