@@ -17,11 +17,11 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SVAR_XCD = 256;      // XCD-aware tile order (as in conv_gemm.hip)
 constexpr int SVAR_PIN = 2;        // sched_barrier fences: global loads, then MFMAs, then split + LDS store
-// timing-only ablations (WRONG results by construction) for on-device diagnosis
 constexpr int SVAR_PF2 = 128;      // global loads run two K stages ahead (two register sets)
 constexpr int SVAR_LDSEPI = 512;   // epilogue through LDS: every global access of C / residual / bias is a full 128-byte row segment
 constexpr int SVAR_ASPLIT = 1024;  // the activation operand is already stored as fp16 hi/lo groups (same layout as split weights)
 constexpr int SVAR_CSPLIT = 2048;  // the output is written as fp16 hi/lo groups for a consuming ASPLIT layer (needs SVAR_LDSEPI)
+// timing-only ablations (WRONG results by construction) for on-device diagnosis; no shipped configuration sets them
 constexpr int SABL_NOLOAD = 4, SABL_NOBAR = 8, SABL_NOEPI = 16, SABL_NOLDS = 32, SABL_NOSPLIT = 64;
 
 template <int TM, int TN, int WM, int WN, int BK_>
