@@ -244,6 +244,45 @@ def test_bricks_oracle_matches_reference_goldens():
         assert_close(f"ipa{j}", out, fx[f"ipa{j}.out"], 1e-6, 1e-6)
 
 
+def test_bricks_host_side_packing_and_errors():
+    """wedetect_amd.bricks without a GPU: constructor contracts of the reference classes, BN folding of the packed
+    convs against the unfolded math, and the refusal to run unloaded (no kernel is launched here)."""
+    import json
+    from oracle import bricks as obr
+    from wedetect_amd.bricks import ImagePoolingAttentionModule, MaxSigmoidAttnBlock
+    with pytest.raises(AssertionError):
+        MaxSigmoidAttnBlock(8, 12, 8, 8, num_heads=8, device="cpu")          # yolo_bricks.py:180-182
+    with pytest.raises(NotImplementedError):
+        MaxSigmoidAttnBlock(8, 8, 8, 8, use_depthwise=True, device="cpu")
+    with pytest.raises(ValueError):
+        MaxSigmoidAttnBlock(8, 8, 8, 8, precision="bf16", device="cpu")
+    with pytest.raises(RuntimeError):
+        MaxSigmoidAttnBlock(8, 8, 8, 8, precision="fp32", device="cpu")(torch.zeros(1, 8, 2, 2), torch.zeros(1, 1, 8))
+    fx = golden("bricks.npz")
+    c = json.loads(str(fx["msa0.cfg"]))
+    p = {k[len("msa0.p."):]: fx[k] for k in fx.files if k.startswith("msa0.p.")}
+    kw = {k: c[k] for k in ("in_channels", "out_channels", "guide_channels", "embed_channels", "num_heads", "with_scale")}
+    m = MaxSigmoidAttnBlock(**kw, precision="fp32", device="cpu").load_state_dict(p)
+    assert m.has_embed_conv and m.head_channels == c["out_channels"] // c["num_heads"] and m.scale is None
+    # packed project_conv == conv -> BN of the oracle, as one GEMM over (kh, kw, cin)-ordered rows
+    x = torch.from_numpy(fx["msa0.x"])
+    ref = obr.conv_module(x, {k: torch.from_numpy(v) for k, v in p.items()}, "project_conv", padding=1)
+    cols = torch.nn.functional.unfold(x, 3, padding=1)                                         # [B, cin*9, HW], (cin, kh, kw) order
+    b, _, hw = cols.shape
+    cols = cols.view(b, c["in_channels"], 9, hw).permute(0, 2, 1, 3).reshape(b, 9 * c["in_channels"], hw)   # -> (kh, kw, cin)
+    got = (m.project_conv.w @ cols + m.project_conv.b[None, :, None]).view_as(ref)
+    assert_close("folded project_conv", got, ref, 2e-6, 1e-5)
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({**p, "guide_fc.weight": p["guide_fc.weight"][:8]})                # channel mismatch
+    c = json.loads(str(fx["ipa1.cfg"]))
+    p = {k[len("ipa1.p."):]: fx[k] for k in fx.files if k.startswith("ipa1.p.")}
+    kw = {k: c[k] for k in ("image_channels", "text_channels", "embed_channels", "num_heads", "with_scale")}
+    ipa = ImagePoolingAttentionModule(**kw, precision="fp32", device="cpu").load_state_dict(p)
+    s = float(p["scale"].reshape(-1)[0])                                                      # with_scale: folded into proj
+    assert_close("proj * scale", ipa.proj.w, p["proj.weight"].astype(np.float64) * s, 1e-7, 1e-6)
+    assert ipa.head_channels == c["embed_channels"] // c["num_heads"] and len(ipa.projections) == 3
+
+
 def test_instance_data_surface():
     from wedetect_amd.detector import InstanceData
     d = InstanceData(bboxes=torch.arange(12.).view(3, 4), scores=torch.tensor([0.9, 0.2, 0.5]), labels=torch.tensor([1, 2, 3]))
