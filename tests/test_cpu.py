@@ -283,6 +283,41 @@ def test_bricks_host_side_packing_and_errors():
     assert ipa.head_channels == c["embed_channels"] // c["num_heads"] and len(ipa.projections) == 3
 
 
+def test_retrieval_file_is_the_references_wire_format(tmp_path):
+    """extract_embedding.py:1763-1774 writes / retrieval_metric.py:362-377 reads: same keys, types and shapes."""
+    from wedetect_amd import evaluate as E
+    g = torch.Generator().manual_seed(5)
+    n, r, d, k = 4, 6, 768, 9
+    emb, sc, bi = torch.randn(n, r, d, generator=g), torch.randn(n, r, generator=g), torch.randn(n, r, generator=g)
+    counts = torch.tensor([6, 0, 3, 1], dtype=torch.int32)
+    recs = E.retrieval_records([11, 12, 13, 14], emb, counts, sc, bi)
+    assert [set(x) for x in recs] == [{"image_id", "embedding", "scale", "bias"}] * n
+    assert [type(x["image_id"]) for x in recs] == [int] * n and [x["embedding"].shape[0] for x in recs] == [6, 0, 3, 1]
+    assert torch.equal(recs[2]["embedding"], emb[2, :3]) and torch.equal(recs[2]["scale"], sc[2, :3])
+    text = torch.nn.functional.normalize(torch.randn(k, d, generator=g), dim=1)
+    path = str(tmp_path / "coco_base.pth")
+    E.save_retrieval_file(path, recs, text)
+    pred = torch.load(path, "cpu")                                          # the reference's own read (retrieval_metric.py:362)
+    assert set(pred) == {"image_embedding", "text_embedding"} and torch.equal(pred["text_embedding"], text)
+    for a, b in zip(pred["image_embedding"], recs):
+        assert a["image_id"] == b["image_id"] and all(torch.equal(a[f], b[f]) for f in ("embedding", "scale", "bias"))
+    # the reference's scoring lines run on the loaded file (images with regions)
+    res = pred["image_embedding"][0]
+    logits = torch.einsum("bw,kw->bk", res["embedding"], pred["text_embedding"])
+    logits = torch.sigmoid(logits * res["scale"].exp().unsqueeze(1) + res["bias"].unsqueeze(1))
+    assert torch.max(logits, dim=0)[0].shape == (k,)
+    assert E.load_retrieval_file(path)["image_embedding"][3]["embedding"].shape == (1, d)
+    with pytest.raises(ValueError):
+        E.retrieval_records([1, 2], emb, counts, sc, bi)
+    with pytest.raises(ValueError):
+        E.retrieval_records([1, 2, 3, 4], emb, torch.tensor([7, 0, 0, 0]), sc, bi)
+    torch.save({"x": 1}, path)
+    with pytest.raises(ValueError):
+        E.load_retrieval_file(path)
+    res = {"a": {"precision": 0.5, "recall": 1.0, "f1": 0.6667}, "b": {"precision": 1.0, "recall": 0.0, "f1": 0.0}}
+    assert E.macro_average(res) == (0.75, 0.5, float(np.mean([0.6667, 0.0])))
+
+
 def test_instance_data_surface():
     from wedetect_amd.detector import InstanceData
     d = InstanceData(bboxes=torch.arange(12.).view(3, 4), scores=torch.tensor([0.9, 0.2, 0.5]), labels=torch.tensor([1, 2, 3]))

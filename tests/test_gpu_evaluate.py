@@ -1,8 +1,9 @@
 """Device proposal-recall matching (wd_recall_match) against the reference's goldens and the oracle."""
 import numpy as np
 import pytest
+import torch
 
-from tests.util import golden
+from tests.util import assert_close, golden
 
 pytestmark = pytest.mark.gpu
 
@@ -43,3 +44,44 @@ def test_matched_ious_bit_exact_vs_oracle_on_a_larger_set():
     got = matched_ious(gts, props, nums)
     ref = oe.matched_ious(gts, props, nums)
     assert got.shape == ref.shape and np.array_equal(got, ref)
+
+
+def test_retrieval_predictions_match_the_references_lines(tmp_path):
+    """retrieval_metric.py:365-377 restated on the CPU vs ``retrieval_predictions`` on a file written by
+    ``save_retrieval_file`` (thresholds kept away from any score by construction of the check)."""
+    from wedetect_amd import evaluate as E
+    g = torch.Generator().manual_seed(17)
+    n, r, d, k = 37, 300, 768, 80
+    emb = torch.nn.functional.normalize(torch.randn(n, r, d, generator=g), dim=2)
+    sc, bi = torch.randn(n, r, generator=g) * 0.2 + 1.5, torch.randn(n, r, generator=g) * 0.3 - 1.0
+    counts = torch.randint(0, r + 1, (n,), generator=g, dtype=torch.int32)
+    counts[3], counts[5] = 0, r
+    text = torch.nn.functional.normalize(torch.randn(k, d, generator=g), dim=1)
+    names = [f"class_{i}" for i in range(k)]
+    path = str(tmp_path / "synthetic_base.pth")
+    E.save_retrieval_file(path, E.retrieval_records(list(range(100, 100 + n)), emb, counts, sc, bi), text)
+    pred = E.load_retrieval_file(path)
+    ref_scores = torch.zeros(n, k)
+    for i, res in enumerate(pred["image_embedding"]):
+        if res["embedding"].shape[0] == 0:
+            continue                                         # the reference's torch.max would raise on an empty image
+        logits = torch.einsum("bw,kw->bk", res["embedding"], pred["text_embedding"])
+        logits = torch.sigmoid(logits * res["scale"].exp().unsqueeze(1) + res["bias"].unsqueeze(1))
+        ref_scores[i] = torch.max(logits, dim=0)[0]
+    got = E.retrieval_scores(pred["image_embedding"], pred["text_embedding"]).cpu()
+    assert_close("retrieval scores from file", got, ref_scores, 2e-6, 1e-5)
+    v = torch.sort(ref_scores[ref_scores > 0]).values          # a threshold in the widest gap near the median score
+    mid = v.numel() // 2
+    j = mid - 25 + int(torch.argmax(v[mid - 24:mid + 26] - v[mid - 25:mid + 25]))
+    thre = float((v[j] + v[j + 1]) / 2)
+    gap = float((ref_scores - thre).abs().min())
+    assert gap > 1e-5, "pick another seed: a score sits on the threshold"
+    out = E.retrieval_predictions(pred, names, thre)
+    ref = {nm: [] for nm in names}
+    for i, res in enumerate(pred["image_embedding"]):
+        for ids in torch.where(ref_scores[i] > thre)[0].tolist():
+            ref[names[ids]].append(res["image_id"])
+    assert out == ref and sum(len(v) for v in out.values()) > 0
+    results = E.evaluate_retrieval_per_class(out, {nm: set(v[:2]) | {1} for nm, v in ref.items()})
+    p_, r_, f_ = E.macro_average(results)
+    assert 0.0 <= p_ <= 1.0 and 0.0 <= r_ <= 1.0 and 0.0 <= f_ <= 1.0

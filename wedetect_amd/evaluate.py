@@ -5,11 +5,17 @@
   (``wd_recall_match``); sorting proposals by score and turning the matched IoUs into recalls stay on the
   host exactly as the reference writes them (numpy), so the result is bit-identical.
 * ``evaluate_retrieval_per_class`` — per-class precision / recall / F1 of retrieved image ids,
-  eval_retrieval/retrieval_metric.py:14-47 (set arithmetic on Python ints: host code)."""
+  eval_retrieval/retrieval_metric.py:14-47 (set arithmetic on Python ints: host code).
+* the retrieval hand-over file — ``retrieval_records`` / ``save_retrieval_file`` write exactly what
+  extract_embedding.py:1763-1774 saves (``{"image_embedding": [{image_id, embedding, scale, bias}, ...],
+  "text_embedding": [K, 768]}`` through ``torch.save``), so the reference's ``retrieval_metric.py`` reads files
+  written here and ``retrieval_predictions`` reads files the reference wrote; the latter is
+  retrieval_metric.py:362-377 with the scoring (sigmoid(E T^T exp(scale) + bias), max over regions) on the device
+  (``wd_retrieval_max``), and ``macro_average`` is the summary at 389-391."""
 from __future__ import annotations
 
 from collections.abc import Sequence
-from typing import Dict, List, Set
+from typing import Dict, List, Sequence as Seq, Set, Tuple
 
 import numpy as np
 import torch
@@ -105,3 +111,76 @@ def evaluate_retrieval_per_class(predictions: Dict[str, List[int]], gt: Dict[str
         results[cat_name] = {"precision": round(precision, 4), "recall": round(recall, 4), "f1": round(f1, 4),
                              "support": len(gt_set), "n_pred": len(pred_set)}
     return results
+
+
+# ------------------------------------------------------------------------------------------ retrieval hand-over file
+def retrieval_records(image_ids: Seq[int], embeddings: torch.Tensor, counts: torch.Tensor, scales: torch.Tensor,
+                      bias: torch.Tensor) -> List[dict]:
+    """Fixed-shape detector / gather outputs -> the per-image records of extract_embedding.py:1765-1773:
+    ``embeddings`` [N, R, D], ``scales`` / ``bias`` [N, R], ``counts`` [N] (kept regions per image); every record holds
+    CPU tensors trimmed to its count, ``image_id`` a Python int."""
+    e, sc, bi = embeddings.detach().cpu(), scales.detach().cpu(), bias.detach().cpu()
+    cn = [int(v) for v in counts.detach().cpu().tolist()]
+    if not (len(image_ids) == e.shape[0] == sc.shape[0] == bi.shape[0] == len(cn)):
+        raise ValueError("image_ids, embeddings, counts, scales and bias must describe the same images")
+    if any(c < 0 or c > e.shape[1] for c in cn):
+        raise ValueError("count outside [0, regions per image]")
+    return [{"image_id": int(i), "embedding": e[n, :c].clone(), "scale": sc[n, :c].clone(), "bias": bi[n, :c].clone()}
+            for n, (i, c) in enumerate(zip(image_ids, cn))]
+
+
+def save_retrieval_file(path: str, records: List[dict], text_embeddings: torch.Tensor) -> None:
+    """extract_embedding.py:1774."""
+    torch.save({"image_embedding": records, "text_embedding": text_embeddings.detach().cpu()}, path)
+
+
+def load_retrieval_file(path: str) -> dict:
+    """retrieval_metric.py:362."""
+    pred = torch.load(path, map_location="cpu")
+    if not isinstance(pred, dict) or "image_embedding" not in pred or "text_embedding" not in pred:
+        raise ValueError(f"{path} is not a retrieval file (needs image_embedding and text_embedding)")
+    return pred
+
+
+def retrieval_scores(records: List[dict], text_embedding: torch.Tensor, device="cuda", images_per_launch: int = 256
+                     ) -> torch.Tensor:
+    """[len(records), K] fp32 on the device: per image the max over its regions of
+    sigmoid(<e, t_k> * exp(scale) + bias) (retrieval_metric.py:369-375); images without regions score 0."""
+    dev = torch.device(device)
+    t = text_embedding.to(dev, torch.float32).contiguous()
+    k, dim = t.shape
+    out = torch.zeros(len(records), k, dtype=torch.float32, device=dev)
+    for lo in range(0, len(records), images_per_launch):
+        chunk = records[lo:lo + images_per_launch]
+        rows = max(1, max(int(r["embedding"].shape[0]) for r in chunk))
+        e = torch.zeros(len(chunk), rows, dim, dtype=torch.float32)
+        sc, bi = torch.zeros(len(chunk), rows, dtype=torch.float32), torch.zeros(len(chunk), rows, dtype=torch.float32)
+        cnt = torch.zeros(len(chunk), dtype=torch.int32)
+        for i, r in enumerate(chunk):
+            n = int(r["embedding"].shape[0])
+            if r["embedding"].shape[1:] != (dim,) or r["scale"].shape[0] != n or r["bias"].shape[0] != n:
+                raise ValueError(f"record of image {r.get('image_id')} is inconsistent with the text bank / itself")
+            e[i, :n], sc[i, :n], bi[i, :n], cnt[i] = r["embedding"], r["scale"], r["bias"], n
+        ed, sd, bd, cd = e.to(dev), sc.to(dev), bi.to(dev), cnt.to(dev)
+        L.retrieval_max(ed, t, sd, bd, cd, out[lo:lo + len(chunk)], len(chunk), rows, k, dim)
+    return out
+
+
+def retrieval_predictions(pred: dict, classnames: Seq[str], thre: float, device="cuda") -> Dict[str, List[int]]:
+    """retrieval_metric.py:365-377: class name -> ids of the images whose best region scores above ``thre``."""
+    if len(classnames) != pred["text_embedding"].shape[0]:
+        raise ValueError("one class name per text embedding row")
+    records = pred["image_embedding"]
+    scores = retrieval_scores(records, pred["text_embedding"], device).cpu()
+    out: Dict[str, List[int]] = {name: [] for name in classnames}
+    for r, row in zip(records, scores):
+        for ids in torch.where(row > thre)[0].tolist():
+            out[classnames[ids]].append(r["image_id"])
+    return out
+
+
+def macro_average(results: Dict[str, Dict[str, float]]) -> Tuple[float, float, float]:
+    """retrieval_metric.py:389-391."""
+    vals = list(results.values())
+    return (float(np.mean([r["precision"] for r in vals])), float(np.mean([r["recall"] for r in vals])),
+            float(np.mean([r["f1"] for r in vals])))
