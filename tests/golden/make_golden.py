@@ -612,10 +612,26 @@ def case_bricks():
     np.savez_compressed(os.path.join(OUT, "bricks.npz"), **fx)
 
 
+def case_configs():
+    """The ``model`` dict, ``img_scale`` and ``test_pipeline`` of config/wedetect_{tiny,base,large}.py as data (the
+    files are plain Python: executed, not copied), for the config-driven builder's tests."""
+    import json
+    out = {}
+    for size in ("tiny", "base", "large"):
+        ns = {}
+        exec(compile(open(os.path.join(REF, "config", f"wedetect_{size}.py")).read(), f"wedetect_{size}.py", "exec"), ns)
+        out[size] = {"model": ns["model"], "img_scale": list(ns["img_scale"]), "test_pipeline": ns["test_pipeline"]}
+    with open(os.path.join(OUT, "model_cfgs.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference tree not present: goldens can only be generated in the build container"
     if "--only-bricks" in sys.argv:
         case_bricks()
+        sys.exit(0)
+    if "--only-configs" in sys.argv:
+        case_configs()
         sys.exit(0)
     # transformers probes torchvision at import: the plugin files (which import it) must be
     # loaded BEFORE the bare torchvision stand-in goes into sys.modules (SURVEY.md §8c-i)
@@ -632,4 +648,5 @@ if __name__ == "__main__":
     case_recall()
     case_retrieval_metric()
     case_bricks()
+    case_configs()
     print("all golden fixtures written to", OUT)

@@ -318,6 +318,60 @@ def test_retrieval_file_is_the_references_wire_format(tmp_path):
     assert E.macro_average(res) == (0.75, 0.5, float(np.mean([0.6667, 0.0])))
 
 
+def test_build_detector_from_the_references_model_dicts():
+    """wedetect_amd.config.build_detector over the ``model`` dicts of config/wedetect_{tiny,base,large}.py (fixture
+    written by make_golden.py from the reference's files): every shipped config builds, with the sizes / thresholds it
+    names; options outside the implemented path and unknown registry names are refused, not ignored."""
+    import copy
+    import json
+    from wedetect_amd import config as C
+    from wedetect_amd.detector import YOLOWorldDetector
+    cfgs = json.load(open(os.path.join(GOLDEN, "model_cfgs.json")))
+    for size, scale in (("tiny", (640, 640)), ("base", (640, 640)), ("large", (1280, 1280))):
+        c = cfgs[size]
+        assert C.check_model_cfg(c["model"]) == size
+        m = C.build_detector(c["model"], img_scale=c["img_scale"], precision="fp32")
+        assert isinstance(m, YOLOWorldDetector) and m.model_size == size and m.img_scale == scale
+        assert m.test_cfg == dict(multi_label=True, nms_pre=30000, score_thr=0.001, nms=dict(type="nms", iou_threshold=0.7),
+                                  max_per_img=300)
+        assert set(C.pipeline_plan(c["test_pipeline"])) == {"LoadImageFromFile", "WeDetectKeepRatioResize", "WeDetectLetterResize",
+                                                            "LoadAnnotations", "LoadText", "PackDetInputs"}
+        with pytest.raises(RuntimeError):                       # built, but no weights / bank / device yet
+            m.predict([torch.zeros(3, *scale, dtype=torch.uint8)], [None])
+    base = cfgs["base"]["model"]
+
+    def mutated(path, value):
+        c = copy.deepcopy(base)
+        d = c
+        for k in path[:-1]:
+            d = d[k]
+        d[path[-1]] = value
+        return c
+    for path, value in ((("mm_neck",), True), (("bbox_head", "head_module", "use_bn_head"), False),
+                        (("data_preprocessor", "std"), [58.4, 57.1, 57.4]), (("data_preprocessor", "bgr_to_rgb"), False),
+                        (("neck", "scale_factor"), 0.75), (("bbox_head", "prior_generator", "strides"), [8, 16, 32, 64]),
+                        (("bbox_head", "head_module", "in_channels"), [512, 512, 1024]),
+                        (("bbox_head", "head_module", "embed_dims"), 512)):
+        with pytest.raises(NotImplementedError):
+            C.build_detector(mutated(path, value))
+    for path, value in ((("type",), "YOLODetector"), (("neck", "type"), "YOLOWorldPAFPN"),
+                        (("bbox_head", "loss_cls", "type"), "FocalLoss"), (("backbone", "image_model", "type"), "ResNet")):
+        with pytest.raises(KeyError):
+            C.build_detector(mutated(path, value))
+    with pytest.raises(ValueError):
+        C.build_detector(mutated(("neck", "model_size"), "large"))
+    with pytest.raises(KeyError):
+        C.build_detector(mutated(("backbone", "image_model", "model_name"), "huge"))
+    no_sf = copy.deepcopy(base)
+    del no_sf["neck"]["scale_factor"]                           # the constructor default is 0.75: not a Base neck
+    with pytest.raises(NotImplementedError):
+        C.build_detector(no_sf)
+    with pytest.raises(KeyError):
+        C.pipeline_plan([dict(type="RandomFlip")])
+    with pytest.raises(NotImplementedError):
+        C.pipeline_plan([dict(type="WeDetectLetterResize", scale=(640, 640), allow_scale_up=True)])
+
+
 def test_instance_data_surface():
     from wedetect_amd.detector import InstanceData
     d = InstanceData(bboxes=torch.arange(12.).view(3, 4), scores=torch.tensor([0.9, 0.2, 0.5]), labels=torch.tensor([1, 2, 3]))
