@@ -449,7 +449,28 @@ def _gather_worker(rank, world, port, q):
     last = rg.collect()
     got.append((last["embeddings"][:, 0, 0].tolist(), last["count"].tolist()))
     assert rg.collect() is None
-    q.put((rank, g["embeddings"][:, 0, 0].tolist(), g["count"].tolist(), r["image_id"].tolist(), got))
+    # class-sharded large-bank retrieval (configs[4]): 7 classes over 2 ranks (4 + 3), 6 images over 2 ranks
+    from oracle import postprocess as opp
+    from wedetect_amd.parallel import class_sharded_retrieval, shard_bank_by_class
+    gen = torch.Generator().manual_seed(99)
+    all_e = torch.nn.functional.normalize(torch.randn(6, 5, 8, generator=gen), dim=2)
+    all_s, all_b = torch.randn(6, 5, generator=gen) * 0.1 + 1.0, torch.randn(6, 5, generator=gen) * 0.1 - 0.5
+    all_c = torch.tensor([5, 0, 3, 1, 5, 2], dtype=torch.int32)
+    bank = torch.nn.functional.normalize(torch.randn(7, 8, generator=gen), dim=1)
+
+    def cpu_scores(e, c, sc, bi, t):                          # the oracle's restatement of retrieval_metric.py:369-375
+        out = torch.zeros(e.shape[0], t.shape[0])
+        for i in range(e.shape[0]):
+            n = int(c[i])
+            if n:
+                out[i] = torch.from_numpy(opp.retrieval_scores(e[i, :n].numpy(), t.numpy(), sc[i, :n].numpy(), bi[i, :n].numpy()))
+        return out
+    sl = slice(ids[0], ids[-1] + 1)
+    sharded = class_sharded_retrieval(all_e[sl], all_c[sl], all_s[sl], all_b[sl], shard_bank_by_class(bank, world, rank), 7,
+                                      score_fn=cpu_scores)
+    whole = cpu_scores(all_e, all_c, all_s, all_b, bank)
+    q.put((rank, g["embeddings"][:, 0, 0].tolist(), g["count"].tolist(), r["image_id"].tolist(), got,
+           float((sharded - whole).abs().max()), tuple(sharded.shape)))
     dist.destroy_process_group()
 
 
@@ -465,7 +486,9 @@ def test_region_gather_world2_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, e0, cnt, ids, piped in outs:
+    for rank, e0, cnt, ids, piped, sharded_err, sharded_shape in outs:
+        # class-sharded == whole bank on every rank (CPU matmuls of different widths may differ in the last bit)
+        assert sharded_err < 1e-6 and sharded_shape == (6, 7), (rank, sharded_err, sharded_shape)
         assert ids == [0, 1, 2, 3, 4, 5], (rank, ids)                # global image order on every rank
         assert e0 == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0]
         assert cnt == [i % 5 + 1 for i in range(6)]

@@ -85,3 +85,31 @@ def test_retrieval_predictions_match_the_references_lines(tmp_path):
     results = E.evaluate_retrieval_per_class(out, {nm: set(v[:2]) | {1} for nm, v in ref.items()})
     p_, r_, f_ = E.macro_average(results)
     assert 0.0 <= p_ <= 1.0 and 0.0 <= r_ <= 1.0 and 0.0 <= f_ <= 1.0
+
+
+def test_device_retrieval_scores_and_single_process_sharded_path():
+    """parallel.device_retrieval_scores (the default scorer of class_sharded_retrieval) vs the file-based scorer and
+    the reference's lines; without a process group the sharded entry point is the plain scorer."""
+    from wedetect_amd import evaluate as E
+    from wedetect_amd.parallel import class_sharded_retrieval, device_retrieval_scores
+    g = torch.Generator().manual_seed(23)
+    n, r, d, k = 9, 300, 768, 203
+    emb = torch.nn.functional.normalize(torch.randn(n, r, d, generator=g), dim=2)
+    sc, bi = torch.randn(n, r, generator=g) * 0.2 + 1.5, torch.randn(n, r, generator=g) * 0.3 - 1.0
+    counts = torch.tensor([300, 0, 1, 17, 300, 250, 3, 64, 128], dtype=torch.int32)
+    bank = torch.nn.functional.normalize(torch.randn(k, d, generator=g), dim=1)
+    dev = lambda t: t.cuda()
+    got = device_retrieval_scores(dev(emb), dev(counts), dev(sc), dev(bi), dev(bank))
+    same = class_sharded_retrieval(dev(emb), dev(counts), dev(sc), dev(bi), dev(bank), k)
+    assert torch.equal(got, same)
+    via_file = E.retrieval_scores(E.retrieval_records(list(range(n)), emb, counts, sc, bi), bank)
+    assert torch.equal(got, via_file)
+    ref = torch.zeros(n, k)
+    for i in range(n):
+        c = int(counts[i])
+        if c:
+            lg = torch.sigmoid(torch.einsum("bw,kw->bk", emb[i, :c], bank) * sc[i, :c].exp().unsqueeze(1) + bi[i, :c].unsqueeze(1))
+            ref[i] = lg.max(dim=0)[0]
+    assert_close("device retrieval scores", got, ref, 2e-6, 1e-5)
+    with pytest.raises(ValueError):
+        class_sharded_retrieval(dev(emb), dev(counts), dev(sc), dev(bi), dev(bank[:100]), k)

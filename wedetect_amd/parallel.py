@@ -9,7 +9,7 @@ in the CPU tests).  The detector forward itself needs no communication (eval-mod
 """
 from __future__ import annotations
 
-from typing import Dict, Optional
+from typing import Callable, Dict, Optional
 
 import torch
 import torch.distributed as dist
@@ -113,3 +113,44 @@ def shard_bank_by_class(bank: torch.Tensor, world: int, rank: int) -> torch.Tens
     (SURVEY.md §8e): every rank scores ALL gathered regions against its K/world classes."""
     r = shard_range(bank.shape[0], world, rank)
     return bank[r.start:r.stop]
+
+
+def device_retrieval_scores(embeddings: torch.Tensor, count: torch.Tensor, scales: torch.Tensor, bias: torch.Tensor,
+                            bank: torch.Tensor) -> torch.Tensor:
+    """[N, K] fp32: max over an image's kept regions of sigmoid(<e, t_k> exp(scale) + bias) on the device
+    (wd_retrieval_max; retrieval_metric.py:369-375).  ``embeddings`` [N, R, D], ``scales`` / ``bias`` [N, R], ``count`` [N]."""
+    from . import lib as L
+    n, r, d = embeddings.shape
+    out = torch.empty(n, bank.shape[0], dtype=torch.float32, device=embeddings.device)
+    L.retrieval_max(embeddings.contiguous(), bank.contiguous(), scales.contiguous(), bias.contiguous(),
+                    count.to(torch.int32).contiguous(), out, n, r, bank.shape[0], d)
+    return out
+
+
+def class_sharded_retrieval(embeddings: torch.Tensor, count: torch.Tensor, scales: torch.Tensor, bias: torch.Tensor,
+                            bank_shard: torch.Tensor, n_classes: int, score_fn: Callable = device_retrieval_scores,
+                            group=None) -> torch.Tensor:
+    """The large-bank retrieval step of configs[4]: images are sharded over the ranks, and so is the
+    text bank — by class, ``bank_shard = shard_bank_by_class(bank, world, rank)`` (a 1M x 768 bank is 384 MB per rank
+    at 8 ranks instead of 3 GB).  (1) one all-gather of the kept regions (+ counts, scales, bias); (2) every rank
+    scores ALL images against ITS classes — ``score_fn(emb, count, scales, bias, bank_shard) -> [N_total, K_shard]``,
+    by default the device kernel; (3) one all-gather of the score blocks.  Returns [N_total, n_classes] on every rank,
+    images in global order, classes in bank order.  Shards of unequal size (n_classes % world != 0) are padded to the
+    largest for the exchange and trimmed afterwards."""
+    if not dist.is_available() or not dist.is_initialized():
+        if bank_shard.shape[0] != n_classes:
+            raise ValueError("single process: the shard must be the whole bank")
+        return score_fn(embeddings, count, scales, bias, bank_shard)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    mine = shard_range(n_classes, world, rank)
+    if bank_shard.shape[0] != len(mine):
+        raise ValueError(f"rank {rank} holds {bank_shard.shape[0]} classes, shard_range gives {len(mine)}")
+    allv = gather_results(dict(e=embeddings, c=count, s=scales, b=bias), group)
+    block = score_fn(allv["e"], allv["c"], allv["s"], allv["b"], bank_shard)              # [N_total, len(mine)]
+    n_total, widest = block.shape[0], len(shard_range(n_classes, world, 0))
+    padded = torch.zeros(n_total, widest, dtype=block.dtype, device=block.device)
+    padded[:, : block.shape[1]] = block
+    blocks = torch.empty(world * n_total, widest, dtype=block.dtype, device=block.device)
+    dist.all_gather_into_tensor(blocks, padded, group=group)
+    blocks = blocks.view(world, n_total, widest)
+    return torch.cat([blocks[r][:, : len(shard_range(n_classes, world, r))] for r in range(world)], dim=1)
