@@ -136,6 +136,16 @@ class _StubModule(types.ModuleType):
             return _ConvModule
         if item == "Linear":
             return torch.nn.Linear
+        if item == "Resize":
+            return _ResizeBase
+        if item == "autocast_box_type":
+            return lambda *a, **k: (lambda fn: fn)
+        if item == "cache_randomness":
+            return lambda fn: fn
+        if item == "imresize":
+            return _imresize
+        if item == "impad":
+            return _impad
         if item and item[0].isupper():
             return _StubMeta(item, (torch.nn.Module,), {"__init__": lambda self, *a, **k: torch.nn.Module.__init__(self)})
         return lambda *a, **k: None
@@ -166,6 +176,29 @@ class _ConvModule(torch.nn.Module):
         if self.bn is not None:
             x = self.bn(x)
         return x if self.act is None else self.act(x)
+
+
+class _ResizeBase:
+    """mmdet.datasets.transforms.Resize as the two WeDetect transforms use it: keeps ``scale`` / ``keep_ratio`` /
+    ``backend`` / ``interpolation`` and runs ``_resize_img`` (the subclasses override it) from ``transform``."""
+
+    def __init__(self, scale=None, keep_ratio=False, clip_object_border=True, backend="cv2", interpolation="bilinear", **kw):
+        self.scale, self.keep_ratio, self.clip_object_border = scale, keep_ratio, clip_object_border
+        self.backend, self.interpolation = backend, interpolation
+
+    def transform(self, results):
+        self._resize_img(results)
+        return results
+
+
+def _imresize(img, size, interpolation="bilinear", backend=None, **kw):
+    """mmcv.imresize stand-in for the GEOMETRY fixtures: an image of the requested (w, h) size (pixels unused)."""
+    return np.zeros((size[1], size[0]) + img.shape[2:], img.dtype)
+
+
+def _impad(img, padding, pad_val=0, padding_mode="constant", **kw):
+    left, top, right, bottom = padding
+    return np.pad(img, ((int(top), int(bottom)), (int(left), int(right)), (0, 0)), constant_values=pad_val[0] if isinstance(pad_val, tuple) else pad_val)
 
 
 _STUBS_INSTALLED = False
@@ -612,6 +645,42 @@ def case_bricks():
     np.savez_compressed(os.path.join(OUT, "bricks.npz"), **fx)
 
 
+def case_mmdet_geometry():
+    """scale_factor / pad_param / shapes produced by the reference's own WeDetectKeepRatioResize + WeDetectLetterResize
+    code (transforms.py:62-123, 180-272, 319-330) over image sizes incl. exact fits, up-scaling candidates, odd
+    paddings and extreme aspect ratios; mmcv's imresize / impad and mmdet's Resize base are stand-ins (sizes only).
+    The product's arithmetic (wedetect_amd.preprocess.mmdet_test_geometry) must reproduce every record."""
+    import json
+    from wedetect_amd.preprocess import mmdet_test_geometry
+    install_stub_finder()
+    spec = importlib.util.spec_from_file_location("refwd_transforms", os.path.join(REF, "wedetect", "datasets", "transformers", "transforms.py"))
+    tr = importlib.util.module_from_spec(spec)
+    sys.modules["refwd_transforms"] = tr
+    spec.loader.exec_module(tr)
+    g = np.random.default_rng(8)
+    sizes = [(720, 1280), (1280, 720), (640, 640), (480, 640), (427, 640), (640, 427), (333, 500), (500, 375), (32, 32),
+             (3, 999), (999, 3), (641, 640), (639, 641), (1080, 1920), (3000, 4000), (375, 1242), (100, 37), (1279, 1281)]
+    sizes += [(int(g.integers(20, 2500)), int(g.integers(20, 2500))) for _ in range(60)]
+    recs = []
+    for scale in ((640, 640), (1280, 1280)):
+        k = tr.WeDetectKeepRatioResize(scale=scale)
+        l = tr.WeDetectLetterResize(scale=scale, allow_scale_up=False, pad_val=dict(img=114))
+        for (h, w) in sizes:
+            res = dict(img=np.zeros((h, w, 3), np.uint8))
+            res = l.transform(k.transform(res))
+            mine = mmdet_test_geometry(h, w, scale)
+            rec = dict(h=h, w=w, scale=list(scale), img_shape=[int(v) for v in res["img_shape"][:2]],
+                       scale_factor=[float(res["scale_factor"][0]), float(res["scale_factor"][1])],
+                       pad_param=[float(v) for v in res["pad_param"]])
+            assert tuple(rec["img_shape"]) == mine["img_shape"], (rec, mine)
+            assert rec["scale_factor"] == list(mine["scale_factor"]), (rec, mine)
+            assert rec["pad_param"] == [float(v) for v in mine["pad_param"]] and res["pad_param"].dtype == np.float32, (rec, mine)
+            recs.append(rec)
+    print(f"  [bit-identical] mmdet test-pipeline geometry, {len(recs)} sizes")
+    with open(os.path.join(OUT, "mmdet_geometry.json"), "w") as f:
+        json.dump(recs, f)
+
+
 def case_configs():
     """The ``model`` dict, ``img_scale`` and ``test_pipeline`` of config/wedetect_{tiny,base,large}.py as data (the
     files are plain Python: executed, not copied), for the config-driven builder's tests."""
@@ -633,6 +702,9 @@ if __name__ == "__main__":
     if "--only-configs" in sys.argv:
         case_configs()
         sys.exit(0)
+    if "--only-geometry" in sys.argv:
+        case_mmdet_geometry()
+        sys.exit(0)
     # transformers probes torchvision at import: the plugin files (which import it) must be
     # loaded BEFORE the bare torchvision stand-in goes into sys.modules
     case_mmdet_modules("tiny", 64)
@@ -649,4 +721,5 @@ if __name__ == "__main__":
     case_retrieval_metric()
     case_bricks()
     case_configs()
+    case_mmdet_geometry()
     print("all golden fixtures written to", OUT)

@@ -372,6 +372,26 @@ def test_build_detector_from_the_references_model_dicts():
         C.pipeline_plan([dict(type="WeDetectLetterResize", scale=(640, 640), allow_scale_up=True)])
 
 
+def test_mmdet_test_pipeline_geometry_matches_the_references_transforms():
+    """preprocess.mmdet_test_geometry vs records produced by the reference's WeDetectKeepRatioResize +
+    WeDetectLetterResize code (tests/golden/mmdet_geometry.json, 156 sizes, two target scales): equal floats."""
+    import json
+    from wedetect_amd.preprocess import mmdet_test_geometry
+    recs = json.load(open(os.path.join(GOLDEN, "mmdet_geometry.json")))
+    assert len(recs) >= 150
+    for r in recs:
+        g = mmdet_test_geometry(r["h"], r["w"], tuple(r["scale"]))
+        assert list(g["img_shape"]) == r["img_shape"] and list(g["scale_factor"]) == r["scale_factor"], r
+        assert g["pad_param"].dtype == np.float32 and g["pad_param"].tolist() == r["pad_param"], r
+        nh, nw = g["no_pad_shape"]
+        assert nh + int(r["pad_param"][0] + r["pad_param"][1]) == r["img_shape"][0]
+        assert nw + int(r["pad_param"][2] + r["pad_param"][3]) == r["img_shape"][1]
+    with pytest.raises(TypeError):
+        mmdet_test_geometry(100, 100, 640)
+    with pytest.raises(ZeroDivisionError):                     # the reference fails the same way on a 1-pixel-high strip
+        mmdet_test_geometry(1, 999, (640, 640))
+
+
 def test_instance_data_surface():
     from wedetect_amd.detector import InstanceData
     d = InstanceData(bboxes=torch.arange(12.).view(3, 4), scores=torch.tensor([0.9, 0.2, 0.5]), labels=torch.tensor([1, 2, 3]))

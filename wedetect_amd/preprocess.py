@@ -71,6 +71,42 @@ def letterbox_geometry(w: int, h: int, new_shape=(640, 640)):
     return nw, nh, dw // 2, dh // 2, r, (dw / 2, dh / 2)
 
 
+def mmdet_test_geometry(ori_h: int, ori_w: int, scale=(640, 640)) -> dict:
+    """Shapes and bookkeeping of the mmdet test pipeline of config/wedetect_*.py:111-118 —
+    ``WeDetectKeepRatioResize(scale)`` then ``WeDetectLetterResize(scale, allow_scale_up=False, pad_val=114)`` —
+    for one ``ori_h x ori_w`` image, exactly as transforms.py:62-123 and 180-272 / 319-330 compute them:
+
+      resized_shape   (h, w) after the keep-ratio resize: ``int(w * ratio)`` (truncated), ratio =
+                      min(max(scale) / max(h, w), min(scale) / min(h, w)); unchanged when ratio == 1
+      no_pad_shape    (h, w) after the letter resize: ``int(round(. * ratio2))``, ratio2 = min(fit, 1.0) — the keep-ratio
+                      step scales small images UP to fit; only this second step never scales up
+      pad_param       float32 [top, bottom, left, right], top = int(round(pad_h // 2 - 0.1))
+      scale_factor    (w, h) python floats: product of the two transforms' measured size ratios
+      img_shape       (scale_h, scale_w)
+
+    ``pad_param`` and ``scale_factor`` are what ``YOLOWorldDetector.predict`` needs to map boxes back to the
+    original image (yolo_world_head.py:728-746).  Pixels are host work in the reference (cv2 area / bilinear
+    through mmcv.imresize, absent here) and are not reproduced by this function."""
+    if not (isinstance(scale, (tuple, list)) and len(scale) == 2):
+        raise TypeError("scale must be a (w, h) pair as in the configs")
+    scale = tuple(int(v) for v in scale)
+    h, w = int(ori_h), int(ori_w)
+    if h <= 0 or w <= 0:
+        raise ValueError("empty image")
+    ratio = min(max(scale) / max(h, w), min(scale) / min(h, w))                      # :86-89
+    h1, w1 = (int(h * ratio), int(w * ratio)) if ratio != 1 else (h, w)              # :104-112
+    sf1 = (w1 / w, h1 / h)                                                           # :114-117
+    sh, sw = scale[::-1]                                                             # :190 (wh -> hw)
+    ratio2 = min(min(sh / h1, sw / w1), 1.0)                                         # :195-199 (allow_scale_up=False)
+    nh, nw = int(round(h1 * ratio2)), int(round(w1 * ratio2))                        # :204-205
+    pad_h, pad_w = sh - nh, sw - nw                                                  # :208-210
+    sf2 = (nw / w1, nh / h1)                                                         # :230-231
+    top, left = int(round(pad_h // 2 - 0.1)), int(round(pad_w // 2 - 0.1))           # :238-239
+    pad_param = np.array([top, pad_h - top, left, pad_w - left], dtype=np.float32)   # :240-245, 271-272
+    return dict(resized_shape=(h1, w1), no_pad_shape=(nh, nw), pad_param=pad_param,
+                scale_factor=(sf2[0] * sf1[0], sf2[1] * sf1[1]), img_shape=(sh, sw))  # :321-326
+
+
 class DeviceLetterbox:
     """Letterboxes a list of RGB uint8 images into one [B, H, W, 3] device canvas."""
 
@@ -117,6 +153,43 @@ class DeviceLetterbox:
             ratios.append(r)
             pads.append(pad)
         return out, ratios, pads
+
+
+class DeviceTestPipeline:
+    """The mmdet test pipeline's image side for callers without cv2 / mmcv: shapes, ``scale_factor`` and ``pad_param``
+    exactly as ``WeDetectKeepRatioResize`` + ``WeDetectLetterResize`` produce them (``mmdet_test_geometry``, pinned to
+    the reference's code), pixels resampled on the device with the antialiased bilinear filter of ``wd_letterbox_u8`` in
+    ONE pass from the original to the final unpadded size.  The reference resamples on the host with cv2 (area when
+    shrinking, bilinear otherwise, in up to two passes): geometry and metadata are identical, pixel values are not —
+    use the reference's own pipeline upstream of ``YOLOWorldDetector.predict`` when bit-equal inputs matter.
+    Returns BGR->RGB-agnostic uint8 canvases: channels are kept in the order they come in."""
+
+    def __init__(self, scale=(640, 640), pad_val: int = 114, device="cuda"):
+        self.scale = tuple(int(v) for v in scale)
+        self._lb = DeviceLetterbox(new_shape=self.scale[::-1], fill=(pad_val,) * 3, device=device)
+
+    def __call__(self, images: Sequence):
+        """-> (canvas uint8 [B, H, W, 3] on the device, [metainfo dict per image: ori_shape, img_shape, scale_factor,
+        pad_param] — the keys ``PackDetInputs`` forwards, config/wedetect_base.py:121-129)."""
+        lb = self._lb
+        th, tw = lb.new_shape
+        out = torch.empty(len(images), th, tw, 3, dtype=torch.uint8, device=lb.dev)
+        metas = []
+        for i, img in enumerate(images):
+            src = _as_device_u8(img, lb.dev)
+            h, w = int(src.shape[0]), int(src.shape[1])
+            geo = mmdet_test_geometry(h, w, self.scale)
+            nh, nw = geo["no_pad_shape"]
+            top, left = int(geo["pad_param"][0]), int(geo["pad_param"][2])
+            bh, kh, ksh = lb._table(w, nw)
+            bv, kv, ksv = lb._table(h, nh)
+            need = h * nw * 3
+            if lb._tmp is None or lb._tmp.numel() < need:
+                lb._tmp = torch.empty(need, dtype=torch.uint8, device=lb.dev)
+            L.letterbox_u8(src, h, w, bh, kh, ksh, bv, kv, ksv, lb._tmp, out[i], th, tw, nw, nh, left, top, lb.fill)
+            metas.append(dict(ori_shape=(h, w), img_shape=geo["img_shape"], scale_factor=geo["scale_factor"],
+                              pad_param=geo["pad_param"]))
+        return out, metas
 
 
 def _as_device_u8(img, dev) -> torch.Tensor:
