@@ -392,6 +392,51 @@ def test_mmdet_test_pipeline_geometry_matches_the_references_transforms():
         mmdet_test_geometry(1, 999, (640, 640))
 
 
+def test_host_geometry_properties_hypothesis():
+    """Size-independent properties of the host-side integer logic (hypothesis): shards partition the index range in
+    order; resampling weights of every output pixel sum to 2^22 within the rounding of their entries and stay inside
+    the input; both letterbox geometries fill the target exactly and never produce negative paddings."""
+    from hypothesis import given, settings, strategies as st
+    from wedetect_amd.parallel import shard_range
+    from wedetect_amd.preprocess import PRECISION_BITS, letterbox_geometry, mmdet_test_geometry, resample_coeffs
+
+    @settings(max_examples=300, deadline=None)
+    @given(st.integers(0, 5000), st.integers(1, 64))
+    def shards(total, world):
+        parts = [shard_range(total, world, r) for r in range(world)]
+        assert [i for p in parts for i in p] == list(range(total))
+        sizes = [len(p) for p in parts]
+        assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.integers(1, 700), st.integers(1, 700))
+    def coeffs(n_in, n_out):
+        bounds, kk = resample_coeffs(n_in, n_out)
+        assert bounds.shape == (n_out, 2) and kk.shape[0] == n_out
+        assert np.all(bounds[:, 0] >= 0) and np.all(bounds[:, 0] + bounds[:, 1] <= n_in) and np.all(bounds[:, 1] >= 1)
+        sums = kk.astype(np.int64).sum(axis=1)
+        assert np.all(np.abs(sums - (1 << PRECISION_BITS)) <= kk.shape[1])      # each entry rounded to nearest
+        for i in range(n_out):
+            assert not kk[i, bounds[i, 1]:].any()                              # nothing beyond the window
+
+    @settings(max_examples=300, deadline=None)
+    @given(st.integers(4, 4000), st.integers(4, 4000), st.sampled_from([(640, 640), (1280, 1280), (640, 512)]))
+    def boxes(h, w, scale):
+        nw, nh, left, top, r, (hx, hy) = letterbox_geometry(w, h, (scale[1], scale[0]))
+        assert 0 <= left and 0 <= top and left + nw <= scale[0] and top + nh <= scale[1]
+        assert max(nw / scale[0], nh / scale[1]) > 0.99 and (hx, hy) == ((scale[0] - nw) / 2, (scale[1] - nh) / 2)
+        try:
+            g = mmdet_test_geometry(h, w, scale)
+        except ZeroDivisionError:
+            assert min(h, w) * min(max(scale) / max(h, w), min(scale) / min(h, w)) < 1.0    # a side collapsed to 0 pixels
+            return
+        t, b, l, rr = g["pad_param"]
+        nh2, nw2 = g["no_pad_shape"]
+        assert min(t, b, l, rr) >= 0 and t + b + nh2 == g["img_shape"][0] and l + rr + nw2 == g["img_shape"][1]
+        assert abs(t - b) <= 1 and abs(l - rr) <= 1 and g["scale_factor"][0] > 0 and g["scale_factor"][1] > 0
+    shards(); coeffs(); boxes()
+
+
 def test_instance_data_surface():
     from wedetect_amd.detector import InstanceData
     d = InstanceData(bboxes=torch.arange(12.).view(3, 4), scores=torch.tensor([0.9, 0.2, 0.5]), labels=torch.tensor([1, 2, 3]))
