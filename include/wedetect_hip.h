@@ -143,6 +143,38 @@ int wd_conv_gemm_split_ws(const WdConvGemm* p, const void* w_split, float w_unsc
 const char* wd_conv_gemm_split_config(int32_t m, int32_t n, int32_t k, int32_t is_conv);
 
 /* ---------------------------------------------------------------------------------------------
+ * wd_cv_resize_paste_u8 — OpenCV-style 8-bit resize of one uint8 HWC 3-channel image fused with the letter pad,
+ * on the device.  Replaces the host pixels work of the mmdet test pipeline: WeDetectKeepRatioResize
+ * (mmcv.imresize -> cv2.resize, INTER_AREA when shrinking / INTER_LINEAR when enlarging;
+ * wedetect/datasets/transformers/transforms.py:94-123) followed by WeDetectLetterResize's constant pad
+ * (transforms.py:237-258).  The arithmetic restates OpenCV 4.x modules/imgproc/src/resize.cpp (third-party,
+ * absent offline: parity unpinned, oracle/cv2_resize.py).  The new_h x new_w result lands at (top, left) of
+ * the [dst_h, dst_w, 3] canvas, every other pixel = fill; swap_rb != 0 writes channels reversed (BGR <-> RGB).
+ * Tables are device arrays computed by the host (wedetect_amd/pipeline.py):
+ *   WD_CVRESIZE_COPY       no resize (new size == source size), no tables
+ *   WD_CVRESIZE_AREA_FAST  integer box sums: p0 = iscale_x, p1 = iscale_y, p2 = 1.f / (p0 * p1)
+ *   WD_CVRESIZE_AREA       xa [new_w, 2] = (first tap, tap count), xidx / xw = source column and float32 weight
+ *                          per tap (computeResizeAreaTab); ya / yidx / yw likewise for rows
+ *   WD_CVRESIZE_LINEAR     xa [new_w, 2] = int16-range coefficient pair (11 fractional bits), xidx [new_w] =
+ *                          source column, p0 = first output column that reads a single tap; ya [new_h, 2],
+ *                          yidx [new_h] = un-clamped source row (clamped to [0, sh) here)
+ * ------------------------------------------------------------------------------------------- */
+#define WD_CVRESIZE_COPY 0
+#define WD_CVRESIZE_AREA_FAST 1
+#define WD_CVRESIZE_AREA 2
+#define WD_CVRESIZE_LINEAR 3
+int wd_cv_resize_paste_u8(const uint8_t* src, int32_t sh, int32_t sw, int32_t mode, const int32_t* xa,
+                          const int32_t* xidx, const float* xw, const int32_t* ya, const int32_t* yidx,
+                          const float* yw, int32_t p0, int32_t p1, float p2, uint8_t* dst, int32_t dst_h,
+                          int32_t dst_w, int32_t new_h, int32_t new_w, int32_t top, int32_t left, int32_t fill,
+                          int32_t swap_rb, void* stream);
+/* wd_chw_to_hwc_u8 — a packed mmdet batch [batch, 3, h, w] (uint8, or fp32 0..255 when src_is_f32; BGR) ->
+ * [batch, h, w, 3] uint8 with the channel order reversed (RGB): DetDataPreprocessor's bgr_to_rgb
+ * (data_preprocessor.py:35-36, config/wedetect_base.py:44-48) + the NHWC layout the stem kernel reads. */
+int wd_chw_to_hwc_u8(const void* src, int32_t src_is_f32, uint8_t* dst, int32_t batch, int32_t h, int32_t w,
+                     void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * wd_letterbox_u8 — keep-ratio resize + centred pad of one uint8 RGB HWC image on the device,
  * bit-exact with PIL's Image.resize(..., BILINEAR) + paste (generate_proposal.py:17-82 letterbox;
  * Pillow src/libImaging/Resample.c: two separable int32 passes with 22 fractional bits, uint8

@@ -1,0 +1,455 @@
+"""CPU tests of the drop-in boundary added in round 2: config files, registries, the `wedetect` import shim, the entry
+scripts' argument handling, the cv2-resize oracle (hand-derived vectors) and the host tables of the device pipeline,
+the ragged multi-GPU gather on gloo (world 3, unequal shards)."""
+import argparse
+import json
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def _norm(x):
+    if isinstance(x, dict):
+        return {k: _norm(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_norm(v) for v in x]
+    return x
+
+
+# ------------------------------------------------------------------------------------------ config files
+def test_config_files_evaluate_to_the_references_dicts():
+    """config/wedetect_{tiny,base,large}.py of this repository, read by wedetect_amd.cfgfile.Config (``_base_``
+    chains, dict merging), give the same ``model`` / ``img_scale`` / ``test_pipeline`` as the reference's config files
+    evaluated by make_golden.py (tests/golden/model_cfgs.json)."""
+    from wedetect_amd.cfgfile import Config
+    ref = json.load(open(os.path.join(GOLDEN, "model_cfgs.json")))
+    for size in ("tiny", "base", "large"):
+        cfg = Config.fromfile(os.path.join(ROOT, "config", f"wedetect_{size}.py"))
+        assert _norm(cfg.model.to_dict()) == _norm(ref[size]["model"])
+        assert _norm(cfg.img_scale) == _norm(ref[size]["img_scale"])
+        assert _norm(cfg.test_pipeline) == _norm(ref[size]["test_pipeline"])
+        assert cfg.default_scope == "mmdet" and cfg.log_level == "INFO"            # from _base_
+        assert cfg.model.backbone.image_model.model_name == size                   # attribute access all the way down
+        assert cfg.filename.endswith(f"wedetect_{size}.py")
+
+
+def test_config_semantics(tmp_path):
+    from wedetect_amd.cfgfile import Config, ConfigDict, DictAction
+    (tmp_path / "base.py").write_text("a = 1\nd = dict(x=1, y=dict(z=2), l=[dict(k=1), dict(k=2)])\nimport os\ndef f(): pass\n")
+    (tmp_path / "other.py").write_text("b = 2\n")
+    (tmp_path / "child.py").write_text(
+        "_base_ = ['base.py', 'other.py']\nd = dict(y=dict(w=3))\nc = _base_.d.y.z + _base_.b\ne = dict(_delete_=True, only=1)\n")
+    (tmp_path / "repl.py").write_text("_base_ = 'base.py'\nd = dict(_delete_=True, q=9)\n")
+    (tmp_path / "dup.py").write_text("_base_ = ['base.py', 'dup2.py']\n")
+    (tmp_path / "dup2.py").write_text("a = 5\n")
+    (tmp_path / "loop.py").write_text("_base_ = 'loop.py'\n")
+    cfg = Config.fromfile(tmp_path / "child.py")
+    assert cfg.a == 1 and cfg.b == 2 and cfg.c == 4
+    assert cfg.d.to_dict() == dict(x=1, y=dict(z=2, w=3), l=[dict(k=1), dict(k=2)])
+    assert cfg.e.to_dict() == dict(only=1) and "os" not in cfg and "f" not in cfg
+    assert Config.fromfile(tmp_path / "repl.py").d.to_dict() == dict(q=9)
+    with pytest.raises(KeyError):
+        Config.fromfile(tmp_path / "dup.py")
+    with pytest.raises(RecursionError):
+        Config.fromfile(tmp_path / "loop.py")
+    with pytest.raises(FileNotFoundError):
+        Config.fromfile(tmp_path / "nope.py")
+    # --cfg-options
+    p = argparse.ArgumentParser()
+    p.add_argument("--cfg-options", nargs="+", action=DictAction)
+    opts = p.parse_args(["--cfg-options", "d.y.z=7", "d.l.1.k=5", "s=abc", "t=(1,2.5)", "u=[a,b]", "v=[(1,2),(3,4)]", "w=true",
+                         "n=None", "m=1,2"]).cfg_options
+    assert opts == {"d.y.z": 7, "d.l.1.k": 5, "s": "abc", "t": (1, 2.5), "u": ["a", "b"], "v": [(1, 2), (3, 4)], "w": True,
+                    "n": None, "m": [1, 2]}
+    cfg.merge_from_dict(opts)
+    assert cfg.d.y.z == 7 and cfg.d.y.w == 3 and cfg.d.l[1].k == 5 and cfg.d.l[0].k == 1 and cfg.t == (1, 2.5)
+    cfg.work_dir = "./work_dirs/x"                                               # infer_wedetect.py:155
+    assert cfg.work_dir == "./work_dirs/x" and cfg.get("missing", 3) == 3 and not hasattr(cfg, "missing")
+    with pytest.raises(AttributeError):
+        cfg.missing
+    cd = ConfigDict(a=dict(b=[dict(c=1)]))
+    assert cd.a.b[0].c == 1 and isinstance(cd.to_dict()["a"], dict) and not isinstance(cd.to_dict()["a"], ConfigDict)
+    # custom_imports: allow_failed_imports=False must raise for a missing module, the shim must import
+    (tmp_path / "imp.py").write_text("custom_imports = dict(imports=['no_such_module_xyz'], allow_failed_imports=False)\n")
+    with pytest.raises(ImportError):
+        Config.fromfile(tmp_path / "imp.py")
+    (tmp_path / "imp2.py").write_text("custom_imports = dict(imports=['wedetect'], allow_failed_imports=False)\n")
+    Config.fromfile(tmp_path / "imp2.py")
+
+
+# ------------------------------------------------------------------------------------------ registries + shim
+def test_registry_and_wedetect_shim():
+    import wedetect
+    import wedetect.models as wm
+    from wedetect_amd.registry import MODELS, TRANSFORMS
+    ref = json.load(open(os.path.join(GOLDEN, "model_cfgs.json")))["base"]
+
+    def names(cfg, out):
+        if isinstance(cfg, dict):
+            if "type" in cfg:
+                out.add(cfg["type"])
+            for v in cfg.values():
+                names(v, out)
+        elif isinstance(cfg, (list, tuple)):
+            for v in cfg:
+                names(v, out)
+        return out
+    model_types = names(ref["model"], set()) - {"nms"}                          # test_cfg.nms.type is an op name, not a class
+    assert model_types <= set(MODELS.module_dict), model_types - set(MODELS.module_dict)
+    assert names(ref["test_pipeline"], set()) <= set(TRANSFORMS.module_dict)
+    for n in ("YOLOWorldDetector", "MultiModalYOLOBackbone", "XLMRobertaLanguageBackbone", "CSPRepBiFPANNeck"):
+        assert getattr(wm, n) is MODELS.get(n)
+    # every sub-dict of the shipped config builds on its own through the registry
+    neck = MODELS.build(ref["model"]["neck"])
+    assert neck.cfg["model_size"] == "base" and "CSPRepBiFPANNeck" in repr(neck)
+    with pytest.raises(NotImplementedError):
+        neck(None)
+    with pytest.raises(NotImplementedError):
+        MODELS.build(dict(type="CSPRepBiFPANNeck", model_size="base", scale_factor=0.75))
+    with pytest.raises(KeyError):
+        MODELS.build(dict(type="YOLOv8PAFPN"))
+    with pytest.raises(KeyError):
+        MODELS.build(dict(model_size="base"))
+    tm = MODELS.build(ref["model"]["backbone"]["text_model"])
+    assert tm.model_name == "./xlm-roberta-base/" and tm.model_size == "base"
+    det = MODELS.build(ref["model"])
+    assert type(det).__name__ == "YOLOWorldDetector" and det.model_size == "base" and det.backbone.with_text_model
+    assert det.num_test_classes == 1203 and det._h.nms_pre == 30000 and isinstance(det, torch.nn.Module)
+    assert wedetect.MMENGINE_REGISTERED in (True, False)
+    t = TRANSFORMS.build(dict(type="LoadAnnotations", with_bbox=True, _scope_="mmdet"))
+    assert t(dict(a=1)) == dict(a=1)
+
+
+def test_detector_options_are_honoured_or_refused():
+    """nms_pre reaches the tower, other NMS types / too many outputs are refused at construction, the
+    configs' (w, h) img_scale becomes (H, W)."""
+    from wedetect_amd.config import build_detector
+    from wedetect_amd.detector import YOLOWorldDetector
+    ref = json.load(open(os.path.join(GOLDEN, "model_cfgs.json")))["base"]["model"]
+    d = YOLOWorldDetector("nano", test_cfg=dict(nms_pre=1000, max_per_img=100))
+    assert d._h.nms_pre == 1000 and d._h.max_out == 100
+    with pytest.raises(NotImplementedError):
+        YOLOWorldDetector("nano", test_cfg=dict(nms=dict(type="soft_nms", iou_threshold=0.5)))
+    with pytest.raises(NotImplementedError):
+        YOLOWorldDetector("nano", test_cfg=dict(nms=dict(type="nms", iou_threshold=0.5, split_thr=100)))
+    with pytest.raises(NotImplementedError):
+        YOLOWorldDetector("nano", test_cfg=dict(max_per_img=2000))
+    with pytest.raises(NotImplementedError):
+        YOLOWorldDetector("nano", test_cfg=dict(multi_label=False))
+    with pytest.raises(TypeError):
+        YOLOWorldDetector()
+    m = build_detector(ref, img_scale=(640, 512))                                # (w, h)
+    assert m.img_scale == (512, 640)                                             # (H, W)
+    with pytest.raises(NotImplementedError):
+        m.half()
+    with pytest.raises(RuntimeError):
+        m.to("cpu")
+    assert m.to(torch.float32) is m and m.eval() is m and m.training is False
+
+
+def test_state_dict_round_trip_and_recursive_loader_hook():
+    """load_state_dict / state_dict / _load_from_state_dict (what mmengine's load_checkpoint walks) on the parameter-free
+    nn.Module detectors; text-tower tensors are routed to the text backbone."""
+    from wedetect_amd import weights as W
+    from wedetect_amd.detector import SimpleYOLOWorldDetector, YOLOWorldDetector
+    sd = {k: torch.from_numpy(v) for k, v in W.make_state_dict("nano").items()}
+    d = YOLOWorldDetector("nano")
+    msg = d.load_state_dict({"state_dict": dict(sd, **{"bbox_head.x.num_batches_tracked": torch.zeros(1)})})
+    assert not msg.missing_keys and not msg.unexpected_keys
+    back = d.state_dict()
+    assert set(back) == set(sd) and all(torch.equal(back[k], sd[k]) for k in sd)
+    d2 = YOLOWorldDetector("nano")
+    missing, unexpected, errors = [], [], []
+    d2._load_from_state_dict({"module." + k: v for k, v in sd.items()}, "module.", {}, True, missing, unexpected, errors)
+    assert not missing and not unexpected and not errors and set(d2.state_dict()) == set(sd)
+    errors = []
+    d2._load_from_state_dict({}, "", {}, True, [], [], errors)
+    assert errors and "missing" in errors[0]
+    assert torch.nn.Module.load_state_dict is not type(d2).load_state_dict
+    u = SimpleYOLOWorldDetector("nano", num_prompts=4)
+    usd = W.make_state_dict("nano", num_prompts=4)
+    u.load_state_dict(W.to_uni_keys(usd), strict=True)
+    assert set(u.state_dict(prefix="m.")) == {"m." + k for k in usd}
+
+
+def test_reparameterize_is_self_contained_with_a_config_text_model():
+    """yolo_world.py:58-61: a detector built from the config owns its text tower; without tokenizer files the failure
+    is a RuntimeError naming them, never a silent fallback.  Texts in data samples select / build banks (82-113)."""
+    from wedetect_amd.config import build_detector
+    from wedetect_amd.detector import DetDataSample, _flat_texts
+    ref = json.load(open(os.path.join(GOLDEN, "model_cfgs.json")))["tiny"]["model"]
+    m = build_detector(ref, img_scale=(640, 640))
+    assert m.backbone.text_model.model_name == "./xlm-roberta-base/"
+    with pytest.raises(RuntimeError, match="load_state_dict|tokenizer"):
+        m.reparameterize([["cat"], ["dog"], [" "]])
+    assert _flat_texts([["a"], ["b", "c"], "d"]) == ("a", "b", "d")
+    bank = torch.nn.functional.normalize(torch.randn(3, 768), dim=1)
+    m.set_text_embeddings(bank, [["cat"], ["dog"], [" "]])
+    s = DetDataSample(metainfo=dict(texts=["cat", "dog", " "], ori_shape=(10, 20)))      # LoadText's flat form
+    assert m._bank_for(s) is m.text_feats and m._bank_for(None) is m.text_feats
+    assert s.texts == ["cat", "dog", " "] and s.ori_shape == (10, 20) and s.pred_instances is None
+    with pytest.raises(RuntimeError):
+        m._bank_for(DetDataSample(metainfo=dict(texts=["bird"])))                # unseen class list needs the tower
+
+
+# ------------------------------------------------------------------------------------------ entry scripts (host logic)
+def test_entry_script_argument_surfaces(tmp_path):
+    import importlib.util
+    import infer_wedetect as iw
+    import generate_proposal as gp
+    a = iw.parse_args(["--config", "c.py", "--checkpoint", "w.pth", "--image", "x.jpg", "--text", "a,b", "--topk", "7",
+                       "--threshold", "0.2", "--device", "cuda:0", "--show", "--amp", "--output-dir", "o",
+                       "--cfg-options", "model.test_cfg.score_thr=0.01"])
+    assert (a.config, a.checkpoint, a.image, a.text, a.topk, a.threshold, a.output_dir) == ("c.py", "w.pth", "x.jpg", "a,b", 7, 0.2, "o")
+    assert a.cfg_options == {"model.test_cfg.score_thr": 0.01} and a.show and a.amp
+    assert iw.read_texts("person, dog ,cat") == [["person"], ["dog"], ["cat"], [" "]]     # infer_wedetect.py:165-167
+    f = tmp_path / "names.txt"
+    f.write_text("人\r\n自行车\n")
+    assert iw.read_texts(str(f)) == [["人"], ["自行车"], [" "]]
+    (tmp_path / "a.jpg").write_bytes(b"")
+    (tmp_path / "b.png").write_bytes(b"")
+    (tmp_path / "c.txt").write_bytes(b"")
+    assert [os.path.basename(p) for p in iw.list_images(str(tmp_path))] == ["a.jpg", "b.png"]
+    assert gp.model_size_of("ckpt/wedetect_base_uni.pth") == "base" and gp.model_size_of("x_large_uni.pth") == "large"
+    assert gp.SimpleYOLOWorldDetector.__name__ == "SimpleYOLOWorldDetector"
+    for name in ("extract_embedding", "retrieval_metric"):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "eval_retrieval", name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)                                             # importable without side effects
+        assert callable(mod.main)
+    ann = dict(images=[dict(id=7, file_name="a.jpg"), dict(id=9, file_name="b.jpg")],
+               categories=[dict(id=2, name="dog"), dict(id=1, name="cat")],
+               annotations=[dict(image_id=7, category_id=1), dict(image_id=9, category_id=1), dict(image_id=9, category_id=2)])
+    (tmp_path / "ann.json").write_text(json.dumps(ann))
+    names, gt = mod.ground_truth(str(tmp_path / "ann.json"))
+    assert names == ["cat", "dog"] and gt == {"cat": {7, 9}, "dog": {9}}
+
+
+# ------------------------------------------------------------------------------------------ cv2 resize oracle
+def test_cv2_resize_oracle_hand_vectors():
+    """OpenCV is absent (parity unpinned): the restatement is pinned to vectors derived by hand from the published
+    algorithm (oracle/cv2_resize.py header)."""
+    from oracle import cv2_resize as cv
+    px = lambda rows: np.asarray(rows, np.uint8)[..., None].repeat(3, axis=2)
+    # INTER_AREA, exact 2x: (a + b + c + d + 2) >> 2 — halves round UP (sum 2 -> 1), unlike cvRound
+    assert cv.cv2_resize_u8(px([[0, 1], [0, 1]]), (1, 1), "area")[0, 0, 0] == 1
+    assert cv.cv2_resize_u8(px([[0, 1], [2, 3]]), (1, 1), "area")[0, 0, 0] == 2
+    # INTER_AREA, exact 3x: cvRound(sum * float32(1/9)); 9 pixels summing to 13 -> 1.444 -> 1; to 14 -> 1.556 -> 2
+    a = np.zeros((3, 3), np.uint8); a[0, :] = (5, 4, 4)
+    assert cv.cv2_resize_u8(px(a), (1, 1), "area")[0, 0, 0] == 1
+    a[1, 0] = 1
+    assert cv.cv2_resize_u8(px(a), (1, 1), "area")[0, 0, 0] == 2
+    # exact 2 x 1 (x by 2, y by 1) is the fast path with area 2: cvRound(sum * 0.5), half to EVEN: (1+2)/2 = 1.5 -> 2, (2+3)/2 = 2.5 -> 2
+    assert cv.cv2_resize_u8(px([[1, 2, 2, 3]]), (2, 1), "area")[0, :, 0].tolist() == [2, 2]
+    # general path, 3 -> 2 columns (scale 1.5): weights (2/3, 1/3) and (1/3, 2/3)
+    tab = cv.area_tab(3, 2, 1.5)
+    assert [(d, s) for d, s, _ in tab] == [(0, 0), (0, 1), (1, 1), (1, 2)]
+    assert np.allclose([w for _, _, w in tab], [2 / 3, 1 / 3, 1 / 3, 2 / 3], atol=1e-7)
+    assert cv.cv2_resize_u8(px([[30, 60, 90]]), (2, 1), "area")[0, :, 0].tolist() == [40, 80]
+    # 5 -> 2 (scale 2.5): cell 0 = px0 + px1 + half px2; cell 1 = half px2 + px3 + px4
+    assert cv.cv2_resize_u8(px([[10, 20, 30, 40, 50]]), (2, 1), "area")[0, :, 0].tolist() == [18, 42]
+    # rows too: 3 x 3 -> 2 x 2 of a separable ramp
+    img = px(np.add.outer([0, 30, 60], [30, 60, 90]))
+    assert cv.cv2_resize_u8(img, (2, 2), "area")[..., 0].tolist() == [[50, 90], [90, 130]]
+    # INTER_LINEAR 2 -> 4: taps (2048,0) (1536,512) (512,1536) (2048,0); fixed point rounds 12.5 -> 13, 17.5 -> 18
+    ofs, coef, xmax, raw, rawcoef = cv.linear_tab(2, 4, 0.5)
+    assert ofs.tolist() == [0, 0, 0, 1] and coef.tolist() == [[2048, 0], [1536, 512], [512, 1536], [2048, 0]] and xmax == 3
+    assert raw.tolist() == [-1, 0, 0, 1] and rawcoef[0].tolist() == [512, 1536]   # rows keep the fraction at the border
+    assert cv.cv2_resize_u8(px([[10, 20]]), (4, 1), "bilinear")[0, :, 0].tolist() == [10, 13, 18, 20]
+    assert cv.cv2_resize_u8(px([[10], [20]]), (1, 4), "bilinear")[:, 0, 0].tolist() == [10, 13, 18, 20]
+    # exact 2x down-scale asked as bilinear is computed as area (resize.cpp)
+    assert np.array_equal(cv.cv2_resize_u8(px([[0, 1], [0, 1]]), (1, 1), "bilinear"), cv.cv2_resize_u8(px([[0, 1], [0, 1]]), (1, 1), "area"))
+    # constant images stay constant in every mode; outputs stay inside the input range
+    g = np.random.default_rng(0)
+    for (h, w), (dh, dw), mode in (((37, 53), (20, 31), "area"), ((40, 60), (20, 20), "area"), ((9, 7), (23, 31), "bilinear")):
+        const = np.full((h, w, 3), 77, np.uint8)
+        assert np.all(cv.cv2_resize_u8(const, (dw, dh), mode) == 77)
+        rnd = g.integers(40, 200, (h, w, 3), dtype=np.uint8)
+        out = cv.cv2_resize_u8(rnd, (dw, dh), mode)
+        assert out.shape == (dh, dw, 3) and out.min() >= 40 and out.max() <= 199
+    # the pipeline composition: keep-ratio + letter pad with the reference's geometry
+    img = g.integers(0, 256, (300, 500, 3), dtype=np.uint8)
+    small = cv.keep_ratio_resize(img, (640, 640))
+    assert small.shape == (384, 640, 3)                                           # enlarged (ratio 1.28): bilinear
+    canvas, pad = cv.letter_pad(small, (640, 640))
+    assert canvas.shape == (640, 640, 3) and pad.tolist() == [128.0, 128.0, 0.0, 0.0]
+    assert np.all(canvas[:128] == 114) and np.array_equal(canvas[128:512], small)
+    with pytest.raises(NotImplementedError):
+        cv.cv2_resize_u8(img, (600, 200), "area")
+
+
+def test_pipeline_host_tables_match_the_oracle_tables():
+    """wedetect_amd.pipeline's plan (what the device kernel consumes) carries the same taps / weights / coefficients
+    as the oracle's table functions, for every mode, and the geometry equals mmdet_test_geometry (pinned to the
+    reference's transform code on 156 sizes)."""
+    from oracle import cv2_resize as cv
+    from wedetect_amd import lib as L
+    from wedetect_amd import pipeline as P
+    from wedetect_amd.preprocess import mmdet_test_geometry
+    for (sh, sw), (dh, dw) in (((720, 1280), (360, 640)), ((1080, 1920), (360, 640)), ((500, 375), (640, 480)), ((427, 640), (427, 640)),
+                               ((1000, 750), (640, 480)), ((33, 47), (20, 31))):
+        interp = "area" if dh < sh else "bilinear"
+        plan = P.resize_plan(sh, sw, dh, dw, interp)
+        sx, sy, isx, isy, fast = cv.resize_scales((sh, sw), (dh, dw))
+        if (sh, sw) == (dh, dw):
+            assert plan["mode"] == L.CVRESIZE_COPY
+        elif interp == "area" and fast:
+            assert plan["mode"] == L.CVRESIZE_AREA_FAST and (plan["p0"], plan["p1"]) == (isx, isy)
+            assert plan["p2"] == float(np.float32(1.0) / np.float32(isx * isy))
+        elif interp == "area":
+            assert plan["mode"] == L.CVRESIZE_AREA
+            for axis, (ss, ds, sc) in (("x", (sw, dw, sx)), ("y", (sh, dh, sy))):
+                tab = cv.area_tab(ss, ds, sc)
+                rng, idx, wts = plan[axis + "a"], plan[axis + "idx"], plan[axis + "w"]
+                assert idx.tolist() == [s for _, s, _ in tab] and wts.dtype == np.float32
+                assert np.array_equal(wts, np.asarray([w for _, _, w in tab], np.float32))
+                dest = [d for d, _, _ in tab]
+                assert rng[:, 1].sum() == len(tab) and all(dest[rng[d, 0]: rng[d, 0] + rng[d, 1]] == [d] * rng[d, 1] for d in range(ds))
+        else:
+            assert plan["mode"] == L.CVRESIZE_LINEAR
+            ofs, coef, xmax, _, _ = cv.linear_tab(sw, dw, sx)
+            _, _, _, raw, rawcoef = cv.linear_tab(sh, dh, sy)
+            assert plan["xidx"].tolist() == ofs.tolist() and plan["xa"].tolist() == coef.tolist() and plan["p0"] == xmax
+            assert plan["yidx"].tolist() == raw.tolist() and plan["ya"].tolist() == rawcoef.tolist()
+    # transforms' bookkeeping == mmdet_test_geometry (itself equal to the reference's code on the golden sizes)
+    kr = P.WeDetectKeepRatioResize(scale=(640, 640))
+    for h, w in ((720, 1280), (1080, 1920), (500, 375), (427, 640), (480, 640), (300, 500), (641, 13), (64, 64)):
+        geo = mmdet_test_geometry(h, w, (640, 640))
+        r = kr(dict(img_shape=(h, w)))
+        assert r["img_shape"] == geo["resized_shape"]
+        pend = r.get("_pending_resize")
+        assert (pend is None) == (geo["resized_shape"] == (h, w))
+        if pend is not None:
+            assert pend[:2] == geo["resized_shape"] and pend[2] == ("area" if max(h, w) > 640 or (min(h, w) > 640) else "bilinear")
+    with pytest.raises(TypeError):
+        P.WeDetectKeepRatioResize(scale=640)
+    with pytest.raises(NotImplementedError):
+        P.WeDetectLetterResize(scale=(640, 640), use_mini_pad=True)
+    lt = P.LoadText()
+    assert lt(dict(texts=[["cat", "kitty"], ["dog"], [" "]]))["texts"] == ["cat", "dog", " "]
+    with pytest.raises(AssertionError):
+        lt(dict())
+    pk = P.PackDetInputs(meta_keys=("img_id", "ori_shape", "pad_param", "texts", "absent"))
+    out = pk(dict(img=np.zeros((4, 6, 3), np.uint8), img_id=3, ori_shape=(4, 6), pad_param=np.zeros(4, np.float32), texts=["a"], junk=1))
+    assert tuple(out["inputs"].shape) == (3, 4, 6) and out["data_samples"].metainfo.keys() == {"img_id", "ori_shape", "pad_param", "texts"}
+    comp = P.Compose([dict(type="LoadAnnotations"), dict(type="LoadText"), lambda d: None, dict(type="LoadText")])
+    assert comp(dict(texts=[["a"]])) is None and "LoadText" in repr(comp)
+
+
+def test_instance_and_sample_containers():
+    from wedetect_amd.detector import DetDataSample, InstanceData
+    d = InstanceData(bboxes=torch.arange(12.).view(3, 4), scores=torch.tensor([0.9, 0.2, 0.5]), labels=torch.tensor([1, 2, 3]))
+    assert len(d[1]) == 1 and d[1].labels.tolist() == [2] and d[-1].labels.tolist() == [3] and len(d[0:2]) == 2
+    assert d[torch.tensor([2, 0])].labels.tolist() == [3, 1] and set(d.keys()) == {"bboxes", "scores", "labels"}
+    assert dict(d.items())["scores"] is d.scores and d.get("nope") is None and "bboxes" in d
+    with pytest.raises(IndexError):
+        d[5]
+    with pytest.raises(AssertionError):
+        d.extra = torch.zeros(2)
+    d.extra = torch.zeros(3)
+    assert "extra" in d.to("cpu").detach().numpy().keys()
+    s = DetDataSample(metainfo=dict(img_id=4))
+    s.pred_instances = d
+    s.set_metainfo(dict(ori_shape=(2, 3)))
+    assert s.img_id == 4 and s.ori_shape == (2, 3) and "pred_instances" in s and s.cpu().pred_instances.labels.tolist() == [1, 2, 3]
+    with pytest.raises(AttributeError):
+        s.nothing
+
+
+# ------------------------------------------------------------------------------------------ ragged gather, gloo world 3
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _ragged_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from wedetect_amd.parallel import RegionGatherer, gather_ragged, gather_regions, shard_range
+    out = {}
+    for total in (7, 2, 9):                                  # 7 -> 3 + 2 + 2; 2 -> 1 + 1 + 0 (an empty rank); 9 -> equal
+        ids = list(shard_range(total, world, rank))
+        emb = torch.stack([torch.full((4, 8), float(i)) for i in ids]) if ids else torch.zeros(0, 4, 8)
+        cnt = torch.tensor([i % 4 + 1 for i in ids], dtype=torch.int32)
+        g = gather_regions(emb, cnt)
+        r = gather_ragged(dict(image_id=torch.tensor(ids, dtype=torch.int64), scale=torch.tensor([[0.5 * i] * 4 for i in ids]).view(-1, 4)))
+        out[total] = (g["embeddings"][:, 0, 0].tolist(), g["count"].tolist(), r["image_id"].tolist(), r["scale"][:, 3].tolist(),
+                      tuple(g["embeddings"].shape))
+    try:
+        gather_ragged(dict(a=torch.zeros(2), b=torch.zeros(3)))
+        out["mismatch"] = "no error"
+    except ValueError:
+        out["mismatch"] = "ValueError"
+    # pipelined per-step exchange with a padded short final batch (count = 0 rows)
+    rg = RegionGatherer()
+    steps = []
+    for step, n_valid in enumerate((2, 2, 1 if rank == 0 else 0)):
+        emb = torch.full((2, 4, 8), float(10 * step + rank))
+        cnt = torch.tensor([3, 4], dtype=torch.int32)
+        cnt[n_valid:] = 0
+        prev = rg.submit(emb, cnt)
+        emb.zero_()
+        if prev is not None:
+            steps.append((prev["embeddings"][:, 0, 0].tolist(), prev["count"].tolist()))
+    last = rg.collect()
+    steps.append((last["embeddings"][:, 0, 0].tolist(), last["count"].tolist()))
+    out["steps"] = steps
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_ragged_gather_world3_gloo():
+    """unequal shards (InferenceSampler gives the first total % world ranks one more image,
+    extract_embedding.py:1631-1638), an EMPTY rank, and the short final batch of the pipelined gatherer."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 3
+    procs = [ctx.Process(target=_ragged_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out in outs:
+        for total in (7, 2, 9):
+            e0, cnt, ids, sc, shape = out[total]
+            assert ids == list(range(total)), (rank, total, ids)                  # global image order on every rank
+            assert e0 == [float(i) for i in range(total)] and cnt == [i % 4 + 1 for i in range(total)]
+            assert sc == [0.5 * i for i in range(total)] and shape == (total, 4, 8)
+        assert out["mismatch"] == "ValueError"
+        st = out["steps"]
+        assert len(st) == 3
+        assert st[0] == ([0.0, 0.0, 1.0, 1.0, 2.0, 2.0], [3, 4, 3, 4, 3, 4])
+        assert st[2] == ([20.0, 20.0, 21.0, 21.0, 22.0, 22.0], [3, 0, 0, 0, 0, 0])  # padded rows carry count 0
+
+
+def test_region_gatherer_single_process_does_not_alias_the_callers_buffers():
+    """without a process group submit() must stage a copy too — the tower overwrites its output
+    buffers in the next step, before the previous result is handed out."""
+    from wedetect_amd.parallel import RegionGatherer
+    rg = RegionGatherer()
+    emb, cnt = torch.zeros(2, 3, 4), torch.zeros(2, dtype=torch.int32)
+    seen = []
+    for step in range(4):
+        emb.fill_(float(step))
+        cnt.fill_(step)
+        prev = rg.submit(emb, cnt)                             # the same tensors every step, like tower.out_embed
+        if prev is not None:
+            seen.append((float(prev["embeddings"][0, 0, 0]), int(prev["count"][0])))
+    emb.fill_(99.0)
+    last = rg.collect()
+    seen.append((float(last["embeddings"][0, 0, 0]), int(last["count"][0])))
+    assert seen == [(0.0, 0), (1.0, 1), (2.0, 2), (3.0, 3)]

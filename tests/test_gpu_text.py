@@ -93,7 +93,7 @@ def test_language_backbone_surface_feeds_the_detector():
         ids = torch.tensor([r + [1] * (ln - len(r)) for r in rows])
         return {"input_ids": ids, "attention_mask": (ids != 1).long()}
 
-    tb = XLMRobertaLanguageBackbone("base", tokenizer=tokenizer).load_state_dict(sd)
+    tb = XLMRobertaLanguageBackbone(model_size="base", tokenizer=tokenizer).load_state_dict(sd)
     texts = [["person", "traffic light", "dog"], ["cat", "kite", "bicycle rack"]]
     feats = tb(texts)
     assert feats.shape == (2, 3, 768)
@@ -107,4 +107,4 @@ def test_language_backbone_surface_feeds_the_detector():
     with pytest.raises(AssertionError):
         tb([["a", "b"], ["c"]])
     with pytest.raises(RuntimeError):
-        XLMRobertaLanguageBackbone("base")([["a"]])
+        XLMRobertaLanguageBackbone(model_size="base")([["a"]])

@@ -16,6 +16,7 @@ from __future__ import annotations
 from typing import Callable, Dict, Optional, Sequence
 
 from .arch import CLS_MID, EMBED_DIM, REG_MAX, REG_MID, STRIDES, get_arch
+from .registry import MODELS
 
 # registry type names of config/wedetect_*.py -> what they are here
 MODEL_TYPES = {
@@ -123,15 +124,20 @@ def check_model_cfg(model_cfg: dict) -> str:
 
 
 def build_detector(model_cfg: dict, img_scale: Optional[Sequence[int]] = None, text_encoder: Optional[Callable] = None,
-                   precision: Optional[str] = None):
+                   precision: Optional[str] = None, tokenizer=None):
     """``MODELS.build(cfg.model)`` for this package: the reference's model dict -> ``YOLOWorldDetector`` (not yet on a
-    device, no weights: ``load_state_dict`` / ``.cuda()`` / ``reparameterize`` follow as in infer_wedetect.py:102-116).
-    ``img_scale``: the config's ``img_scale`` (test pipeline target; default per size)."""
-    from .detector import YOLOWorldDetector
+    device, no weights: ``load_state_dict`` / ``.cuda()`` / ``reparameterize`` follow as in infer_wedetect.py:102-116),
+    with the text tower the config names wired in.  ``img_scale``: the config's ``img_scale``, written (w, h) as
+    mmdet does (config/wedetect_base.py:109, transforms.py:190 reverses it); kept as the default (H, W) input shape."""
     size = check_model_cfg(model_cfg)
-    return YOLOWorldDetector(model_size=size, img_scale=img_scale, test_cfg=dict(model_cfg.get("test_cfg") or {}),
-                             text_encoder=text_encoder, max_classes=int(model_cfg.get("num_test_classes", 1203)),
-                             precision=precision)
+    hw = None
+    if img_scale is not None:
+        if len(img_scale) != 2:
+            raise TypeError("img_scale must be a (w, h) pair")
+        hw = (int(img_scale[1]), int(img_scale[0]))
+    det = MODELS.build(dict(model_cfg), img_scale=hw, text_encoder=text_encoder, precision=precision, tokenizer=tokenizer)
+    assert det.model_size == size
+    return det
 
 
 def pipeline_plan(test_pipeline: Sequence[dict]) -> Dict[str, str]:
@@ -147,3 +153,80 @@ def pipeline_plan(test_pipeline: Sequence[dict]) -> Dict[str, str]:
             _require(not step.get("allow_scale_up", False), "WeDetectLetterResize.allow_scale_up=True")
         plan[t] = PIPELINE_TYPES[t]
     return plan
+
+
+# ------------------------------------------------------------------------------------------------------
+# registry entries for the component names of the configs.  The image side is ONE fused launch sequence
+# (engine.ImageTower), so these are specification objects: they take the reference constructors' keywords,
+# keep them, and refuse at construction what the tower does not implement — ``MODELS.build`` of any
+# sub-dict of a shipped config resolves, and a stock mmengine registry (register_with_mmengine) finds the
+# same names.  YOLOWorldDetector consumes the dicts directly (check_model_cfg above).
+# ------------------------------------------------------------------------------------------------------
+class _Spec:
+    TYPE = ""
+
+    def __init__(self, **kw):
+        self.cfg = dict(kw, type=self.TYPE)
+
+    def __repr__(self):
+        return f"{self.TYPE}({', '.join(f'{k}={v!r}' for k, v in self.cfg.items() if k != 'type')})"
+
+    def __call__(self, *a, **kw):
+        raise NotImplementedError(f"{self.TYPE} is part of the fused image tower (wedetect_amd.engine.ImageTower) and has no "
+                                  "stand-alone forward; run YOLOWorldDetector.predict / test_step")
+
+
+def _spec(name: str, check=None, doc: str = ""):
+    def __init__(self, **kw):
+        _Spec.__init__(self, **kw)
+        if check is not None:
+            check(self.cfg)
+    cls = type(name, (_Spec,), dict(TYPE=name, __init__=__init__, __doc__=doc or MODEL_TYPES.get(name, "")))
+    MODELS.register_module(module=cls)
+    return cls
+
+
+def _check_image_model(c):
+    get_arch(c["model_name"])
+
+
+def _check_neck(c):
+    size = c.get("model_size")
+    if size is not None:
+        _require(float(c.get("scale_factor", 0.75)) == float(get_arch(size).neck_scale),
+                 f"neck.scale_factor {c.get('scale_factor', 0.75)} for size {size!r}")
+
+
+def _check_head_module(c):
+    _require(bool(c.get("use_bn_head", False)), "head_module.use_bn_head=False (ContrastiveHead without BatchNorm)")
+    _require(int(c.get("embed_dims", EMBED_DIM)) == EMBED_DIM, f"head_module.embed_dims {c.get('embed_dims')}")
+
+
+def _check_preproc(c):
+    _require([float(v) for v in c.get("mean", [0.0] * 3)] == [0.0] * 3, f"data_preprocessor.mean {c.get('mean')}")
+    _require([float(v) for v in c.get("std", [255.0] * 3)] == [255.0] * 3, f"data_preprocessor.std {c.get('std')}")
+    _require(bool(c.get("bgr_to_rgb", True)), "data_preprocessor.bgr_to_rgb=False")
+
+
+def _check_priors(c):
+    _require(float(c.get("offset", 0.5)) == 0.5 and tuple(c.get("strides", STRIDES)) == STRIDES, f"prior_generator {c}")
+
+
+ConvNextVisionBackbone = _spec("ConvNextVisionBackbone", _check_image_model)
+CSPRepBiFPANNeck = _spec("CSPRepBiFPANNeck", _check_neck)
+YOLOWorldHeadModule = _spec("YOLOWorldHeadModule", _check_head_module)
+YOLOWorldHead = _spec("YOLOWorldHead")
+YOLOWDetDataPreprocessor = _spec("YOLOWDetDataPreprocessor", _check_preproc)
+MlvlPointGenerator = _spec("MlvlPointGenerator", _check_priors)
+WeDetectDistancePointBBoxCoder = _spec("WeDetectDistancePointBBoxCoder")
+for _n in TRAINING_ONLY_TYPES:
+    _spec(_n, doc="training-only entry of the configs: constructed and kept, never evaluated on the inference path")
+
+
+def _register_text_backbone():
+    from .text import XLMRobertaLanguageBackbone
+    MODELS.register_module(module=XLMRobertaLanguageBackbone)
+
+
+_register_text_backbone()
+from . import detector as _detector  # noqa: E402,F401  (registers YOLOWorldDetector / MultiModalYOLOBackbone)

@@ -5,24 +5,31 @@ Mirrors (names, arguments, return structures, error behaviour):
         model = SimpleYOLOWorldDetector('base', prompt_dim=768, num_prompts=256)
         model.load_state_dict(ckpt, strict=False); model.cuda(); model.eval()
         outputs = model([path_or_PIL, ...])  ->  list of dict(bboxes, embeddings, scores, labels, scales, bias)
-  * ``YOLOWorldDetector``        wedetect/models/detectors/yolo_world.py:19-113
+  * ``YOLOWorldDetector``        wedetect/models/detectors/yolo_world.py:19-113, built either from the reference's
+        config keywords (``MODELS.build(cfg.model)``: mm_neck, num_train_classes, num_test_classes,
+        data_preprocessor, backbone, neck, bbox_head, train_cfg, test_cfg) or directly by size name
         model.reparameterize(texts) / model.test_step(dict(inputs=[...], data_samples=[...]))
         -> data samples with ``.pred_instances.{bboxes, scores, labels}`` (infer_wedetect.py:117-131)
 
-All tensor math is done by libwedetect_hip.so through ``ImageTower``; this file only does
-host-side bookkeeping (PIL letterbox, metadata, result containers).  There is no CPU
-fallback: constructing a detector without a HIP device / the built library raises.
+Both are ``torch.nn.Module``s without parameters of their own: the weights live in packed device buffers owned by
+``ImageTower``; ``load_state_dict`` / ``state_dict`` / ``_load_from_state_dict`` (what mmengine's ``load_checkpoint``
+walks) take and return the reference's key layout.  All tensor math is done by libwedetect_hip.so through
+``ImageTower``; this file only does host-side bookkeeping.  There is no CPU fallback: running a detector without a HIP
+device / the built library raises.
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, List, Optional, Sequence, Union
+from collections import OrderedDict
+from typing import Callable, Dict, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 import torch
 
 from .arch import EMBED_DIM, all_params, get_arch
+from .registry import MODELS
 
 _IMG_SIZE = {"tiny": (640, 640), "base": (640, 640), "large": (1280, 1280), "nano": (128, 128)}
+MAX_OUT_ROWS = 1024          # wd_nms_gather keeps its kept-list in LDS (include/wedetect_hip.h)
 
 
 # ------------------------------------------------------------------------------------------
@@ -92,15 +99,18 @@ def letterbox(img, new_shape=(640, 640), color=(114, 114, 114)):
 
 
 class _TowerHolder:
-    """Shared plumbing: weights -> packed device tensors -> ImageTower per batch size."""
+    """Shared plumbing: weights -> packed device tensors -> one ImageTower per (batch, H, W)."""
 
-    def __init__(self, arch: str, num_prompts: int, img_size, max_classes: int, max_out: int,
-                 precision: Optional[str] = None):
+    def __init__(self, arch: str, num_prompts: int, max_classes: int, max_out: int, precision: Optional[str] = None,
+                 nms_pre: int = 30000):
+        if max_out > MAX_OUT_ROWS:
+            raise NotImplementedError(f"max_per_img / num_proposals {max_out} > {MAX_OUT_ROWS} (the NMS kernel's kept-list capacity)")
+        if nms_pre < 1:
+            raise ValueError("nms_pre must be positive")
         self.arch = get_arch(arch)
         self.precision = precision
         self.num_prompts = num_prompts
-        self.img_size = tuple(img_size)
-        self.max_classes, self.max_out = max_classes, max_out
+        self.max_classes, self.max_out, self.nms_pre = max_classes, max_out, nms_pre
         self._sd: Optional[Dict[str, np.ndarray]] = None
         self._packed = None
         self._towers = {}
@@ -125,7 +135,10 @@ class _TowerHolder:
         self._towers.clear()
         return _IncompatibleKeys(missing, unexpected)
 
-    def tower(self, batch: int):
+    def state(self) -> "OrderedDict[str, torch.Tensor]":
+        return OrderedDict((k, torch.from_numpy(np.array(v))) for k, v in (self._sd or {}).items())
+
+    def tower(self, batch: int, height: int, width: int):
         from .engine import ImageTower
         from .pack import pack
         if self._sd is None:
@@ -134,70 +147,101 @@ class _TowerHolder:
             raise RuntimeError("model is not on a HIP device: call .cuda() (there is no CPU execution path)")
         if self._packed is None:
             self._packed = pack(self._sd, self.arch, self.device)
-        if batch not in self._towers:
-            self._towers[batch] = ImageTower(self.arch, self._packed, batch, self.img_size[0], self.img_size[1],
-                                             device=self.device, max_classes=self.max_classes, max_out=self.max_out,
-                                             precision=self.precision)
-        return self._towers[batch]
+        key = (batch, height, width)
+        if key not in self._towers:
+            if len(self._towers) >= 4:                       # each tower owns its activation buffers
+                self._towers.pop(next(iter(self._towers)))
+            self._towers[key] = ImageTower(self.arch, self._packed, batch, height, width, device=self.device,
+                                           max_classes=self.max_classes, max_out=self.max_out, nms_pre=self.nms_pre,
+                                           precision=self.precision)
+        return self._towers[key]
+
+
+class _DeviceModule(torch.nn.Module):
+    """nn.Module plumbing shared by the two detectors: no parameters, weights in ``self._h`` (a _TowerHolder)."""
+
+    _h: _TowerHolder
+
+    def cuda(self, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible: wedetect_amd has no CPU execution path")
+        if isinstance(device, (str, torch.device)):
+            device = torch.device(device).index
+        self._h.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self._on_device(self._h.device)
+        return self
+
+    def _on_device(self, device) -> None:
+        pass
+
+    def to(self, *args, **kwargs):
+        device, dtype, _, _ = torch._C._nn._parse_to(*args, **kwargs)
+        if dtype is not None and dtype != torch.float32:
+            raise NotImplementedError("the device path computes in fp32 / fp16x3 (ImageTower precision=...); "
+                                      f"casting the module to {dtype} is not supported")
+        if device is not None:
+            if device.type != "cuda":
+                raise RuntimeError(f"cannot move to {device}: wedetect_amd has no CPU execution path")
+            return self.cuda(device)
+        return self
+
+    def half(self):
+        return self.to(torch.float16)
+
+    def bfloat16(self):
+        return self.to(torch.bfloat16)
+
+    def cpu(self):
+        raise RuntimeError("wedetect_amd has no CPU execution path")
+
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        out = OrderedDict() if destination is None else destination
+        for k, v in self._h.state().items():
+            out[prefix + k] = v
+        return out
+
+    def _load_state(self, state_dict, strict: bool):
+        return self._h.load(state_dict, strict)
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        if "state_dict" in state_dict and isinstance(state_dict["state_dict"], dict):
+            state_dict = state_dict["state_dict"]           # mmengine checkpoint wrapper
+        return self._load_state(state_dict, strict)
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        """The hook torch's and mmengine's recursive loaders call per module: this module takes every key under
+        its prefix (there are no child modules holding parameters)."""
+        sub = {k[len(prefix):]: v for k, v in state_dict.items() if k.startswith(prefix)}
+        try:
+            msg = self._load_state(sub, False)
+        except RuntimeError as e:
+            error_msgs.append(str(e))
+            return
+        missing_keys.extend(prefix + k for k in msg.missing_keys)
+        if strict:
+            unexpected_keys.extend(prefix + k for k in msg.unexpected_keys)
 
 
 # ------------------------------------------------------------------------------------------
 # WeDetect-Uni: proposals + embeddings
 # ------------------------------------------------------------------------------------------
-class SimpleYOLOWorldDetector:
+class SimpleYOLOWorldDetector(_DeviceModule):
     """Drop-in for generate_proposal.py:1052 / extract_embedding.py:1088."""
 
     def __init__(self, backbone_size, prompt_dim=768, num_prompts=512, num_proposals=300, img_size=None,
                  precision: Optional[str] = None):
+        super().__init__()
         if prompt_dim != EMBED_DIM:
             raise ValueError("prompt_dim must be 768")
         self.backbone_size = backbone_size
         self.num_proposals = num_proposals
         self.img_size = tuple(img_size) if img_size is not None else _IMG_SIZE[backbone_size]
-        self._h = _TowerHolder(backbone_size, num_prompts, self.img_size, max(num_prompts, 1), num_proposals, precision)
+        self._h = _TowerHolder(backbone_size, num_prompts, max(num_prompts, 1), num_proposals, precision)
         self._lb = None
-        self.training = False
-
-    # -- nn.Module-like surface used by the reference scripts
-    def load_state_dict(self, state_dict, strict: bool = True):
-        return self._h.load(state_dict, strict)
-
-    def cuda(self, device=None):
-        if not torch.cuda.is_available():
-            raise RuntimeError("no HIP device visible: wedetect_amd has no CPU execution path")
-        self._h.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
-        return self
-
-    def eval(self):
-        self.training = False
-        return self
-
-    def __call__(self, image_paths, rescale=True):
-        return self.forward(image_paths, rescale)
 
     @torch.no_grad()
     def forward(self, image_paths: Sequence[Union[str, object]], rescale=True) -> List[Dict[str, torch.Tensor]]:
-        from PIL import Image
-        from .preprocess import DeviceLetterbox
-        if self._h.device is None:
-            raise RuntimeError("model is not on a HIP device: call .cuda() (there is no CPU execution path)")
-        imgs, metas = [], []
-        for p in image_paths:
-            imgs.append(Image.open(p).convert("RGB") if isinstance(p, str) else p)
-        # letterbox on the device (wd_letterbox_u8, bit-exact with the PIL resize + paste of the
-        # reference): the host only decodes and uploads
-        if self._lb is None:
-            self._lb = DeviceLetterbox(self.img_size, device=self._h.device)
-        x, ratios, pads = self._lb(imgs)
-        for img, ratio, (dw, dh) in zip(imgs, ratios, pads):
-            w, h = img.size
-            sc = ratio if rescale else 1.0
-            metas.append([dw, dh, 0.0, sc, sc, float(w), float(h), 0.0])
-        b = len(imgs)
-        tower = self._h.tower(b)
-        meta = torch.tensor(metas, dtype=torch.float32, device=self._h.device)
-        res = tower.detect(x, tower.P["prompts"], meta, normalize_text=False, score_thr=0.0, with_embed=True)
-        counts = res["count"].tolist()                      # one D2H sync per batch
+        res, counts, tower = self.forward_batch(image_paths, rescale)
         out = []
         ls = torch.tensor(tower.lvl_logit_scale, dtype=torch.float32, device=self._h.device)
         cb = torch.tensor(tower.lvl_bias, dtype=torch.float32, device=self._h.device)
@@ -213,105 +257,342 @@ class SimpleYOLOWorldDetector:
             })
         return out
 
+    @torch.no_grad()
+    def forward_batch(self, image_paths: Sequence[Union[str, object]], rescale=True):
+        """The same step with the results left in the tower's fixed-shape device buffers ([B, R, ...] + counts):
+        what the multi-GPU gather exchanges (parallel.gather_results).  Returns (buffers, counts list, tower)."""
+        from PIL import Image
+        from .preprocess import DeviceLetterbox
+        if self._h.device is None:
+            raise RuntimeError("model is not on a HIP device: call .cuda() (there is no CPU execution path)")
+        imgs, metas = [], []
+        for p in image_paths:
+            imgs.append(Image.open(p).convert("RGB") if isinstance(p, str) else p)
+        # letterbox on the device (wd_letterbox_u8, bit-exact with the PIL resize + paste of the
+        # reference): the host only decodes and uploads
+        if self._lb is None:
+            self._lb = DeviceLetterbox(self.img_size, device=self._h.device)
+        x, ratios, pads = self._lb(imgs)
+        for img, ratio, (dw, dh) in zip(imgs, ratios, pads):
+            w, h = img.size if hasattr(img, "size") and not isinstance(img, (np.ndarray, torch.Tensor)) else (img.shape[1], img.shape[0])
+            sc = ratio if rescale else 1.0
+            metas.append([dw, dh, 0.0, sc, sc, float(w), float(h), 0.0])
+        tower = self._h.tower(len(imgs), self.img_size[0], self.img_size[1])
+        meta = torch.tensor(metas, dtype=torch.float32, device=self._h.device)
+        res = tower.detect(x, tower.P["prompts"], meta, normalize_text=False, score_thr=0.0, with_embed=True)
+        counts = res["count"].tolist()                      # one D2H sync per batch
+        return res, counts, tower
+
 
 # ------------------------------------------------------------------------------------------
 # WeDetect: open-vocabulary detection against a text bank
 # ------------------------------------------------------------------------------------------
 class InstanceData:
-    """Minimal stand-in for mmengine.structures.InstanceData as infer_wedetect.py uses it:
-    attribute and item access, boolean-mask / index ``__getitem__``, ``cpu()``, ``numpy()``."""
+    """Stand-in for mmengine.structures.InstanceData as the reference's scripts and mmdet's result handling use
+    it: attribute and item access, boolean-mask / index / slice ``__getitem__``, ``len``, ``keys/values/items``,
+    ``cpu / cuda / to / detach / numpy``, ``in``."""
 
-    def __init__(self, **fields):
+    def __init__(self, metainfo: Optional[dict] = None, **fields):
         object.__setattr__(self, "_f", dict(fields))
+        object.__setattr__(self, "_meta", dict(metainfo or {}))
 
     def __getattr__(self, k):
         try:
             return self._f[k]
         except KeyError:
-            raise AttributeError(k)
+            if k in self._meta:
+                return self._meta[k]
+            raise AttributeError(f"InstanceData has no field {k!r}") from None
 
     def __setattr__(self, k, v):
+        if self._f and hasattr(v, "__len__") and len(v) != len(self):
+            raise AssertionError(f"the length of values {len(v)} is not consistent with the length of this InstanceData {len(self)}")
         self._f[k] = v
+
+    def __delattr__(self, k):
+        del self._f[k]
 
     def __getitem__(self, item):
         if isinstance(item, str):
             return self._f[item]
-        return InstanceData(**{k: v[item] for k, v in self._f.items()})
+        if isinstance(item, int):
+            if item >= len(self) or item < -len(self):
+                raise IndexError(f"index {item} out of range")
+            item = slice(item, None, len(self)) if item >= 0 else slice(item + len(self), None, len(self))
+        return InstanceData(self._meta, **{k: (v[item] if not isinstance(v, list) else _index_list(v, item)) for k, v in self._f.items()})
 
     def __contains__(self, k):
-        return k in self._f
+        return k in self._f or k in self._meta
 
     def __len__(self):
         return len(next(iter(self._f.values()))) if self._f else 0
 
+    def __repr__(self):
+        return "<InstanceData(" + ", ".join(f"{k}: {tuple(v.shape) if hasattr(v, 'shape') else type(v).__name__}" for k, v in self._f.items()) + ")>"
+
     def keys(self):
-        return self._f.keys()
+        return list(self._f.keys())
+
+    def values(self):
+        return list(self._f.values())
+
+    def items(self):
+        return list(self._f.items())
+
+    def get(self, k, default=None):
+        return self._f.get(k, default)
+
+    def _map(self, fn):
+        return InstanceData(self._meta, **{k: (fn(v) if isinstance(v, torch.Tensor) else v) for k, v in self._f.items()})
 
     def cpu(self):
-        return InstanceData(**{k: v.cpu() for k, v in self._f.items()})
+        return self._map(lambda t: t.cpu())
+
+    def cuda(self):
+        return self._map(lambda t: t.cuda())
+
+    def to(self, *a, **kw):
+        return self._map(lambda t: t.to(*a, **kw))
+
+    def detach(self):
+        return self._map(lambda t: t.detach())
 
     def numpy(self):
-        return InstanceData(**{k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in self._f.items()})
+        return InstanceData(self._meta, **{k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in self._f.items()})
 
 
-class YOLOWorldDetector:
+def _index_list(v: list, item):
+    if isinstance(item, slice):
+        return v[item]
+    idx = item.tolist() if hasattr(item, "tolist") else list(item)
+    if idx and isinstance(idx[0], bool):
+        return [x for x, m in zip(v, idx) if m]
+    return [v[i] for i in idx]
+
+
+class DetDataSample:
+    """Data sample as ``PackDetInputs`` builds it: ``metainfo`` (also readable as attributes: ``sample.texts``,
+    ``sample.ori_shape``, ...) + ``pred_instances`` / ``gt_instances``."""
+
+    def __init__(self, metainfo: Optional[dict] = None, **kw):
+        object.__setattr__(self, "_meta", dict(metainfo or {}))
+        object.__setattr__(self, "_data", {})
+        self._meta.update(kw)
+
+    @property
+    def metainfo(self) -> dict:
+        return self._meta
+
+    def set_metainfo(self, metainfo: dict) -> None:
+        self._meta.update(metainfo)
+
+    def metainfo_keys(self):
+        return list(self._meta.keys())
+
+    def keys(self):
+        return list(self._data.keys())
+
+    def __contains__(self, k):
+        return k in self._data or k in self._meta
+
+    def get(self, k, default=None):
+        return self._data.get(k, self._meta.get(k, default))
+
+    def __getattr__(self, k):
+        if k in self._data:
+            return self._data[k]
+        if k in self._meta:
+            return self._meta[k]
+        if k in ("pred_instances", "gt_instances", "ignored_instances"):
+            return None
+        raise AttributeError(f"DetDataSample has no attribute {k!r}")
+
+    def __setattr__(self, k, v):
+        self._data[k] = v
+
+    def _map(self, name, *a, **kw):
+        out = DetDataSample(self._meta)
+        for k, v in self._data.items():
+            out._data[k] = getattr(v, name)(*a, **kw) if hasattr(v, name) else v
+        return out
+
+    def cpu(self):
+        return self._map("cpu")
+
+    def cuda(self):
+        return self._map("cuda")
+
+    def to(self, *a, **kw):
+        return self._map("to", *a, **kw)
+
+    def numpy(self):
+        return self._map("numpy")
+
+
+def _meta_of(sample) -> dict:
+    if sample is None:
+        return {}
+    if isinstance(sample, dict):
+        return sample.get("metainfo", sample)
+    return getattr(sample, "metainfo", {}) or {}
+
+
+def _flat_texts(texts) -> Tuple[str, ...]:
+    """``[[a], [b]]`` (reparameterize, infer_wedetect.py:165-167), ``[a, b]`` (what LoadText leaves in a data sample,
+    mm_transforms.py:126-133) -> ``(a, b)``: one caption per class, the first of each list."""
+    return tuple((t[0] if isinstance(t, (list, tuple)) else t) for t in texts)
+
+
+class MultiModalYOLOBackbone:
+    """``model.backbone`` of the reference detector (mm_backbone.py:594-656) as far as inference callers touch it:
+    ``forward_text(texts)`` and ``with_text_model``.  The image side is the fused ``ImageTower``; it has no
+    per-module forward."""
+
+    def __init__(self, image_model, text_model=None, frozen_stages: int = -1, with_text_model: bool = True, **kw):
+        self.image_model = MODELS.build(image_model) if isinstance(image_model, dict) else image_model
+        self.text_model = MODELS.build(text_model) if isinstance(text_model, dict) else text_model
+        self.with_text_model = self.text_model is not None and with_text_model
+
+    def forward_text(self, text: List[List[str]]) -> torch.Tensor:
+        assert self.with_text_model, "forward_text() requires a text model"          # mm_backbone.py:648
+        return self.text_model(text)
+
+    def forward_image(self, image):
+        raise NotImplementedError("the image tower is one fused launch sequence (engine.ImageTower): use "
+                                  "YOLOWorldDetector.predict / test_step")
+
+
+class YOLOWorldDetector(_DeviceModule):
     """Drop-in for the configured ``YOLOWorldDetector`` (mm_neck=False, use_bn_head=True).
 
-    ``test_cfg`` keeps the reference's keys (config/wedetect_base.py:18-25).  The class bank comes
-    from a text tower: pass ``text_encoder`` (callable List[str] -> [K, 768] tensor, e.g.
-    ``wedetect_amd.text.XLMRobertaLanguageBackbone(...).encode_classes``) or set the bank directly
-    with ``set_text_embeddings``; ``reparameterize`` without either raises."""
+    Two ways to construct it.  (1) The reference's keywords, as ``MODELS.build(cfg.model)`` passes them
+    (yolo_world.py:15-24 + the mmdet single-stage detector's ``data_preprocessor, backbone, neck, bbox_head, train_cfg,
+    test_cfg``): the dicts are validated by ``config.check_model_cfg`` — unknown registry names raise ``KeyError``,
+    options outside the implemented path ``NotImplementedError`` — and the text tower named by
+    ``backbone.text_model`` is wired in, so ``reparameterize(texts)`` works as at yolo_world.py:58-61.
+    (2) ``YOLOWorldDetector("base", test_cfg=..., text_encoder=...)`` for callers without a config.
 
-    def __init__(self, model_size="base", img_scale=None, test_cfg=None, text_encoder: Optional[Callable] = None,
-                 max_classes: int = 1203, precision: Optional[str] = None):
+    ``test_cfg`` keeps the reference's keys (config/wedetect_base.py:18-25).  Inputs may have any H x W that is a
+    multiple of 32 (one ImageTower is kept per shape); ``img_scale`` = (H, W) is only the default shape."""
+
+    def __init__(self, model_size: Optional[str] = None, img_scale=None, test_cfg=None,
+                 text_encoder: Optional[Callable] = None, max_classes: Optional[int] = None, precision: Optional[str] = None,
+                 *, mm_neck: bool = False, num_train_classes: int = 80, num_test_classes: int = 80,
+                 data_preprocessor=None, backbone=None, neck=None, bbox_head=None, train_cfg=None, init_cfg=None,
+                 tokenizer=None):
+        super().__init__()
+        self.mm_neck, self.num_train_classes, self.num_test_classes = mm_neck, num_train_classes, num_test_classes
+        self.backbone: Optional[MultiModalYOLOBackbone] = None
+        if backbone is not None:
+            from .config import check_model_cfg
+            model_cfg = dict(type="YOLOWorldDetector", mm_neck=mm_neck, num_train_classes=num_train_classes,
+                             num_test_classes=num_test_classes, data_preprocessor=data_preprocessor, backbone=backbone,
+                             neck=neck, bbox_head=bbox_head, train_cfg=train_cfg, test_cfg=test_cfg)
+            size = check_model_cfg(model_cfg)
+            if model_size is not None and model_size != size:
+                raise ValueError(f"model_size={model_size!r} contradicts the config ({size!r})")
+            model_size = size
+            self.backbone = MultiModalYOLOBackbone(backbone["image_model"], backbone.get("text_model"))
+            if self.backbone.text_model is not None:
+                if tokenizer is not None:
+                    self.backbone.text_model.tokenizer = tokenizer
+                if precision is not None:
+                    self.backbone.text_model.precision = precision
+            if max_classes is None:
+                max_classes = max(int(num_test_classes), 1)
+        elif model_size is None:
+            raise TypeError("YOLOWorldDetector needs either the config keywords (backbone=..., neck=..., bbox_head=...) or a model_size")
         cfg = dict(multi_label=True, nms_pre=30000, score_thr=0.001, nms=dict(type="nms", iou_threshold=0.7),
                    max_per_img=300)
         cfg.update(test_cfg or {})
         if not cfg["multi_label"]:
             raise NotImplementedError("only multi_label=True (every shipped config) is implemented")
+        nms = dict(cfg["nms"])
+        if nms.get("type", "nms") != "nms":
+            raise NotImplementedError(f"test_cfg.nms.type={nms.get('type')!r}: only the plain greedy 'nms' is implemented")
+        if set(nms) - {"type", "iou_threshold"}:
+            raise NotImplementedError(f"test_cfg.nms options {sorted(set(nms) - {'type', 'iou_threshold'})} are not implemented")
         self.test_cfg = cfg
         self.model_size = model_size
         self.img_scale = tuple(img_scale) if img_scale is not None else _IMG_SIZE[model_size]
-        self._h = _TowerHolder(model_size, 0, self.img_scale, max_classes, cfg["max_per_img"], precision)
+        self._h = _TowerHolder(model_size, 0, max_classes if max_classes is not None else 1203, int(cfg["max_per_img"]),
+                               precision, nms_pre=int(cfg["nms_pre"]))
         self.text_encoder = text_encoder
         self.texts = None
         self.text_feats: Optional[torch.Tensor] = None
-        self.training = False
+        self._banks: Dict[Tuple[str, ...], torch.Tensor] = {}
 
-    def load_state_dict(self, state_dict, strict: bool = True):
-        if "state_dict" in state_dict and isinstance(state_dict["state_dict"], dict):
-            state_dict = state_dict["state_dict"]           # mmengine checkpoint wrapper
-        return self._h.load(state_dict, strict)
+    # -- weights --------------------------------------------------------------------------
+    def _load_state(self, state_dict, strict: bool):
+        msg = self._h.load(state_dict, strict)
+        tm = self.backbone.text_model if self.backbone is not None else None
+        if tm is not None:
+            sub = {k: v for k, v in state_dict.items() if k.startswith("backbone.text_model.")}
+            if sub:
+                tm.load_state_dict(sub)
+            elif strict:
+                raise RuntimeError("Error(s) in loading state_dict: no backbone.text_model.* tensors in the checkpoint")
+        self._banks.clear()
+        self.text_feats = self.texts = None
+        return msg
 
-    def cuda(self, device=None):
-        if not torch.cuda.is_available():
-            raise RuntimeError("no HIP device visible: wedetect_amd has no CPU execution path")
-        self._h.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
-        return self
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        out = super().state_dict(destination=destination, prefix=prefix)
+        tm = self.backbone.text_model if self.backbone is not None else None
+        if tm is not None:
+            for k, v in tm.state_dict().items():
+                out[prefix + "backbone.text_model." + k] = v
+        return out
 
-    to = lambda self, device: self.cuda()
-
-    def eval(self):
-        self.training = False
-        return self
+    def _on_device(self, device) -> None:
+        tm = self.backbone.text_model if self.backbone is not None else None
+        if tm is not None:
+            tm.cuda(device)
 
     # -- text side ------------------------------------------------------------------------
     def set_text_embeddings(self, feats: torch.Tensor, texts: Optional[List[List[str]]] = None) -> None:
         """Class bank [K, 768] (any norm: it is L2-normalised on device like
         BNContrastiveHead does, yolo_world_head.py:101)."""
         if feats.dim() == 3:
+            if feats.shape[0] != 1:
+                raise ValueError("a [B, K, 768] bank must have B == 1 (one bank for the whole batch)")
             feats = feats[0]
         if feats.dim() != 2 or feats.shape[1] != EMBED_DIM:
             raise ValueError("text embeddings must be [K, 768]")
         self.text_feats = feats.detach().to(torch.float32)
         self.texts = texts
+        if texts is not None:
+            self._banks[_flat_texts(texts)] = self.text_feats
+
+    def _encode(self, flat: Tuple[str, ...]) -> torch.Tensor:
+        if self.backbone is not None and self.backbone.with_text_model:
+            return self.backbone.forward_text([list(flat)])[0]              # [1, K, D] -> [K, D]
+        if self.text_encoder is not None:
+            return self.text_encoder(list(flat))
+        raise NotImplementedError("no text tower: build the detector from a config with backbone.text_model, pass "
+                                  "text_encoder=..., or call set_text_embeddings(bank)")
 
     def reparameterize(self, texts: List[List[str]]) -> None:
-        """yolo_world.py:58-61.  Needs the text tower, which is supplied by the caller."""
-        if self.text_encoder is None:
-            raise NotImplementedError("reparameterize(texts) needs text_encoder=... (wedetect_amd.text.XLMRobertaLanguageBackbone"
-                                      " with a tokenizer) or set_text_embeddings(bank)")
-        self.set_text_embeddings(self.text_encoder([t[0] if isinstance(t, (list, tuple)) else t for t in texts]), texts)
+        """yolo_world.py:58-61: ``self.texts = texts; self.text_feats = self.backbone.forward_text(texts)``."""
+        flat = _flat_texts(texts)
+        self.set_text_embeddings(self._encode(flat), texts)
+
+    def _bank_for(self, sample) -> torch.Tensor:
+        """extract_feat (yolo_world.py:82-113): data samples that carry ``texts`` are scored against those texts; the
+        reference re-runs the text tower for every image, here the bank of each distinct class list is built once."""
+        texts = _meta_of(sample).get("texts") if sample is not None else None
+        if texts is None:
+            if self.text_feats is None:
+                raise RuntimeError("no class bank: call reparameterize(texts) or set_text_embeddings(bank) first, or "
+                                   "pack `texts` into the data samples")
+            return self.text_feats
+        flat = _flat_texts(texts)
+        bank = self._banks.get(flat)
+        if bank is None:
+            if len(self._banks) > 64:
+                self._banks.clear()
+            bank = self._banks[flat] = self._encode(flat).detach().to(torch.float32)
+        return bank
 
     # -- image side -----------------------------------------------------------------------
     @torch.no_grad()
@@ -321,67 +602,70 @@ class YOLOWorldDetector:
             samples = [None] * len(inputs)
         return self.predict(inputs, samples)
 
+    def forward(self, inputs, data_samples=None, mode: str = "predict"):
+        if mode != "predict":
+            raise NotImplementedError(f"mode={mode!r}: only inference ('predict') is on this path")
+        return self.predict(inputs, data_samples if data_samples is not None else [None] * len(inputs))
+
     @torch.no_grad()
     def predict(self, batch_inputs, batch_data_samples, rescale: bool = True):
         """batch_inputs: list / tensor of [3, H, W] images as the mmdet pipeline packs them
         (uint8 or float 0-255, BGR — DetDataPreprocessor does bgr_to_rgb and /255,
-        wedetect_base.py:44-48).  Every image must already be letterboxed to ``img_scale``."""
-        if self.text_feats is None:
-            raise RuntimeError("no class bank: call reparameterize(texts) or set_text_embeddings(bank) first")
+        wedetect_base.py:44-48), all of one shape with H, W multiples of 32 (the test pipeline letterboxes
+        to ``img_scale``)."""
         dev = self._h.device
         if dev is None:
             raise RuntimeError("model is not on a HIP device: call .cuda()")
         xs = [x for x in batch_inputs]
-        b = len(xs)
-        x = torch.stack([t.to(dev) for t in xs])
-        if tuple(x.shape[1:]) != (3, self.img_scale[0], self.img_scale[1]):
-            raise ValueError(f"inputs must be [3,{self.img_scale[0]},{self.img_scale[1]}] after the test pipeline")
-        x = x.flip(1).permute(0, 2, 3, 1)                    # BGR CHW -> RGB HWC
-        x = (x if x.dtype == torch.uint8 else x.round().clamp(0, 255).to(torch.uint8)).contiguous()
-        metas = []
-        for s in batch_data_samples:
-            m = _meta_of(s)
-            ori = m.get("ori_shape", self.img_scale)
-            sf = m.get("scale_factor", (1.0, 1.0))
-            pad = m.get("pad_param", None)
-            px, py = (0.0, 0.0) if pad is None else (float(pad[2]), float(pad[0]))
-            sx, sy = (float(sf[0]), float(sf[1])) if rescale else (1.0, 1.0)
-            if not rescale:
-                px = py = 0.0
-            metas.append([px, py, 0.0, sx, sy, float(ori[1]), float(ori[0]), 1.0])
-        tower = self._h.tower(b)
-        meta = torch.tensor(metas, dtype=torch.float32, device=dev)
-        bank = self.text_feats.to(dev)
-        res = tower.detect(x, bank, meta, normalize_text=True, score_thr=self.test_cfg["score_thr"],
-                           iou_thr=self.test_cfg["nms"]["iou_threshold"], with_embed=False)
-        counts = res["count"].tolist()
-        out = []
-        for i, (n, s) in enumerate(zip(counts, batch_data_samples)):
-            inst = InstanceData(bboxes=res["bboxes"][i, :n].clone(), scores=res["scores"][i, :n].clone(),
-                                labels=res["labels"][i, :n].to(torch.int64))
-            if s is None:
-                s = DetDataSample()
-            s.pred_instances = inst
-            out.append(s)
+        samples = list(batch_data_samples) if batch_data_samples is not None else [None] * len(xs)
+        if len(samples) != len(xs):
+            raise ValueError(f"{len(xs)} inputs but {len(samples)} data samples")
+        banks = [self._bank_for(s) for s in samples]
+        shapes = {tuple(t.shape) for t in xs}
+        if len(shapes) != 1 or len(next(iter(shapes))) != 3 or next(iter(shapes))[0] != 3:
+            raise ValueError(f"inputs must be [3, H, W] tensors of one shape after the test pipeline, got {sorted(shapes)}")
+        _, hh, ww = next(iter(shapes))
+        if hh % 32 or ww % 32:
+            raise ValueError(f"input size {hh}x{ww} is not a multiple of 32 (letterbox to img_scale first)")
+        out: List[Optional[DetDataSample]] = [None] * len(xs)
+        groups: Dict[int, List[int]] = {}
+        for i, bk in enumerate(banks):
+            groups.setdefault(id(bk), []).append(i)
+        for idxs in groups.values():
+            from . import lib as L
+            chw = torch.stack([xs[i].to(dev) for i in idxs])     # [b, 3, H, W] BGR, contiguous
+            if chw.dtype not in (torch.uint8, torch.float32):
+                chw = chw.to(torch.float32)
+            x = torch.empty(len(idxs), hh, ww, 3, dtype=torch.uint8, device=dev)
+            L.chw_to_hwc_u8(chw, x)                              # bgr_to_rgb + NHWC (data_preprocessor.py:35-36)
+            metas = []
+            for i in idxs:
+                m = _meta_of(samples[i])
+                ori = m.get("ori_shape", (hh, ww))
+                sf = m.get("scale_factor", (1.0, 1.0))
+                pad = m.get("pad_param", None)
+                px, py = (0.0, 0.0) if pad is None else (float(pad[2]), float(pad[0]))
+                sx, sy = (float(sf[0]), float(sf[1])) if rescale else (1.0, 1.0)
+                if not rescale:
+                    px = py = 0.0
+                metas.append([px, py, 0.0, sx, sy, float(ori[1]), float(ori[0]), 1.0])
+            tower = self._h.tower(len(idxs), hh, ww)
+            meta = torch.tensor(metas, dtype=torch.float32, device=dev)
+            res = tower.detect(x, banks[idxs[0]].to(dev), meta, normalize_text=True, score_thr=self.test_cfg["score_thr"],
+                               iou_thr=self.test_cfg["nms"]["iou_threshold"], with_embed=False)
+            counts = res["count"].tolist()
+            for j, (i, n) in enumerate(zip(idxs, counts)):
+                inst = InstanceData(bboxes=res["bboxes"][j, :n].clone(), scores=res["scores"][j, :n].clone(),
+                                    labels=res["labels"][j, :n].to(torch.int64))
+                s = samples[i]
+                if s is None:
+                    s = DetDataSample()
+                elif isinstance(s, dict):
+                    s = DetDataSample(metainfo=_meta_of(s))
+                s.pred_instances = inst
+                out[i] = s
         return out
 
 
-class DetDataSample:
-    """Bare data sample: ``metainfo`` dict + ``pred_instances``."""
-
-    def __init__(self, metainfo: Optional[dict] = None, **kw):
-        self.metainfo = dict(metainfo or {})
-        self.metainfo.update(kw)
-        self.pred_instances = None
-
-    @property
-    def texts(self):
-        return self.metainfo.get("texts")
-
-
-def _meta_of(sample) -> dict:
-    if sample is None:
-        return {}
-    if isinstance(sample, dict):
-        return sample.get("metainfo", sample)
-    return getattr(sample, "metainfo", {}) or {}
+MODELS.register_module(module=YOLOWorldDetector)
+MODELS.register_module(module=MultiModalYOLOBackbone)

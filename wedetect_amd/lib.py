@@ -27,6 +27,7 @@ EXPORTS = (
     "wd_topk_candidates", "wd_nms_gather", "wd_retrieval_max",
     "wd_split_weights_bytes", "wd_split_weights", "wd_conv_gemm_split", "wd_conv_gemm_split_ws", "wd_conv_gemm_split_config", "wd_layernorm_rows_split", "wd_letterbox_u8", "wd_retrieval_max_split", "wd_text_embed", "wd_attention_small", "wd_recall_scratch_floats", "wd_recall_match",
     "wd_max_sigmoid_attn", "wd_adaptive_maxpool_nhwc", "wd_cross_attention_small", "wd_time_next_gemm",
+    "wd_cv_resize_paste_u8", "wd_chw_to_hwc_u8",
 )
 
 
@@ -102,6 +103,8 @@ def _load():
     lib.wd_cross_attention_small.argtypes = [vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.wd_time_next_gemm.argtypes = [vp, vp]
     lib.wd_letterbox_u8.argtypes = [vp, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.wd_cv_resize_paste_u8.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.wd_chw_to_hwc_u8.argtypes = [vp, i32, vp, i32, i32, i32, vp]
     lib.wd_conv_gemm_split_config.restype = C.c_char_p
     lib.wd_conv_gemm_split_config.argtypes = [i32, i32, i32, i32]
     if lib.wd_sizeof_conv_gemm() != C.sizeof(ConvGemm):
@@ -214,6 +217,26 @@ def letterbox_u8(src, h, w, bounds_h, kk_h, ksize_h, bounds_v, kk_v, ksize_v, tm
     check(LIB.wd_letterbox_u8(_p(src), h, w, _p(bounds_h), _p(kk_h), ksize_h, _p(bounds_v), _p(kk_v), ksize_v, _p(tmp),
                               _p(dst), dst_h, dst_w, new_w, new_h, left, top, int(fill[0]), int(fill[1]), int(fill[2]),
                               stream_ptr()), "wd_letterbox_u8")
+
+
+CVRESIZE_COPY, CVRESIZE_AREA_FAST, CVRESIZE_AREA, CVRESIZE_LINEAR = 0, 1, 2, 3
+
+
+def cv_resize_paste_u8(src, sh, sw, mode, xa, xidx, xw, ya, yidx, yw, p0, p1, p2, dst, dst_h, dst_w, new_h, new_w, top, left,
+                       fill=114, swap_rb=False) -> None:
+    check(LIB.wd_cv_resize_paste_u8(_p(src), sh, sw, mode, _p(xa), _p(xidx), _p(xw), _p(ya), _p(yidx), _p(yw), int(p0), int(p1),
+                                    float(p2), _p(dst), dst_h, dst_w, new_h, new_w, top, left, int(fill), int(bool(swap_rb)),
+                                    stream_ptr()), "wd_cv_resize_paste_u8")
+
+
+def chw_to_hwc_u8(src, dst) -> None:
+    """src [B, 3, H, W] uint8 / float32 (BGR, 0..255) -> dst [B, H, W, 3] uint8 (RGB)."""
+    b, c, h, w = src.shape
+    if c != 3 or tuple(dst.shape) != (b, h, w, 3) or dst.dtype != torch.uint8 or src.dtype not in (torch.uint8, torch.float32):
+        raise WedetectHipError("chw_to_hwc_u8: src [B,3,H,W] uint8|float32, dst [B,H,W,3] uint8")
+    if not src.is_contiguous() or not dst.is_contiguous():
+        raise WedetectHipError("chw_to_hwc_u8: contiguous tensors only")
+    check(LIB.wd_chw_to_hwc_u8(_p(src), int(src.dtype == torch.float32), _p(dst), b, h, w, stream_ptr()), "wd_chw_to_hwc_u8")
 
 
 def l2norm_rows(x, y) -> None:

@@ -26,19 +26,52 @@ def shard_range(total: int, world: int, rank: int) -> range:
     return range(begin, begin + base + (1 if rank < left else 0))
 
 
+def _world(group=None) -> int:
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def gather_ragged(fields: Dict[str, torch.Tensor], group=None) -> Dict[str, torch.Tensor]:
+    """All-gather per-image tensors whose leading axis (images held by this rank) may DIFFER between ranks — the
+    last batches of an ``InferenceSampler`` split (extract_embedding.py:1631-1638: the first ``total % world`` ranks
+    hold one image more) or a short final batch.  One small all-gather of the lengths, every field padded to the
+    longest rank for ``all_gather_into_tensor`` and trimmed afterwards; result rows are rank-major = the global image
+    order of ``shard_range``.  Every field of one call must have the same leading length; a rank may hold 0 images."""
+    if not fields:
+        return {}
+    lens = {int(v.shape[0]) for v in fields.values()}
+    if len(lens) != 1:
+        raise ValueError(f"fields disagree on the number of local images: {sorted(lens)}")
+    n_local = lens.pop()
+    if _world(group) == 1:
+        return dict(fields)
+    world = dist.get_world_size(group)
+    any_t = next(iter(fields.values()))
+    n_all = torch.empty(world, dtype=torch.int64, device=any_t.device)
+    dist.all_gather_into_tensor(n_all, torch.tensor([n_local], dtype=torch.int64, device=any_t.device), group=group)
+    n_all = [int(v) for v in n_all.tolist()]
+    widest = max(n_all)
+    out = {}
+    for k, v in fields.items():
+        if n_local < widest:
+            pad = torch.zeros((widest - n_local,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+            v = torch.cat([v, pad], dim=0)
+        o = torch.empty((world * widest,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+        dist.all_gather_into_tensor(o, v.contiguous(), group=group)
+        if min(n_all) == widest:
+            out[k] = o
+        else:
+            o = o.view((world, widest) + tuple(v.shape[1:]))
+            out[k] = torch.cat([o[r, : n_all[r]] for r in range(world)], dim=0)
+    return out
+
+
 def gather_regions(embeddings: torch.Tensor, count: torch.Tensor, group=None) -> Dict[str, torch.Tensor]:
     """All-gather the kept-region embeddings [B_local, R, D] and counts [B_local] of every
-    rank -> [world * B_local, R, D], [world * B_local]; rank-major order, i.e. the global
-    image order when images were sharded with ``shard_range`` and equal per-rank batches."""
-    if not dist.is_available() or not dist.is_initialized():
-        return dict(embeddings=embeddings, count=count)
-    world = dist.get_world_size(group)
-    out_e = torch.empty((world * embeddings.shape[0],) + tuple(embeddings.shape[1:]), dtype=embeddings.dtype,
-                        device=embeddings.device)
-    out_c = torch.empty(world * count.shape[0], dtype=count.dtype, device=count.device)
-    dist.all_gather_into_tensor(out_e, embeddings.contiguous(), group=group)
-    dist.all_gather_into_tensor(out_c, count.contiguous(), group=group)
-    return dict(embeddings=out_e, count=out_c)
+    rank -> [sum B_local, R, D], [sum B_local]; rank-major order, i.e. the global image order when images were
+    sharded with ``shard_range``.  Ranks may hold different numbers of images (ragged final batch)."""
+    if embeddings.shape[0] != count.shape[0]:
+        raise ValueError("embeddings and count disagree on the number of images")
+    return gather_ragged(dict(embeddings=embeddings, count=count), group)
 
 
 class RegionGatherer:
@@ -48,7 +81,9 @@ class RegionGatherer:
     stream goes straight on to the next batch and picks the result up with ``collect`` — at the
     next ``submit`` at the latest.  Over xGMI a [32, 300, 768] fp32 block per rank is ~4 ms at 8
     ranks; overlapped it costs the step nothing.  The tower's output buffers may be overwritten
-    as soon as ``submit`` returns (the staging copy is ordered before it on the same stream)."""
+    as soon as ``submit`` returns (the staging copy is ordered before it on the same stream) — with or without a
+    process group.  Every rank must submit the same B_local per step (pad the final short batch with count = 0
+    rows, or use ``gather_ragged`` for it)."""
 
     def __init__(self, group=None):
         self.group = group
@@ -68,13 +103,15 @@ class RegionGatherer:
     def submit(self, embeddings: torch.Tensor, count: torch.Tensor) -> Optional[Dict[str, torch.Tensor]]:
         """Starts the exchange of this step; returns the PREVIOUS step's gathered result (or None)."""
         prev = self.collect()
-        if not dist.is_available() or not dist.is_initialized():
-            self.pending = (None, embeddings, count)
-            return prev
-        world = dist.get_world_size(self.group)
+        single = not dist.is_available() or not dist.is_initialized()
+        world = 1 if single else dist.get_world_size(self.group)
         s = self._slot(embeddings, count, world)
         s["emb"].copy_(embeddings, non_blocking=True)
         s["cnt"].copy_(count, non_blocking=True)
+        if single:                                    # same contract without a process group: the caller's buffers
+            self.pending = (None, s["emb"], s["cnt"])  # are free again as soon as submit returns
+            self.turn ^= 1
+            return prev
         h1 = dist.all_gather_into_tensor(s["out_e"], s["emb"], group=self.group, async_op=True)
         h2 = dist.all_gather_into_tensor(s["out_c"], s["cnt"], group=self.group, async_op=True)
         self.pending = ((h1, h2), s["out_e"], s["out_c"])
@@ -96,16 +133,8 @@ class RegionGatherer:
 
 def gather_results(fields: Dict[str, torch.Tensor], group=None) -> Dict[str, torch.Tensor]:
     """Same exchange for any dict of per-image tensors with a leading B_local axis (image ids,
-    scales, bias ... — the four lists of extract_embedding.py:1753-1756 in one place)."""
-    if not dist.is_available() or not dist.is_initialized():
-        return dict(fields)
-    world = dist.get_world_size(group)
-    out = {}
-    for k, v in fields.items():
-        o = torch.empty((world * v.shape[0],) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
-        dist.all_gather_into_tensor(o, v.contiguous(), group=group)
-        out[k] = o
-    return out
+    scales, bias ... — the four lists of extract_embedding.py:1753-1756 in one place); ragged-safe."""
+    return gather_ragged(fields, group)
 
 
 def shard_bank_by_class(bank: torch.Tensor, world: int, rank: int) -> torch.Tensor:

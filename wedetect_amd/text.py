@@ -103,19 +103,27 @@ class TextTower:
 
 
 class XLMRobertaLanguageBackbone:
-    """Operator-surface mirror of the reference class (mm_backbone.py:341-390): ``forward(texts)`` with
-    ``texts`` = ``List[List[str]]`` returns ``[B, K, D]`` normalised text features.  ``tokenizer`` is any
-    callable ``(list_of_strings) -> {"input_ids": [n, L], "attention_mask": [n, L]}`` (HF's
-    ``AutoTokenizer(..., return_tensors="pt", padding=True)`` fits); its SentencePiece files are not
-    available offline, so it has to be supplied.  ``forward_ids`` takes the tokenizer's output directly."""
+    """Operator-surface mirror of the reference class (mm_backbone.py:330-390; constructor keywords ``model_name,
+    model_size, frozen_modules, dropout, training_use_cache, init_cfg`` as the configs pass them):
+    ``forward(texts)`` with ``texts`` = ``List[List[str]]`` returns ``[B, K, D]`` normalised text features.
+
+    ``tokenizer`` is any callable ``(list_of_strings) -> {"input_ids": [n, L], "attention_mask": [n, L]}``.  When
+    none is given, ``AutoTokenizer.from_pretrained(model_name)`` is tried at first use, like the reference's
+    constructor does (its SentencePiece files must be on disk: there is no download path here); a failure raises.
+    ``forward_ids`` takes the tokenizer's output directly.  Weights arrive through ``load_state_dict`` (the
+    detector forwards the checkpoint's ``backbone.text_model.*`` tensors); the device tower is built at first use."""
 
     HEADS = {"tiny": 12, "base": 12, "large": 16, "xlarge": 16}
 
-    def __init__(self, model_size: str = "base", tokenizer=None, precision: str = "fp16x3"):
+    def __init__(self, model_name: Optional[str] = None, model_size: str = "base", frozen_modules=(), dropout: float = 0.0,
+                 training_use_cache: bool = False, init_cfg=None, *, tokenizer=None, precision: Optional[str] = None):
         if model_size not in self.HEADS:
             raise ValueError(f"model_size must be one of {sorted(self.HEADS)}")
-        self.model_size, self.tokenizer, self.precision = model_size, tokenizer, precision
+        self.model_name, self.model_size, self.tokenizer = model_name, model_size, tokenizer
+        self.precision = precision
+        self._state: Optional[Dict[str, torch.Tensor]] = None
         self._tower: Optional[TextTower] = None
+        self._device = None
         self.training = False
 
     def load_state_dict(self, state_dict, strict: bool = True):
@@ -125,26 +133,55 @@ class XLMRobertaLanguageBackbone:
         missing = [k for k in need if k not in sd and k[6:] not in sd]
         if missing:
             raise RuntimeError(f"cannot build the text tower, missing {missing}")
-        self._tower = TextTower({k: v for k, v in sd.items() if not k.endswith("position_ids")}, self.HEADS[self.model_size],
-                                precision=self.precision)
+        self._state = {k: v for k, v in sd.items() if not k.endswith("position_ids")}
+        self._tower = None
+        return self
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return dict(self._state or {})
+
+    def cuda(self, device=None):
+        self._device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self._tower is not None and self._tower.dev != self._device:
+            self._tower = None
         return self
 
     def eval(self):
         return self
 
-    def forward_ids(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
-        if self._tower is None:
+    def _ensure(self) -> TextTower:
+        if self._state is None:
             raise RuntimeError("load_state_dict() must be called before encoding text")
-        return self._tower.encode(input_ids, attention_mask)
+        if self._tower is None:
+            import os
+            prec = self.precision or os.environ.get("WEDETECT_PRECISION", "fp16x3")
+            self._tower = TextTower(self._state, self.HEADS[self.model_size], device=self._device or "cuda", precision=prec)
+        return self._tower
+
+    def _tokenizer(self):
+        if self.tokenizer is None:
+            if not self.model_name:
+                raise RuntimeError("no tokenizer: pass one to the constructor, give model_name=<directory with the XLM-R "
+                                   "tokenizer files>, or use forward_ids")
+            try:
+                from transformers import AutoTokenizer
+                hf = AutoTokenizer.from_pretrained(self.model_name)
+            except Exception as e:                                 # missing files, no network
+                raise RuntimeError(f"cannot load the tokenizer of {self.model_name!r} ({type(e).__name__}: {e}); tokenizer "
+                                   "files are host-side data this package does not ship") from e
+            self.tokenizer = lambda strings: hf(text=list(strings), return_tensors="pt", padding=True)   # mm_backbone.py:383
+        return self.tokenizer
+
+    def forward_ids(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return self._ensure().encode(input_ids, attention_mask)
 
     def forward(self, text) -> torch.Tensor:
-        if self.tokenizer is None:
-            raise RuntimeError("no tokenizer: pass one to the constructor or use forward_ids (tokenizer files are host-side)")
         num = [len(t) for t in text]
         if max(num) != min(num):
             raise AssertionError("number of sequences not equal in batch")      # mm_backbone.py:377-379
+        tokenizer = self._tokenizer()
         flat = [s for t in text for s in t]
-        tok = self.tokenizer(flat)
+        tok = tokenizer(flat)
         feats = self.forward_ids(torch.as_tensor(tok["input_ids"]), torch.as_tensor(tok["attention_mask"]))
         return feats.reshape(-1, num[0], feats.shape[-1])
 
