@@ -59,17 +59,34 @@ def iou_suppresses(bi: np.ndarray, bj: np.ndarray, thr: float) -> np.ndarray:
     return ovr > f32(thr)
 
 
+def _iou_f32(bi: np.ndarray, bj: np.ndarray) -> np.ndarray:
+    area_i = (bi[2] - bi[0]) * (bi[3] - bi[1])
+    area_j = (bj[:, 2] - bj[:, 0]) * (bj[:, 3] - bj[:, 1])
+    w = np.maximum(f32(0), np.minimum(bi[2], bj[:, 2]) - np.maximum(bi[0], bj[:, 0]))
+    h = np.maximum(f32(0), np.minimum(bi[3], bj[:, 3]) - np.maximum(bi[1], bj[:, 1]))
+    inter = w * h
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return inter / (area_i + area_j - inter)
+
+
 def batched_nms(boxes: np.ndarray, scores: np.ndarray, labels: np.ndarray, thr: float,
-                max_keep: Optional[int] = None) -> np.ndarray:
+                max_keep: Optional[int] = None, stats: Optional[dict] = None) -> np.ndarray:
     """Class-aware greedy NMS.  Inputs must already be in the defined total order
     (they are: the output of filter_scores_and_topk).  Returns kept candidate indices
     in that order.  ``max_keep`` stops early — identical to slicing the full result,
-    because whether a box is kept depends only on earlier kept boxes."""
+    because whether a box is kept depends only on earlier kept boxes.
+
+    ``stats`` (a dict, filled in place) records how far every decision taken was from flipping — what a second
+    implementation with ~1e-6 numerical noise on scores / boxes needs to know before index-exact agreement can be
+    demanded: ``iou_margin`` = min |IoU - thr| over every IoU test performed; ``pair_gap`` = min score gap between
+    a kept box and a box it suppressed (a swap of the two would keep the other one); ``kept_gap`` = min score gap
+    between consecutive kept boxes (a swap reorders the output)."""
     boxes = np.ascontiguousarray(boxes, dtype=f32)
     n = boxes.shape[0]
     assert np.all(scores[:-1] >= scores[1:]), "candidates must be sorted by score desc"
     suppressed = np.zeros(n, dtype=bool)
     keep: List[int] = []
+    iou_margin, pair_gap = np.inf, np.inf
     for i in range(n):
         if suppressed[i]:
             continue
@@ -80,7 +97,30 @@ def batched_nms(boxes: np.ndarray, scores: np.ndarray, labels: np.ndarray, thr: 
         if rest.size:
             sup = iou_suppresses(boxes[i], boxes[rest], thr)
             suppressed[rest[sup]] = True
+            if stats is not None:
+                ovr = _iou_f32(boxes[i], boxes[rest]).astype(np.float64)
+                ovr = ovr[np.isfinite(ovr)]
+                if ovr.size:
+                    iou_margin = min(iou_margin, float(np.min(np.abs(ovr - float(f32(thr))))))
+                if np.any(sup):
+                    pair_gap = min(pair_gap, float(np.min(scores[i].astype(np.float64) - scores[rest[sup]].astype(np.float64))))
+    if stats is not None:
+        ks = scores[np.asarray(keep, dtype=np.int64)].astype(np.float64) if keep else np.zeros(0)
+        stats["iou_margin"] = iou_margin if np.isfinite(iou_margin) else 1.0
+        stats["pair_gap"] = pair_gap if np.isfinite(pair_gap) else 1.0
+        stats["kept_gap"] = float(np.min(-np.diff(ks))) if ks.size > 1 else 1.0
     return np.asarray(keep, dtype=np.int64)
+
+
+def cut_gap(scores: np.ndarray, score_thr: float, topk: int) -> float:
+    """Score gap at the ``nms_pre`` cut of filter_scores_and_topk: (last candidate taken) - (first one left out); 1.0
+    when every valid candidate fits."""
+    flat = np.ascontiguousarray(scores, dtype=f32).reshape(-1)
+    valid = flat[flat > f32(score_thr)]
+    if valid.shape[0] <= topk:
+        return 1.0
+    part = np.partition(valid, valid.shape[0] - topk - 1)
+    return float(part[valid.shape[0] - topk:].min().astype(np.float64) - part[valid.shape[0] - topk - 1].astype(np.float64))
 
 
 def unletterbox(boxes: np.ndarray, pad_xy: Tuple[float, float], ratio: float,
@@ -104,12 +144,14 @@ def uni_predict_image(boxes: np.ndarray, embed: np.ndarray, scores: np.ndarray,
     letterboxed network coordinates (NMS runs before the un-letterbox there)."""
     s, labels, anchors = filter_scores_and_topk(scores, score_thr, nms_pre)
     cand_boxes = boxes[anchors]
-    keep = batched_nms(cand_boxes, s, labels, iou_thr, max_keep=num_proposals)
+    stats: dict = {}
+    keep = batched_nms(cand_boxes, s, labels, iou_thr, max_keep=num_proposals, stats=stats)
+    stats["cut_gap"] = cut_gap(scores, score_thr, nms_pre)
     a = anchors[keep]
     lv = level_of[a]
     return dict(bboxes=cand_boxes[keep], embeddings=embed[a], scores=s[keep], labels=labels[keep],
                 anchors=a, scales=logit_scale[lv].astype(f32), bias=contrast_bias[lv].astype(f32),
-                num_candidates=np.int64(s.shape[0]), keep=keep)
+                num_candidates=np.int64(s.shape[0]), keep=keep, margins=stats)
 
 
 def rescale_boxes(b: np.ndarray, pad_xy, scale_xy) -> np.ndarray:
@@ -134,8 +176,9 @@ def mmdet_predict_image_from_candidates(cand_boxes, s, labels, pad_param, scale_
     b = cand_boxes.astype(f32)
     pad = (0.0, 0.0) if pad_param is None else (pad_param[2], pad_param[0])
     b = rescale_boxes(b, pad, scale_factor)
-    keep = batched_nms(b, s, labels, iou_thr, max_keep=max_per_img)
-    return dict(bboxes=clamp_boxes(b[keep], ori_hw), keep=keep)
+    stats: dict = {}
+    keep = batched_nms(b, s, labels, iou_thr, max_keep=max_per_img, stats=stats)
+    return dict(bboxes=clamp_boxes(b[keep], ori_hw), keep=keep, margins=stats)
 
 
 def mmdet_predict_image(boxes: np.ndarray, scores: np.ndarray, pad_param, scale_factor,
@@ -150,7 +193,8 @@ def mmdet_predict_image(boxes: np.ndarray, scores: np.ndarray, pad_param, scale_
     r = mmdet_predict_image_from_candidates(boxes[anchors], s, labels, pad_param, scale_factor, ori_hw,
                                             iou_thr, max_per_img)
     keep = r["keep"]
-    return dict(bboxes=r["bboxes"], scores=s[keep], labels=labels[keep], anchors=anchors[keep])
+    r["margins"]["cut_gap"] = cut_gap(scores, score_thr, nms_pre)
+    return dict(bboxes=r["bboxes"], scores=s[keep], labels=labels[keep], anchors=anchors[keep], margins=r["margins"])
 
 
 def retrieval_scores(embedding: np.ndarray, text: np.ndarray, scale: np.ndarray,

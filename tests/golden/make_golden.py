@@ -279,8 +279,16 @@ def load_uni_model(gp, arch, num_prompts, seed):
     return model, sd_np
 
 
+def _margins(o) -> np.ndarray:
+    """Decision margins of one image's post-process (oracle/postprocess.py batched_nms stats + the nms_pre cut):
+    [min |IoU - thr| over the IoU tests taken, min score gap kept-vs-suppressed, min gap between kept rows, gap at the cut].
+    A second implementation with noise below these reproduces the index lists exactly."""
+    m = o["margins"]
+    return np.asarray([m["iou_margin"], m["pair_gap"], m["kept_gap"], m["cut_gap"]], dtype=np.float64)
+
+
 # ------------------------------------------------------------------ cases
-def case_network(gp, arch, b, hw, seed_w=2026, seed_img=1234, num_prompts=256, full_predict=True):
+def case_network(gp, arch, b, hw, seed_w=2026, seed_img=1234, num_prompts=256, full_predict=True, k_text=80):
     """Reference pure-torch copy vs oracle on (arch, b, hw)."""
     tag = f"{arch}_b{b}_{hw}"
     print(f"== network case {tag}")
@@ -290,7 +298,7 @@ def case_network(gp, arch, b, hw, seed_w=2026, seed_img=1234, num_prompts=256, f
     imgs = W.make_images(b, hw, hw, seed=seed_img)
     x = orc.preprocess_u8(imgs)
 
-    fx = dict(arch=arch, b=b, hw=hw, seed_w=seed_w, seed_img=seed_img, num_prompts=num_prompts)
+    fx = dict(arch=arch, b=b, hw=hw, seed_w=seed_w, seed_img=seed_img, num_prompts=num_prompts, k_text=k_text)
     c_ref = model.backbone(x)
     c_orc = orc.backbone(sd, a, x)
     for i in range(4):
@@ -317,7 +325,6 @@ def case_network(gp, arch, b, hw, seed_w=2026, seed_img=1234, num_prompts=256, f
     # mmdet-path head: YOLOWorldHeadModule.forward with a [B,K,768] text tensor that is
     # L2-normalised inside BNContrastiveHead (generate_proposal.py:605-623, 716-752 —
     # the same code as yolo_world_head.py:90-108, 263-294).
-    k_text = 80
     text = torch.from_numpy(W.make_text_bank(k_text) * np.float32(1.7))     # not unit-norm on purpose
     text_b = text[None].repeat(b, 1, 1)
     outs = model.bbox_head(p_ref, text_b)
@@ -337,7 +344,8 @@ def case_network(gp, arch, b, hw, seed_w=2026, seed_img=1234, num_prompts=256, f
             fx[f"mm.img{i}.pad"], fx[f"mm.img{i}.sf"], fx[f"mm.img{i}.ori"] = np.asarray(pad), np.asarray(sf), np.asarray(ori)
             for key in ("bboxes", "scores", "labels", "anchors"):
                 fx[f"mm.img{i}.{key}"] = o[key]
-            print(f"  mm img{i}: kept {o['scores'].shape[0]}")
+            fx[f"mm.img{i}.margins"] = _margins(o)
+            print(f"  mm img{i}: kept {o['scores'].shape[0]}, margins (iou, pair, kept, cut) {fx[f'mm.img{i}.margins']}")
     if full_predict:
         with stable_sort():
             res = model.head_predict(p_ref)
@@ -360,6 +368,8 @@ def case_network(gp, arch, b, hw, seed_w=2026, seed_img=1234, num_prompts=256, f
             fx[f"img{i}.embed_l2"] = np.linalg.norm(o["embeddings"].astype(np.float64), axis=1)
             fx[f"img{i}.num_candidates"] = o["num_candidates"]
             fx[f"img{i}.min_score_gap"] = np.float64(np.min(-gaps)) if n > 1 else np.float64(1.0)
+            fx[f"img{i}.margins"] = _margins(o)
+            print(f"  img{i}: margins (iou, pair, kept, cut) {fx[f'img{i}.margins']}")
             print(f"  img{i}: kept {n}, candidates {int(o['num_candidates'])}, min score gap {fx[f'img{i}.min_score_gap']:.3g}")
     np.savez_compressed(os.path.join(OUT, f"net_{tag}.npz"), **fx)
 
@@ -699,6 +709,13 @@ if __name__ == "__main__":
     if "--only-bricks" in sys.argv:
         case_bricks()
         sys.exit(0)
+    if "--only-network" in sys.argv:
+        gp = import_generate_proposal()
+        case_network(gp, "base", 1, 64)
+        case_network(gp, "base", 2, 128)
+        case_network(gp, "base", 1, 640)
+        case_network(gp, "large", 1, 640, k_text=1203)
+        sys.exit(0)
     if "--only-configs" in sys.argv:
         case_configs()
         sys.exit(0)
@@ -716,6 +733,7 @@ if __name__ == "__main__":
     case_network(gp, "base", 2, 128)
     case_network(gp, "base", 1, 640)
     case_network(gp, "large", 1, 64, full_predict=False)
+    case_network(gp, "large", 1, 640, k_text=1203)
     case_letterbox(gp)
     case_recall()
     case_retrieval_metric()
