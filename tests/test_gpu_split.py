@@ -187,7 +187,7 @@ def test_layernorm_split_output_is_the_split_of_the_fp32_output(rows, c):
     assert torch.equal(xi.view(torch.int32), ys.view(torch.int32))
 
 
-@pytest.mark.parametrize("cfg", [-1, 50, 51, 55, 60, 63])
+@pytest.mark.parametrize("cfg", [-1, 50, 51, 55, 60, 63, 64])
 def test_presplit_operands_give_bit_identical_results(cfg):
     """LN(split) -> GEMM(A split, C split, GELU) -> GEMM(A split, residual) == the same chain with
     fp32 buffers and the loader-side split, bit for bit; the split C is the split of the fp32 C."""
@@ -204,8 +204,8 @@ def test_presplit_operands_give_bit_identical_results(cfg):
     kw1 = dict(batch=1, hin=1, win=m, cin=c, lda=c, n=4 * c, ldc=4 * c, act=L.ACT_GELU)
     kw2 = dict(batch=1, hin=1, win=m, cin=4 * c, lda=4 * c, n=c, ldc=c, res=res, ldres=c)
     c1 = cfg if cfg != 55 else 50
-    ref1 = {60: 51, 63: 51}.get(c1, c1)          # the direct-to-LDS kernel sums k in the order of the BK 16 tile
-    ref2 = {60: 51, 63: 51}.get(cfg, cfg)
+    ref1 = {60: 51, 63: 51, 64: 51}.get(c1, c1)  # the direct-to-LDS kernels sum k in the order of the BK 16 tile
+    ref2 = {60: 51, 63: 51, 64: 51}.get(cfg, cfg)
     L.conv_gemm(t32, None, b1, h32, w_split=ws1, split_cfg=ref1, **kw1)
     L.conv_gemm(h32, None, b2, o32, w_split=ws2, split_cfg=ref2, **kw2)
     # pre-split chain
@@ -287,3 +287,35 @@ def test_retrieval_max_split_matches_fp32_kernel_and_shards():
         parts.append(o)
     # every shard picks its own power-of-two weight scale: exact, so the shards reproduce the whole-bank bits
     assert torch.equal(torch.cat(parts, dim=1), out)
+
+
+@pytest.mark.parametrize("m,n,k", [(257, 320, 64), (1000, 256, 96), (513, 512, 128), (2048, 768, 1024), (300, 40, 160)])
+@pytest.mark.parametrize("mode", ["gelu_csplit", "residual"])
+def test_p8_kernel_bit_identical_to_the_128_tile_kernel(m, n, k, mode):
+    """cfg 64 (256 x 256 tiles, K tiles of 32, counted LDS-DMA waits, two staggered wave groups) against cfg 60 on
+    ragged shapes: partial row / column tiles (clamped DMA rows), K tiles 2 (prologue only), 3 (first tail form) and
+    more, both epilogues.  Same per-accumulator MFMA order => the same bits."""
+    from wedetect_amd import lib as L
+    x, g, b = _rand((m, k), 91, 2.0), _rand((k,), 92), _rand((k,), 93, 0.1)
+    w, bias = _rand((n, k), 94, k ** -0.5), _rand((n,), 95, 0.1)
+    ws = L.split_weights(w)
+    xs = torch.empty(m, k, device="cuda")
+    L.layernorm_rows(x, xs, g, b, m, k, split=True)
+    kw = dict(batch=1, hin=1, win=m, cin=k, lda=k, n=n, ldc=n)
+    if mode == "gelu_csplit":
+        kw.update(act=L.ACT_GELU)
+        flags = L.SPLIT_A | L.SPLIT_C
+    else:
+        kw.update(res=_rand((m, n), 96), ldres=n)
+        flags = L.SPLIT_A
+    outs = []
+    for cfg in (60, 64):
+        c = torch.full((m, n), 7.0, device="cuda")
+        L.conv_gemm(xs, None, bias, c, w_split=ws, split_cfg=cfg, split_flags=flags, **kw)
+        outs.append(c)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32)), f"max|d| {float((outs[0] - outs[1]).abs().max())}"
+    for _ in range(3):                                            # no race between runs
+        c = torch.full((m, n), 7.0, device="cuda")
+        L.conv_gemm(xs, None, bias, c, w_split=ws, split_cfg=64, split_flags=flags, **kw)
+        assert torch.equal(c.view(torch.int32), outs[1].view(torch.int32))

@@ -48,3 +48,77 @@ def check_checksum(name: str, got_nhwc, fx, prefix: str, atol: float, rtol: floa
     mean = float(np.mean(g.astype(np.float64)))
     assert abs(mean - float(fx[f"{prefix}.mean"])) <= atol + 1e-4 * abs(float(fx[f"{prefix}.mean"])), \
         f"{name}: mean {mean} vs golden {float(fx[f'{prefix}.mean'])}"
+
+
+# ------------------------------------------------------------------------------------------ index parity
+PARITY_LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_r02.jsonl")
+
+
+def compare_kept_lists(name, got_anchor, got_label, got_score, ref_anchor, ref_label, ref_score, margins=None,
+                       score_tol: float = 1e-3, got_boxes=None, ref_boxes=None):
+    """Index parity of a kept-detection list against the reference's (north_star: "box indices/classes bit-exact").
+
+    Scores must agree within ``score_tol``.  The (anchor, class) lists must be IDENTICAL, position by position, except
+    where the reference itself says two implementations with fp32 summation noise cannot be told apart: rows whose
+    reference scores lie within ``eps`` of each other (eps = 4 x the score difference measured in this very comparison,
+    floor 1e-6) may appear in any order among themselves ("tie run").  That relaxation is only granted while the
+    reference's NMS decisions were not themselves within noise of flipping (``margins`` = [min |IoU - thr|, min
+    kept-vs-suppressed score gap, min kept gap, gap at the nms_pre cut] recorded by the golden generator; the IoU noise
+    is bounded by 8 x (box difference measured here) / (smallest box side)); if they were, the fallback is >= 97 % overlap.  Returns (rows of got, rows of ref) of the common detections and appends one JSON
+    line with what was observed to gpurun_out/parity_r02.jsonl."""
+    import json
+    ga, gl, gs = (np.asarray(to_np(x)) for x in (got_anchor, got_label, got_score))
+    ra, rl, rs = (np.asarray(x) for x in (ref_anchor, ref_label, ref_score))
+    assert ga.shape[0] == ra.shape[0], f"{name}: kept {ga.shape[0]} vs reference {ra.shape[0]}"
+    n = ra.shape[0]
+    assert_close(f"{name} sorted scores", gs, rs, score_tol, 0)
+    noise = float(np.max(np.abs(gs.astype(np.float64) - rs.astype(np.float64)))) if n else 0.0
+    eps = max(4.0 * noise, 1e-6)
+    exact = bool(np.array_equal(ga, ra) and np.array_equal(gl, rl))
+    got = list(zip(ga.tolist(), gl.tolist()))
+    want = list(zip(ra.tolist(), rl.tolist()))
+    overlap = len(set(got) & set(want)) / max(1, n)
+    # tie runs of the reference list
+    run_exact, runs, longest = True, 0, 1
+    i = 0
+    rs64 = rs.astype(np.float64)
+    while i < n:
+        j = i
+        while j + 1 < n and rs64[j] - rs64[j + 1] < eps:
+            j += 1
+        runs += 1
+        longest = max(longest, j - i + 1)
+        if sorted(got[i:j + 1]) != sorted(want[i:j + 1]):
+            run_exact = False
+        i = j + 1
+    gi = {k: j for j, k in enumerate(want)}
+    rows = [(j, gi[k]) for j, k in enumerate(got) if k in gi]
+    jj = np.asarray([r[0] for r in rows], dtype=np.int64)
+    gg = np.asarray([r[1] for r in rows], dtype=np.int64)
+    box_noise, min_side = 0.0, 1.0
+    if got_boxes is not None and ref_boxes is not None and len(rows):
+        gb, rb = np.asarray(to_np(got_boxes))[jj].astype(np.float64), np.asarray(ref_boxes)[gg].astype(np.float64)
+        box_noise = float(np.max(np.abs(gb - rb)))
+        side = np.minimum(rb[:, 2] - rb[:, 0], rb[:, 3] - rb[:, 1])
+        min_side = float(max(1.0, np.min(side)))
+    decided = True
+    if margins is not None:
+        iou_m, pair_g, kept_g, cut_g = (float(v) for v in margins)
+        iou_eps = 8.0 * box_noise / min_side + 1e-7
+        decided = iou_m > iou_eps and pair_g > eps
+    rec = dict(case=name, kept=int(n), exact=exact, tie_run_exact=run_exact, overlap=round(overlap, 4), score_noise=noise, eps=eps,
+               tie_runs=runs, longest_run=longest, box_noise=box_noise, margins=[float(v) for v in margins] if margins is not None else None,
+               nms_decided_beyond_noise=decided)
+    try:
+        os.makedirs(os.path.dirname(PARITY_LOG), exist_ok=True)
+        with open(PARITY_LOG, "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass
+    print(f"[parity] {rec}")
+    if decided:
+        assert run_exact, (f"{name}: kept (anchor, class) list differs from the reference beyond near-ties "
+                           f"(eps {eps:.2e}, overlap {overlap:.4f}, margins {margins})")
+    else:
+        assert overlap >= 0.97, f"{name}: only {overlap:.3f} of the reference's detections reproduced"
+    return jj, gg

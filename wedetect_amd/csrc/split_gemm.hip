@@ -119,7 +119,7 @@ extern "C" const char* wd_conv_gemm_split_config(int32_t m, int32_t n, int32_t k
 // K splits for an under-filled launch: few tiles and a long K loop are latency-bound (one workgroup walks
 // K serially); S workgroups per tile walk K / S each and a second pass adds the partial sums.
 static int pick_ksplits(const WdConvGemm& p, int cfg, int flags, long long ws_floats) {
-  if (ws_floats <= 0 || (flags & WD_SPLIT_C) || (p.n & 3) || cfg == 55 || cfg == 63) return 1;
+  if (ws_floats <= 0 || (flags & WD_SPLIT_C) || (p.n & 3) || cfg == 55 || cfg == 63 || cfg == 64) return 1;
   const int bm = 128, bn = (cfg == 52 || cfg == 53) ? 64 : 128, bk = (cfg == 50) ? 32 : 16;
   const long long tiles = (long long)((p.m + (cfg == 52 ? 255 : bm - 1)) / (cfg == 52 ? 256 : bm)) * ((p.n + bn - 1) / bn);
   const int nk = (p.k + bk - 1) / bk;
@@ -150,7 +150,7 @@ static int conv_gemm_split_impl(const WdConvGemm* pp, const void* w_split, float
     // directly (cfg 60 / 63); the 2x2 downsample conv and odd K keep the register-staged kernels.
     // long-m layers (ConvNeXt stages 1-2): the ping-pong 256 x 128 kernel, else 128 x 128
     if (production && plain && !special && p.k % 16 == 0) cfg = p.m >= 131072 ? 63 : 60;
-    if (cfg != 50 && cfg != 51 && cfg != 55 && cfg != 60 && cfg != 63) cfg = 51;
+    if (cfg != 50 && cfg != 51 && cfg != 55 && cfg != 60 && cfg != 63 && cfg != 64) cfg = 51;
     if ((flags & WD_SPLIT_C) && cfg == 55) cfg = 50;
   }
   const long long ws_floats = ws ? ws_bytes / 4 : 0;
@@ -160,7 +160,7 @@ static int conv_gemm_split_impl(const WdConvGemm* pp, const void* w_split, float
     if (splits > nk) splits = nk;                             // never an empty split
   }
   if (splits > 1) {
-    if ((flags & WD_SPLIT_C) || (p.n & 3) || cfg == 55 || cfg == 63) return WD_ERR_UNSUPPORTED;
+    if ((flags & WD_SPLIT_C) || (p.n & 3) || cfg == 55 || cfg == 63 || cfg == 64) return WD_ERR_UNSUPPORTED;
     if ((long long)splits * p.m * p.n > ws_floats) return WD_ERR_WORKSPACE;
   }
   int lrc;
