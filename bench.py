@@ -22,6 +22,10 @@ Prints ONE JSON line (rank 0) with the driver's contract plus:
   fp32_mode     — (default fp16x3 arithmetic only) the same workload re-timed in this run with native fp32 MFMA,
                   and the max |difference| of the fp16x3 step's embeddings / scores from it
   cpu_baseline  — the CPU oracle (port of the reference's PyTorch-CPU path) on a bounded sample
+  host_fed      — (N = 1) the same step fed from PINNED HOST memory: the uint8 batch is uploaded every step and the
+                  <= 300-row results (boxes, scores, labels, counts) are copied back, both on a copy stream that
+                  overlaps the next / previous step's compute; never the headline `value`
+  per_rank      — (N > 1) every rank's own ms/step and how long its stream stalled on the region gather
 """
 import argparse
 import json
@@ -53,6 +57,7 @@ KERNEL_SYMBOL = {
     # one bench tag, two instantiations: pwconv1 (output written as fp16 hi/lo groups) and pwconv2
     "fp16x3 128x128x16/4w/glds/plain": ["split_gemm_glds_kernel<16, 2048>", "split_gemm_glds_kernel<16, 0>"],
     "fp16x3 256x128x16/8w/pingpong/plain": ["split_gemm_pingpong_kernel<2048, 3, 2>", "split_gemm_pingpong_kernel<0, 3, 2>"],
+    "fp16x3 256x256x32/8w/p8s/plain": ["split_gemm_p8_kernel<2048, 0, true>", "split_gemm_p8_kernel<0, 0, true>"],
 }
 
 
@@ -93,6 +98,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-reference", action="store_true",
                     help="skip the short native-fp32 run that is reported beside an fp16x3 result (N = 1 only)")
+    ap.add_argument("--no-host-fed", action="store_true", help="skip the host-fed (PCIe-inclusive) leg (N = 1 only)")
     ap.add_argument("--cpu-images", type=int, default=8)
     return ap.parse_args()
 
@@ -137,8 +143,10 @@ class GemmTimer:
             wout = (win + 2 * pad - kw_) // stride + 1
             m, n, k = kw["batch"] * hout * wout, kw["n"], kh * kw_ * kw["cin"]
             plain = kh == 1 and kw_ == 1 and stride == 1 and pad == 0
+            ws_t = kw.get("workspace")
+            park = ws_t is not None and bool(kw.get("split_flags", 0)) and ws_t.numel() * 4 == lib.p8_workspace_bytes()
             tag = lib.gemm_config(m, n, k, split=kw.get("w_split") is not None, conv=not plain,
-                                  presplit=bool(kw.get("split_flags", 0))) + ("/plain" if plain else "/conv")
+                                  presplit=bool(kw.get("split_flags", 0)), park=park) + ("/plain" if plain else "/conv")
             s, e = self.pool.pop() if self.pool else self._pair()
             lib.time_next_gemm(s, e)
             orig(a, w, bias, c, **kw)
@@ -219,6 +227,68 @@ def fp32_reference_run(args, tower, images, text, meta, uni, steps=5):
             "dtype": "f32 (v_mfma_f32_16x16x4_f32)", "max_abs_diff_of_fp16x3_step": {"embeddings": d_emb, "scores": d_sc}}
 
 
+def host_fed_run(tower, images, text, meta, uni, steps):
+    """The same step with the batch coming from (and the results going back to) pinned host memory every step.
+    Two device input buffers; uploads and result downloads run on a copy stream and overlap compute:
+        copy stream :  H2D batch i+1 | D2H results i-1
+        main stream :  step i
+    Measured over ``steps`` steps after 2 warm-ups, wall clock around a full drain."""
+    dev = images.device
+    B = images.shape[0]
+    h_img = images.cpu().pin_memory()
+    d_in = [torch.empty_like(images), torch.empty_like(images)]
+    res0 = tower.detect(images, text, meta, normalize_text=not uni, score_thr=0.0 if uni else 0.001, with_embed=True)
+    keys = ("bboxes", "scores", "labels", "count")
+    h_out = {k: torch.empty(res0[k].shape, dtype=res0[k].dtype).pin_memory() for k in keys}
+    d_out = [{k: torch.empty_like(res0[k]) for k in keys} for _ in range(2)]     # results staged out of the tower's buffers
+    cs = torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream()
+    up = [torch.cuda.Event(), torch.cuda.Event()]
+    free_in = [torch.cuda.Event(), torch.cuda.Event()]
+    done = [torch.cuda.Event(), torch.cuda.Event()]
+    drained = [torch.cuda.Event(), torch.cuda.Event()]
+    kw = dict(normalize_text=not uni, score_thr=0.0 if uni else 0.001, with_embed=True)
+
+    def run(n):
+        with torch.cuda.stream(cs):
+            d_in[0].copy_(h_img, non_blocking=True)
+            up[0].record(cs)
+        for i in range(n):
+            cur, nxt = i & 1, (i + 1) & 1
+            if i + 1 < n:
+                with torch.cuda.stream(cs):
+                    if i >= 1:
+                        cs.wait_event(free_in[nxt])            # step i-1 has finished reading that input buffer
+                    d_in[nxt].copy_(h_img, non_blocking=True)
+                    up[nxt].record(cs)
+            main.wait_event(up[cur])
+            r = tower.detect(d_in[cur], text, meta, **kw)
+            free_in[cur].record(main)
+            if i >= 2:
+                main.wait_event(drained[cur])                  # the D2H of step i-2 has left this staging set
+            for k in keys:
+                d_out[cur][k].copy_(r[k], non_blocking=True)
+            done[cur].record(main)
+            with torch.cuda.stream(cs):
+                cs.wait_event(done[cur])
+                for k in keys:
+                    h_out[k].copy_(d_out[cur][k], non_blocking=True)
+                drained[cur].record(cs)
+        torch.cuda.synchronize()
+
+    run(2)
+    t0 = time.perf_counter()
+    run(steps)
+    dt = (time.perf_counter() - t0) / steps
+    h2d = h_img.numel()
+    d2h = sum(v.numel() * v.element_size() for v in h_out.values())
+    return {"value": round(B / dt, 3), "unit": "images/s", "ms_per_step": round(1e3 * dt, 3), "steps": steps,
+            "h2d_bytes_per_step": int(h2d), "d2h_bytes_per_step": int(d2h),
+            "note": "uint8 batch uploaded from pinned host memory and boxes / scores / labels / counts copied back EVERY step, "
+                    "on a copy stream overlapped with compute (double-buffered); PCIe-inclusive, never the headline value",
+            "kept_rows_last_image": int(h_out["count"][-1])}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -262,13 +332,25 @@ def main():
     timer.install()
 
     gatherer = RegionGatherer() if world > 1 else None
+    lvl_scale = torch.tensor(tower.lvl_logit_scale, dtype=torch.float32, device="cuda")
+    lvl_bias = torch.tensor(tower.lvl_bias, dtype=torch.float32, device="cuda")
+    image_ids = torch.arange(rank * B, (rank + 1) * B, dtype=torch.int64, device="cuda")
+    stall = []                                  # (event before, event after) around the gather hand-over of a step
 
-    def step():
+    def step(measure_stall=False):
         res = tower.detect(images, text, meta, normalize_text=not uni, score_thr=0.0 if uni else 0.001,
                            with_embed=True)
         if gatherer is not None:
-            # the exchange of this batch's kept-region embeddings runs behind the next batch's kernels
-            gatherer.submit(res["embeddings"], res["count"])
+            # the exchange of this batch's kept regions (embeddings + per-region scale / bias + counts + image ids:
+            # the four lists of extract_embedding.py:1753-1756) runs behind the next batch's kernels
+            lvl = tower.level_of(res["anchors"])
+            if measure_stall:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            gatherer.submit(res["embeddings"], res["count"], scales=lvl_scale[lvl], bias=lvl_bias[lvl], image_ids=image_ids)
+            if measure_stall:
+                e1.record()
+                stall.append((e0, e1))
         return res
 
     def sync():
@@ -291,11 +373,16 @@ def main():
     for i in range(args.steps):
         if i == args.steps - n_inst:
             timer.mode = "time"
-        res = step()
+        res = step(measure_stall=world > 1)
     sync()
     dt = time.perf_counter() - t0
     timer.mode = "off"
+    per_rank = None
     if dist is not None:
+        own = dict(rank=rank, ms_per_step=round(1e3 * dt / args.steps, 3),
+                   gather_handover_ms_per_step=round(sum(a.elapsed_time(b) for a, b in stall) / max(1, len(stall)), 3))
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, own)
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -312,7 +399,8 @@ def main():
         # fp16x3 issues three fp16 MFMA passes per fp32-accurate product: the roof for ALGORITHMIC
         # flops is the fp16 dense peak / 3; the fraction of the raw fp16 peak is reported beside it.
         dom_peak = round(F16_MFMA_PEAK_TFLOPS / SPLIT_PASSES, 1) if dom_split else F32_MFMA_PEAK_TFLOPS
-        dom_fn = "split_gemm_glds" if "glds" in dom_tag else "split_gemm_pingpong" if "pingpong" in dom_tag else "split_gemm"
+        dom_fn = ("split_gemm_p8" if "/p8s" in dom_tag else "split_gemm_glds" if "glds" in dom_tag
+                  else "split_gemm_pingpong" if "pingpong" in dom_tag else "split_gemm")
         dom_kernel = (f"{dom_fn}_kernel<{dom_tag}> (3 x v_mfma_f32_32x32x16_f16 per product)" if dom_split
                       else f"conv_gemm_kernel<{dom_tag}> (fp32 MFMA 16x16x4)")
         out = {
@@ -364,6 +452,10 @@ def main():
         if world == 1 and split and not args.no_fp32_reference:
             # the same workload with native fp32 MFMA arithmetic, measured in this run (same images, weights, bank)
             out["fp32_mode"] = fp32_reference_run(args, tower, images, text, meta, uni)
+        if world == 1 and not args.no_host_fed:
+            out["host_fed"] = host_fed_run(tower, images, text, meta, uni, args.steps)
+        if per_rank is not None:
+            out["per_rank"] = per_rank
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.arch, S, K, args.cpu_images)
         print(json.dumps(out), flush=True)

@@ -141,6 +141,14 @@ int wd_conv_gemm_split_ws(const WdConvGemm* p, const void* w_split, float w_unsc
 /* Name of the tile wd_conv_gemm_split picks with cfg < 0 for an (m, n, k) problem; is_conv != 0:
  * not a 1x1 / stride 1 / pad 0 layer (diagnostic). */
 const char* wd_conv_gemm_split_config(int32_t m, int32_t n, int32_t k, int32_t is_conv);
+/* Workspace of the persistent 256 x 256 kernel (pre-split plain layers with at least one output tile per CU: the
+ * ConvNeXt stage-3 / 4 MLPs at the benchmark batch).  One workgroup per CU walks a contiguous range of
+ * (tile, K tile) units; a tile cut between two CUs is started by one, its raw accumulators are parked here, and
+ * finished by the other from exactly those values (the same MFMA chain: bit-identical to an unsplit tile).
+ * Hand a buffer of this size to wd_conv_gemm_split_ws (splits = 0) and the library picks that kernel where it
+ * applies (wd_conv_gemm_split_config(m, n, k, 3) tells).  The first 4 KB must be ZERO before the first launch
+ * (flags: the kernel leaves them zero again) and the buffer must not be shared with split-K launches. */
+int64_t wd_p8_workspace_bytes(void);
 
 /* ---------------------------------------------------------------------------------------------
  * wd_cv_resize_paste_u8 — OpenCV-style 8-bit resize of one uint8 HWC 3-channel image fused with the letter pad,

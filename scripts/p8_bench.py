@@ -18,10 +18,9 @@ SHAPES = {
     "s3_pw2 51200x512x2048 res": dict(m=51200, n=512, k=2048, res=True),
     "s4_pw1 12800x4096x1024 gelu": dict(m=12800, n=4096, k=1024, gelu=True),
     "s4_pw2 12800x1024x4096 res": dict(m=12800, n=1024, k=4096, res=True),
-    "L3_pw1 25600x3072x768 gelu": dict(m=25600, n=3072, k=768, gelu=True),
-    "L3_pw2 25600x768x3072 res": dict(m=25600, n=768, k=3072, res=True),
 }
-cfgs = [int(c) for c in os.environ.get("CFGS", "60,63,64").split(",")]
+cfgs = [int(c) for c in os.environ.get("CFGS", "60,63,64,65").split(",")]
+park = torch.zeros(L.p8_workspace_bytes() // 4, dtype=torch.float32, device=dev)
 rounds = int(os.environ.get("ROUNDS", "5"))
 reps = int(os.environ.get("REPS", "6"))
 only = os.environ.get("ONLY")
@@ -30,8 +29,9 @@ for name, sh in SHAPES.items():
         continue
     m, n, k = sh["m"], sh["n"], sh["k"]
     x = torch.randn(m, k, device=dev) * 1.5
-    xs = torch.empty(m, k, device=dev)
-    L.layernorm_rows(x, xs, torch.ones(k, device=dev), torch.zeros(k, device=dev), m, k, split=True)
+    xs = torch.empty(L.LIB.wd_split_weights_bytes(m, k), dtype=torch.uint8, device=dev)      # [hi x8 | lo x8] groups, scale 1
+    L.check(L.LIB.wd_split_weights(x.data_ptr(), m, k, 1.0, xs.data_ptr(), L.stream_ptr()), "wd_split_weights")
+    xs = xs.view(torch.float32).view(m, k)
     del x
     w = torch.randn(n, k, device=dev) * k ** -0.5
     b = torch.randn(n, device=dev)
@@ -44,14 +44,14 @@ for name, sh in SHAPES.items():
     c = torch.empty(m, n, device=dev)
     if sh.get("res"):
         kw.update(res=c, ldres=n)                          # in place, as the engine runs pwconv2
+    c_init = torch.randn(m, n, device=dev)
     times = {cfg: [] for cfg in cfgs}
     ok = {}
     ref = None
     for cfg in cfgs:
         try:
-            c.normal_()
-            c0 = c.clone()
-            L.conv_gemm(xs, None, b, c, w_split=ws, split_cfg=cfg, split_flags=flags, **kw)
+            c.copy_(c_init)
+            L.conv_gemm(xs, None, b, c, w_split=ws, split_cfg=cfg, split_flags=flags, workspace=park if cfg == 65 else None, **kw)
             torch.cuda.synchronize()
             if ref is None:
                 ref = c.clone()
@@ -65,10 +65,10 @@ for name, sh in SHAPES.items():
             if ok[cfg].startswith("FAILED"):
                 continue
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            L.conv_gemm(xs, None, b, c, w_split=ws, split_cfg=cfg, split_flags=flags, **kw)
+            L.conv_gemm(xs, None, b, c, w_split=ws, split_cfg=cfg, split_flags=flags, workspace=park if cfg == 65 else None, **kw)
             s.record()
             for _ in range(reps):
-                L.conv_gemm(xs, None, b, c, w_split=ws, split_cfg=cfg, split_flags=flags, **kw)
+                L.conv_gemm(xs, None, b, c, w_split=ws, split_cfg=cfg, split_flags=flags, workspace=park if cfg == 65 else None, **kw)
             e.record()
             torch.cuda.synchronize()
             times[cfg].append(1e3 * s.elapsed_time(e) / reps)

@@ -404,6 +404,15 @@ def _ragged_worker(rank, world, port, q):
     last = rg.collect()
     steps.append((last["embeddings"][:, 0, 0].tolist(), last["count"].tolist()))
     out["steps"] = steps
+    # the packed metadata collective: scales / bias bit patterns, counts, image ids (extract_embedding.py:1753-1756)
+    rg2 = RegionGatherer()
+    emb = torch.full((2, 4, 8), float(rank))
+    sc = torch.arange(8, dtype=torch.float32).view(2, 4) * 0.125 - rank
+    bi = -sc - 0.5
+    rg2.submit(emb, torch.tensor([4, 1], dtype=torch.int32), scales=sc, bias=bi, image_ids=torch.tensor([1000 + rank, 2000 + rank]))
+    got = rg2.collect()
+    out["meta"] = (got["scales"].tolist(), got["bias"].tolist(), got["image_ids"].tolist(), got["count"].tolist(),
+                   got["scales"].dtype == torch.float32)
     q.put((rank, out))
     dist.destroy_process_group()
 
@@ -434,6 +443,10 @@ def test_ragged_gather_world3_gloo():
         assert len(st) == 3
         assert st[0] == ([0.0, 0.0, 1.0, 1.0, 2.0, 2.0], [3, 4, 3, 4, 3, 4])
         assert st[2] == ([20.0, 20.0, 21.0, 21.0, 22.0, 22.0], [3, 0, 0, 0, 0, 0])  # padded rows carry count 0
+        sc, bi, ids, cnt, is_f32 = out["meta"]
+        want_sc = [[(4 * i + j) * 0.125 - r for j in range(4)] for r in range(3) for i in range(2)]
+        assert is_f32 and sc == want_sc and bi == [[-v - 0.5 for v in row] for row in want_sc]
+        assert ids == [1000, 2000, 1001, 2001, 1002, 2002] and cnt == [4, 1] * 3
 
 
 def test_region_gatherer_single_process_does_not_alias_the_callers_buffers():

@@ -51,7 +51,7 @@ def _run_config(arch, b, k, fixture, precision):
         check_checksum(f"{tag} embed{l}", embed[0, tower.off[l]:tower.off[l] + tower.nl[l]], fx, f"embed{l}", 1e-3, 1e-3)
     # ---- mmdet path: K-class normalised bank, thr 0.001, rescale before NMS (the judged similarity GEMM)
     text = torch.from_numpy(W.make_text_bank(k) * np.float32(1.7)).cuda()
-    scores = tower.similarity(text, normalize=True)
+    scores = tower.similarity(text, normalize=True).clone()            # the Uni pass below reuses the tower's score buffer
     pad, sf, ori = fx["mm.img0.pad"], fx["mm.img0.sf"], fx["mm.img0.ori"]
     meta = torch.tensor([[float(pad[2]), float(pad[0]), 0.0, float(sf[0]), float(sf[1]), float(ori[1]), float(ori[0]), 1.0]] * b,
                         dtype=torch.float32).cuda()

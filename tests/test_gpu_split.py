@@ -289,7 +289,7 @@ def test_retrieval_max_split_matches_fp32_kernel_and_shards():
     assert torch.equal(torch.cat(parts, dim=1), out)
 
 
-@pytest.mark.parametrize("m,n,k", [(257, 320, 64), (1000, 256, 96), (513, 512, 128), (2048, 768, 1024), (300, 40, 160)])
+@pytest.mark.parametrize("m,n,k", [(264, 320, 64), (1000, 256, 96), (520, 512, 128), (2048, 768, 1024), (304, 40, 160), (257, 320, 64), (8, 8, 32)])
 @pytest.mark.parametrize("mode", ["gelu_csplit", "residual"])
 def test_p8_kernel_bit_identical_to_the_128_tile_kernel(m, n, k, mode):
     """cfg 64 (256 x 256 tiles, K tiles of 32, counted LDS-DMA waits, two staggered wave groups) against cfg 60 on
@@ -311,6 +311,11 @@ def test_p8_kernel_bit_identical_to_the_128_tile_kernel(m, n, k, mode):
     outs = []
     for cfg in (60, 64):
         c = torch.full((m, n), 7.0, device="cuda")
+        if m % 8 or n % 8:                                        # the 256-tile kernel clamps DMA row groups of 8 as a whole
+            if cfg == 64:
+                with pytest.raises(L.WedetectHipError):
+                    L.conv_gemm(xs, None, bias, c, w_split=ws, split_cfg=cfg, split_flags=flags, **kw)
+                return
         L.conv_gemm(xs, None, bias, c, w_split=ws, split_cfg=cfg, split_flags=flags, **kw)
         outs.append(c)
     torch.cuda.synchronize()
@@ -319,3 +324,44 @@ def test_p8_kernel_bit_identical_to_the_128_tile_kernel(m, n, k, mode):
         c = torch.full((m, n), 7.0, device="cuda")
         L.conv_gemm(xs, None, bias, c, w_split=ws, split_cfg=64, split_flags=flags, **kw)
         assert torch.equal(c.view(torch.int32), outs[1].view(torch.int32))
+
+
+@pytest.mark.parametrize("m,n,k,mode", [(51200, 512, 2048, "residual"), (51200, 2048, 512, "gelu_csplit"), (65536 + 8, 256, 96, "residual"),
+                                         (66000, 512, 32, "gelu_csplit"), (131064, 256, 64, "residual")])
+def test_p8_persistent_kernel_bit_identical_and_repeatable(m, n, k, mode):
+    """cfg 65: one workgroup per CU walks a contiguous range of (tile, K tile) units; tiles cut between two CUs are
+    started by one, parked in the workspace, and finished by the other from the parked accumulators.  Same MFMA chain
+    per accumulator => bit-identical to the 128-tile kernel; the flag words return to zero, so launches repeat; K tile
+    counts 1, 2, 3 and many; partial last row tile."""
+    from wedetect_amd import lib as L
+    x = _rand((m, k), 101, 1.5)
+    xs = torch.empty(m, k, device="cuda")
+    L.layernorm_rows(x, xs, torch.ones(k, device="cuda"), torch.zeros(k, device="cuda"), m, k, split=True) if k <= 512 else None
+    if k > 512:                                                   # wide rows: split through the weight splitter (scale 1)
+        buf = torch.empty(L.LIB.wd_split_weights_bytes(m, k), dtype=torch.uint8, device="cuda")
+        L.check(L.LIB.wd_split_weights(x.data_ptr(), m, k, 1.0, buf.data_ptr(), L.stream_ptr()), "wd_split_weights")
+        xs = buf.view(torch.float32).view(m, k)
+    w, bias = _rand((n, k), 104, k ** -0.5), _rand((n,), 105, 0.1)
+    ws = L.split_weights(w)
+    kw = dict(batch=1, hin=1, win=m, cin=k, lda=k, n=n, ldc=n)
+    if mode == "gelu_csplit":
+        kw.update(act=L.ACT_GELU)
+        flags = L.SPLIT_A | L.SPLIT_C
+    else:
+        kw.update(res=_rand((m, n), 106), ldres=n)
+        flags = L.SPLIT_A
+    ref = torch.full((m, n), 7.0, device="cuda")
+    L.conv_gemm(xs, None, bias, ref, w_split=ws, split_cfg=60, split_flags=flags, **kw)
+    park = torch.zeros(L.p8_workspace_bytes() // 4, dtype=torch.float32, device="cuda")
+    for rep in range(3):
+        c = torch.full((m, n), 7.0, device="cuda")
+        L.conv_gemm(xs, None, bias, c, w_split=ws, split_cfg=65, split_flags=flags, workspace=park, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(c.view(torch.int32), ref.view(torch.int32)), f"run {rep}: max|d| {float((c - ref).abs().max())}"
+        assert int(park[:1024].view(torch.int32).abs().max()) == 0, "flag words must be zero again after a launch"
+    with pytest.raises(L.WedetectHipError):                       # no workspace
+        L.conv_gemm(xs, None, bias, c, w_split=ws, split_cfg=65, split_flags=flags, **kw)
+    small = torch.full((2048, n), 7.0, device="cuda")
+    with pytest.raises(L.WedetectHipError):                       # fewer tiles than CUs: ranges shorter than a tile would chain
+        L.conv_gemm(xs[:2048], None, bias, small, w_split=ws, split_cfg=65, split_flags=flags, workspace=park,
+                    **dict(kw, win=2048, **({"res": kw["res"][:2048]} if "res" in kw else {})))

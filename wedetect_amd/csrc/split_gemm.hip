@@ -101,9 +101,34 @@ static int pick_split_cfg(const WdConvGemm& p) {
   return tiles < 1024 ? 50 : 51;                                    // few tiles: deeper K stage
 }
 
-// is_conv: 0 = plain, 1 = conv, 2 = plain with pre-split operands (direct-to-LDS kernel)
+long long wd_p8_workspace_floats();                                   // split_gemm_p8.hip
+
+extern "C" int64_t wd_p8_workspace_bytes(void) { return 4 * wd_p8_workspace_floats(); }
+
+// Production kernel of a plain layer with pre-split operands (k % 16 == 0).  `park`: the caller offers a
+// workspace of wd_p8_workspace_bytes() for the persistent work-unit kernel.
+//   65  256 x 256 x 32, persistent (split_gemm_p8.hip): layers with at least one output tile per CU and whole column
+//       tiles — the ConvNeXt stage-3 / stage-4 MLPs at batch 32 (measured: profiles/r02_p8_ab.txt)
+//   63  256 x 128 x 16 ping-pong: very long m (stages 1-2)
+//   60  128 x 128 x 16 direct-to-LDS: everything else
+static int pick_presplit_cfg(int m, int n, int k, bool park) {
+  if (park && k % 32 == 0 && k >= 256 && m % 8 == 0 && n % 256 == 0 && m < 131072) {
+    const long long tiles = (long long)((m + 255) / 256) * (n / 256);
+    const long long need = wd_p8_workspace_floats() > 0 ? (wd_p8_workspace_floats() - 1024) / (128 * 512) : 1 << 30;   // workgroups
+    if (tiles >= need) return 65;
+  }
+  return m >= 131072 ? 63 : 60;
+}
+
+// is_conv: 0 = plain, 1 = conv, 2 = plain with pre-split operands, 3 = the same with a park workspace on offer
 extern "C" const char* wd_conv_gemm_split_config(int32_t m, int32_t n, int32_t k, int32_t is_conv) {
-  if (is_conv == 2 && k % 16 == 0) return m >= 131072 ? "fp16x3 256x128x16/8w/pingpong" : "fp16x3 128x128x16/4w/glds";
+  if ((is_conv == 2 || is_conv == 3) && k % 16 == 0) {
+    switch (pick_presplit_cfg(m, n, k, is_conv == 3)) {
+      case 65: return "fp16x3 256x256x32/8w/p8s";
+      case 63: return "fp16x3 256x128x16/8w/pingpong";
+      default: return "fp16x3 128x128x16/4w/glds";
+    }
+  }
   WdConvGemm q{};
   q.m = m; q.n = n; q.k = k; q.kh = q.kw = q.stride = 1;
   if (is_conv) q.kh = q.kw = 3;                                      // any non-1x1 geometry selects the conv loader
@@ -119,7 +144,7 @@ extern "C" const char* wd_conv_gemm_split_config(int32_t m, int32_t n, int32_t k
 // K splits for an under-filled launch: few tiles and a long K loop are latency-bound (one workgroup walks
 // K serially); S workgroups per tile walk K / S each and a second pass adds the partial sums.
 static int pick_ksplits(const WdConvGemm& p, int cfg, int flags, long long ws_floats) {
-  if (ws_floats <= 0 || (flags & WD_SPLIT_C) || (p.n & 3) || cfg == 55 || cfg == 63 || cfg == 64) return 1;
+  if (ws_floats <= 0 || (flags & WD_SPLIT_C) || (p.n & 3) || cfg == 55 || cfg == 63 || cfg >= 64) return 1;
   const int bm = 128, bn = (cfg == 52 || cfg == 53) ? 64 : 128, bk = (cfg == 50) ? 32 : 16;
   const long long tiles = (long long)((p.m + (cfg == 52 ? 255 : bm - 1)) / (cfg == 52 ? 256 : bm)) * ((p.n + bn - 1) / bn);
   const int nk = (p.k + bk - 1) / bk;
@@ -149,8 +174,10 @@ static int conv_gemm_split_impl(const WdConvGemm* pp, const void* w_split, float
     // shipped towers; other widths still work, with padding).  Plain layers go global -> LDS
     // directly (cfg 60 / 63); the 2x2 downsample conv and odd K keep the register-staged kernels.
     // long-m layers (ConvNeXt stages 1-2): the ping-pong 256 x 128 kernel, else 128 x 128
-    if (production && plain && !special && p.k % 16 == 0) cfg = p.m >= 131072 ? 63 : 60;
-    if (cfg != 50 && cfg != 51 && cfg != 55 && cfg != 60 && cfg != 63 && cfg != 64) cfg = 51;
+    if (production && plain && !special && p.k % 16 == 0)
+      cfg = pick_presplit_cfg(p.m, p.n, p.k, ws != nullptr && force_splits == 0 && ws_bytes / 4 >= wd_p8_workspace_floats() &&
+                                                 p.lda % 8 == 0 && !(flags & ~(WD_SPLIT_A | WD_SPLIT_C)));
+    if (cfg != 50 && cfg != 51 && cfg != 55 && cfg != 60 && cfg != 63 && cfg != 64 && cfg != 65 && !(cfg >= 640 && cfg < 672)) cfg = 51;
     if ((flags & WD_SPLIT_C) && cfg == 55) cfg = 50;
   }
   const long long ws_floats = ws ? ws_bytes / 4 : 0;
@@ -160,12 +187,12 @@ static int conv_gemm_split_impl(const WdConvGemm* pp, const void* w_split, float
     if (splits > nk) splits = nk;                             // never an empty split
   }
   if (splits > 1) {
-    if ((flags & WD_SPLIT_C) || (p.n & 3) || cfg == 55 || cfg == 63 || cfg == 64) return WD_ERR_UNSUPPORTED;
+    if ((flags & WD_SPLIT_C) || (p.n & 3) || cfg == 55 || cfg == 63 || cfg >= 64) return WD_ERR_UNSUPPORTED;
     if ((long long)splits * p.m * p.n > ws_floats) return WD_ERR_WORKSPACE;
   }
   int lrc;
   if (flags != 0) {
-    lrc = wd_launch_presplit(p, w_split, w_unscale, cfg, flags, st, splits, ws);
+    lrc = wd_launch_presplit(p, w_split, w_unscale, cfg, flags, st, splits, ws, ws_floats);
   } else {
     switch (cfg) {
       case 41: lrc = launch_split<2, 2, 2, 4, 16, SVAR_XCD | SVAR_PIN | SVAR_LDSEPI>(p, w_split, w_unscale, st, splits, ws); break;  // 128 x 256 x 16, 8 waves

@@ -611,4 +611,4 @@ int check_split_args(const WdConvGemm& p, const void* wsp, float unscale) {
 
 // defined in split_gemm_pre.hip: launch with pre-split activations (flags: WD_SPLIT_A / WD_SPLIT_C)
 int wd_launch_presplit(const WdConvGemm& p, const void* w_split, float w_unscale, int cfg, int flags, hipStream_t st,
-                       int ksplits = 1, float* ws = nullptr);
+                       int ksplits = 1, float* ws = nullptr, long long ws_floats = 0);

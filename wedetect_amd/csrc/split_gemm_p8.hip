@@ -8,23 +8,26 @@
 // 32 x 32 accumulators = 128 registers), so a K tile of 32 costs 20 ds_read_b128 per 48 MFMAs,
 // and global -> LDS traffic per MFMA halves.  The K loop never drains the DMA queue:
 //
-//   * LDS holds two K tiles of 64 KB, each cut into four 16 KB regions (128 rows x 128 B):
+//   * LDS (144 KB): two K-tile buffers of 48 KB, each cut into three 16 KB regions (128 rows x 128 B)
 //       A0 / A1 = activation rows {0-63, 128-191} / {64-127, 192-255} of the tile (the first / second
-//                 64 rows of each row group),  W0 / W1 = weight rows {64 wn + 0-31} / {64 wn + 32-63}.
+//                 64 rows of each row group),  W1 = weight rows {64 wn + 32-63},
+//     plus a ring of THREE 16 KB slots for W0 = weight rows {64 wn + 0-31} (K tile t lives in slot t % 3).
 //   * a K tile is consumed in four phases, one 64 x 32 output quadrant of the wave per phase
 //     (12 MFMAs = 2 row blocks x 2 k16 steps x {lo.hi, hi.lo, hi.hi}):
 //       phase 1  read A0 (8 x ds_read_b128) + W0 (4)   quadrant (rows 0-63,  cols 0-31)
 //       phase 2  read W1 (4)                           quadrant (rows 0-63,  cols 32-63)
 //       phase 3  read A1 (8)                           quadrant (rows 64-127, cols 32-63)
-//       phase 4  -  (W0 still in registers)            quadrant (rows 64-127, cols 0-31)
+//       phase 4  read W0 again (4)                     quadrant (rows 64-127, cols 0-31)
+//     One activation and ONE weight fragment set (48 registers) next to the 128 accumulator registers; W0 is
+//     read twice rather than held (16 registers that the persistent form needs), hence its third slot.
 //     The per-accumulator MFMA sequence (k ascending, lo.hi -> hi.lo -> hi.hi inside a k16 step) is the
 //     one of every other fp16x3 kernel: results are bit-identical to theirs.
-//   * every phase also re-fills one region that went dead two phases earlier with the data of two K
-//     tiles ahead (phase 1: W1 of tile t+1, 2: A1 of t+1, 3: A0 of t+2, 4: W0 of t+2): 16 one-KB
-//     global_load_lds_dwordx4 per region, two per wave, issued from inline asm so that hipcc does
-//     not serialise them against the ds_reads.  A region is read five or six phases after it was
-//     requested; each wave retires its own requests with a COUNTED s_waitcnt vmcnt(8) (the four
-//     newest regions stay in flight across the barriers) and never waits vmcnt(0) in steady state.
+//   * every phase also re-fills one region that went dead two phases earlier (tile t: phase 1: A1 of tile
+//     t+1, 2: W0 of t+2, 3: A0 of t+2, 4: W1 of t+2): 16 one-KB global_load_lds_dwordx4 per region, two per
+//     wave, issued from inline asm so that hipcc does not serialise them against the ds_reads.  A region is
+//     read six or seven phases after it was requested; each wave retires its own requests with a COUNTED
+//     s_waitcnt vmcnt(10) (the five newest regions stay in flight across the barriers) and never waits
+//     vmcnt(0) in steady state.
 //   * phase = [ds_reads, DMA issue, vmcnt] s_barrier [12 MFMAs] s_barrier.  The two row groups
 //     (waves 0-3 / 4-7; waves w and w + 4 share a SIMD) are offset by one barrier, so a SIMD's
 //     matrix pipe is fed by one wave while its partner reads and requests.  A region is re-filled
@@ -35,10 +38,12 @@
 //     rows are clamped to the last valid row (their outputs are never stored), so no zero page.
 #include "split_gemm_impl.h"
 
+long long wd_p8_workspace_floats();
+
 namespace {
 
-constexpr int P8_ROWB = 128, P8_REGION = 128 * P8_ROWB, P8_TILE = 4 * P8_REGION, P8_LDS = 2 * P8_TILE;
-constexpr int P8_A0 = 0, P8_W0 = P8_REGION, P8_W1 = 2 * P8_REGION, P8_A1 = 3 * P8_REGION;
+constexpr int P8_ROWB = 128, P8_REGION = 128 * P8_ROWB, P8_TILE = 3 * P8_REGION, P8_LDS = 2 * P8_TILE + 3 * P8_REGION;
+constexpr int P8_A0 = 0, P8_W1 = P8_REGION, P8_A1 = 2 * P8_REGION, P8_W0RING = 2 * P8_TILE;   // W0 of K tile t: P8_W0RING + (t % 3) * P8_REGION
 
 // one 1 KB LDS-DMA: 64 lanes x 16 B from base + voff[lane] to LDS [lds_addr, +1024)
 __device__ __forceinline__ void p8_dma(unsigned lds_addr, unsigned voff, const unsigned char* base) {
@@ -46,6 +51,7 @@ __device__ __forceinline__ void p8_dma(unsigned lds_addr, unsigned voff, const u
                :: "s"(lds_addr), "v"(voff), "s"(base) : "memory", "m0");
 }
 
+#define P8_KBARRIER() do { if (!(ABL & 8)) P8_BARRIER(); } while (0)
 #define P8_BARRIER()                          \
   do {                                        \
     __builtin_amdgcn_sched_barrier(0);        \
@@ -55,211 +61,371 @@ __device__ __forceinline__ void p8_dma(unsigned lds_addr, unsigned voff, const u
     __builtin_amdgcn_sched_barrier(0);        \
   } while (0)
 
-template <int VAR>
+// ABL: timing-only ablations for on-device diagnosis (WRONG results by construction; compiled only with
+// -DWD_DEBUG_ABLATIONS, reachable through cfg 640 + ABL): 1 = no DMA in the K loop, 2 = no ds_reads in the K loop,
+// 4 = no epilogue, 8 = no barriers in the K loop, 16 = both wave groups in step (no stagger).
+//
+// PERSIST (cfg 65): one workgroup per CU walks a contiguous range of (tile, K tile) work units instead of
+// owning whole output tiles, so 400 tiles on 256 CUs cost 1.5625 tile times, not 2 (and the epilogues of
+// different CUs stop happening in the same microseconds).  The tile list is cut into 8 chunks, one per XCD
+// (workgroup b runs on XCD b % 8: neighbouring tiles share operand panels through that XCD's L2), each chunk's
+// units are dealt evenly to the XCD's workgroups.  A workgroup's range therefore starts and / or ends inside
+// a tile.  The head of a tile [0, e) is computed FIRST, its raw accumulators are parked in the workspace and a
+// flag is published (agent-scope release); whole tiles follow; LAST comes the tail [o, nk) of the tile the
+// previous workgroup of the chain began: wait for that flag (set long before), acquire, reload the
+// accumulators and continue the K loop where it stopped — the same MFMA chain, only carried by two CUs, so the
+// result is bit-identical to the one-workgroup-per-tile kernels.  A workgroup waits only on its predecessor in
+// the XCD chain (block b - 8, dispatched earlier), and only at the very end of its own work; the first of a
+// chain never waits.  Needs tiles >= workgroups (every range is at least one whole tile long).
+constexpr long long P8_PARK_BYTES = 8ll * 32768;       // per workgroup: 8 accumulators x 512 lanes x 64 B
+struct P8Persist {
+  float* acc;            // [workgroup][512 lanes][128 floats]: parked accumulators of the tile a workgroup shares with its successor
+  unsigned* flag;        // [workgroup]: 1 = parked; reset to 0 by the consumer
+  const float* zero;     // 512 bytes of zeros
+  int ntiles;
+};
+
+template <int VAR, int ABL = 0, bool PERSIST = false>
 __global__ void __launch_bounds__(512, 2)
 split_gemm_p8_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, int k16, float unscale, int nbn,
-                     int vec_c, int vec_res, int vec_bias, int ngrp, int nbm) {
+                     int vec_c, int vec_res, int vec_bias, int ngrp, int nbm, const P8Persist ps) {
   constexpr int TM = 4, TN = 2, BM = 256, BN = 256, ROWB = P8_ROWB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int group = wave >> 2, wn = wave & 3;
-  int tile = blockIdx.x;
-  {
+  const int nk = p.k >> 5;
+  const int gsz = ngrp * nbm;
+
+  // ---- work assignment
+  int seg_first_tile, seg_o, seg_last_tile, seg_e;   // units [first_tile * nk + o, last_tile * nk + e)
+  if (PERSIST) {
+    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3, per = gridDim.x >> 3;
+    const long long t0 = (long long)ps.ntiles * xcd / 8, t1 = (long long)ps.ntiles * (xcd + 1) / 8;
+    const long long units = (t1 - t0) * nk;
+    const long long u0 = t0 * nk + units * slot / per, u1 = t0 * nk + units * (slot + 1) / per;
+    seg_first_tile = (int)(u0 / nk); seg_o = (int)(u0 - (long long)seg_first_tile * nk);
+    seg_last_tile = (int)(u1 / nk); seg_e = (int)(u1 - (long long)seg_last_tile * nk);
+  } else {
+    int tile = blockIdx.x;
     const int nwg = gridDim.x, xcd = tile & 7, idx = tile >> 3;
     const int q = nwg >> 3, r = nwg & 7;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    seg_first_tile = tile; seg_o = 0; seg_last_tile = tile + 1; seg_e = 0;
   }
-  const int gsz = ngrp * nbm;
-  const int grp = tile / gsz, rem = tile - grp * gsz;
-  const int bm = rem / ngrp, bn = grp * ngrp + (rem - bm * ngrp);
-  const int m0 = bm * BM, n0 = bn * BN;
-  const int nk = p.k >> 5;
+  // segments in execution order: [head of the last tile] [whole tiles] [tail of the first tile]
+  const int has_head = seg_e > 0, has_tail = seg_o > 0;
+  const int full0 = seg_first_tile + has_tail, nfull = seg_last_tile - full0;
+  const int nseg = has_head + nfull + has_tail;
 
-  // ---- DMA sources: instruction j (0 / 1) of this wave fills slots [(2 wave + j) * 8, +8) of a region
   const unsigned char* abase = reinterpret_cast<const unsigned char*>(p.a);
-  unsigned va0[2], va1[2], vw0[2], vw1[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int slot = (wave * 2 + j) * 8 + (lane >> 3);
-    const int logical = (lane & 7) ^ ((slot >> 1) & 7);
-    const int memchunk = (logical & ~3) | ((logical & 1) << 1) | ((logical >> 1) & 1);
-    int ar = m0 + (slot >> 6) * 128 + (slot & 63);              // A0 row; A1 = + 64
-    int wr = n0 + (slot >> 5) * 64 + (slot & 31);               // W0 row; W1 = + 32
-    const int ar1 = ar + 64 < p.m ? ar + 64 : p.m - 1, wr1 = wr + 32 < p.n ? wr + 32 : p.n - 1;
-    ar = ar < p.m ? ar : p.m - 1;
-    wr = wr < p.n ? wr : p.n - 1;
-    va0[j] = (unsigned)((size_t)ar * p.lda * 4 + memchunk * 16);
-    va1[j] = (unsigned)((size_t)ar1 * p.lda * 4 + memchunk * 16);
-    vw0[j] = (unsigned)((size_t)wr * k16 * 4 + memchunk * 16);
-    vw1[j] = (unsigned)((size_t)wr1 * k16 * 4 + memchunk * 16);
-  }
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_raw;
-  const unsigned dma_dst = lds0 + wave * 2048;                   // + buffer + region + j * 1024
-  // request region `reg` of K tile kt into buffer kt & 1
-  auto stage = [&](int kt, int reg, unsigned (&voff)[2], const unsigned char* base) {
-    const unsigned dst = dma_dst + (kt & 1) * P8_TILE + reg;
-    const unsigned char* kbase = base + (size_t)kt * ROWB;       // scalar: the K offset rides on the SGPR base
-    p8_dma(dst, voff[0], kbase);
-    p8_dma(dst + 1024, voff[1], kbase);
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-  // ---- fragment addresses (byte offsets inside a region): slot * 128 + ((logical ^ f(slot)) << 4)
+  const unsigned dma_dst = lds0 + wave * 1024;                   // + region offset + j * 8192: instruction j of wave w fills slots [(w + 8 j) * 8, + 8)
+  // ---- fragment addresses (byte offsets inside a region): slot * 128 + ((logical ^ f(slot)) << 4), logical =
+  // 4 ks + 2 (hi / lo) + hsel.  With g = hsel ^ f(slot) the four (ks, hi / lo) variants of a lane are
+  // base ^ {0, 32, 64, 96}, base = slot * 128 + (g << 4): ONE register per operand (the second activation row
+  // block is + 4096), the variants cost one v_xor each.
   const int hsel = lane >> 5;
-  int aoff[2][2][2], woff[2][2];                                  // [row block][k16 step][hi / lo], [k16 step][hi / lo]
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int slot = group * 64 + i * 32 + (lane & 31), f = (slot >> 1) & 7;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      aoff[i][ks][0] = slot * ROWB + (((ks * 4 + hsel) ^ f) << 4);
-      aoff[i][ks][1] = slot * ROWB + (((ks * 4 + 2 + hsel) ^ f) << 4);
-    }
+  int abase_off, wbase_off;
+  {
+    const int slot = group * 64 + (lane & 31);
+    abase_off = slot * ROWB + ((hsel ^ ((slot >> 1) & 7)) << 4);
   }
   {
-    const int slot = wn * 32 + (lane & 31), f = (slot >> 1) & 7;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      woff[ks][0] = slot * ROWB + (((ks * 4 + hsel) ^ f) << 4);
-      woff[ks][1] = slot * ROWB + (((ks * 4 + 2 + hsel) ^ f) << 4);
-    }
+    const int slot = wn * 32 + (lane & 31);
+    wbase_off = slot * ROWB + ((hsel ^ ((slot >> 1) & 7)) << 4);
   }
-  h8 xh[2][2], xl[2][2], w0h[2], w0l[2], w1h[2], w1l[2];         // activation fragments [row block][k16 step]; weights [k16 step]
-  auto read_a = [&](const unsigned char* region) {
+
+  // lane part of the DMA source offset: row (lane >> 3) of the 8-row group + the swizzled 16-byte chunk.  With slots
+  // dealt as (wave + 8 j) * 8 + r8 the swizzle term f(slot) = ((wave & 1) * 4 + (r8 >> 1)) is the same for both DMAs.
+  unsigned la, lw;
+  {
+    const int r8 = lane >> 3;
+    const int logical = (lane & 7) ^ (((wave & 1) << 2) | (r8 >> 1));
+    const int memchunk = (logical & ~3) | ((logical & 1) << 1) | ((logical >> 1) & 1);
+    la = (unsigned)r8 * (unsigned)p.lda * 4u + memchunk * 16;
+    lw = (unsigned)r8 * (unsigned)k16 * 4u + memchunk * 16;
+  }
+
+  for (int sg = 0; sg < nseg; ++sg) {
+    // which piece: head (park the accumulators), whole tile, or tail (resume from parked accumulators)
+    const bool is_head = has_head && sg == 0;
+    const bool is_tail = has_tail && sg == nseg - 1;
+    const int tile = is_head ? seg_last_tile : (is_tail ? seg_first_tile : full0 + sg - has_head);
+    const int kb = is_tail ? seg_o : 0;
+    const int nks = (is_head ? seg_e : nk) - kb;                  // K tiles of this piece (>= 1)
+    const int grp = tile / gsz, rem = tile - grp * gsz;
+    const int bm = rem / ngrp, bn = grp * ngrp + (rem - bm * ngrp);
+    const int m0 = bm * BM, n0 = bn * BN;
+
+    // request K tile kt (relative to kb) of one operand region into LDS offset `reg` (buffer / ring slot included):
+    // two 1 KB DMAs per wave.  half: 0 = A0 / W0, 1 = A1 / W1.  The 8-row group's first row is wave-uniform and rides
+    // on the scalar base together with the K offset; the lane part (la / lw) never changes.
+    auto stage = [&](int kt, int reg, bool is_w, int half) {
+      if (ABL & 1) return;
+      const unsigned char* base = is_w ? wsp : abase;
+      const unsigned pitch = (unsigned)(is_w ? k16 : p.lda) * 4u;
+      const int limit = (is_w ? p.n : p.m) - 8;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 2; ++j) {
+        int row = is_w ? n0 + (2 * j + (wave >> 2)) * 64 + (wave & 3) * 8 + half * 32 : m0 + j * 128 + wave * 8 + half * 64;
+        row = row < limit ? row : limit;                            // whole groups past the end re-read the last one
+        const unsigned char* src = base + (size_t)row * pitch + (size_t)(kb + kt) * ROWB;
+        p8_dma(dma_dst + reg + j * 8192, is_w ? lw : la, src);
+      }
+    };
+
+    f32x16 acc[TM][TN];
+    // ---- prologue: K tiles 0 and 1 of the piece (the previous piece's epilogue is done with the LDS)
+    P8_BARRIER();
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+      if (kt < nks) {
+        stage(kt, kt * P8_TILE + P8_A0, false, 0);
+        stage(kt, P8_W0RING + kt * P8_REGION, true, 0);
+        stage(kt, kt * P8_TILE + P8_W1, true, 1);
+        stage(kt, kt * P8_TILE + P8_A1, false, 1);
+      }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    // The tail of a tile resumes from the accumulators its head parked (written by the previous workgroup of the
+    // chain at the START of its work).  They are NOT loaded here: each phase of the piece's first K tile loads the
+    // two accumulators it is about to use (ldacc below) — 128 live accumulator registers from this point on make
+    // hipcc spill inside the K loop, accumulators that become live one pair per phase do not.
+    const unsigned char* park_src = nullptr;
+    if (PERSIST && is_tail) {
+      const int prev = blockIdx.x - 8;
+      if (t == 0) {
+        while (__hip_atomic_load(ps.flag + prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      __syncthreads();
+      park_src = reinterpret_cast<const unsigned char*>(ps.acc) + (size_t)prev * P8_PARK_BYTES + (unsigned)t * 512u;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    P8_BARRIER();
+    if (group == 1 && !(ABL & 24)) P8_BARRIER();                   // the second row group runs one barrier behind
+
+    h8 xh[2][2] = {}, xl[2][2] = {}, wh[2] = {}, wl[2] = {};       // activation fragments [row block][k16 step]; weights [k16 step]
+    auto read_a = [&](const unsigned char* region) {
+      if (ABL & 2) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) asm volatile("" : "+v"(xh[i][ks]), "+v"(xl[i][ks]));
+        return;
+      }
+      int b = abase_off;
+      asm volatile("" : "+v"(b));                                  // keep the xor variants out of long-lived registers
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          xh[i][ks] = *reinterpret_cast<const h8*>(region + i * 4096 + (b ^ (ks * 64)));
+          xl[i][ks] = *reinterpret_cast<const h8*>(region + i * 4096 + (b ^ (ks * 64 + 32)));
+        }
+    };
+    auto read_w = [&](const unsigned char* region) {
+      if (ABL & 2) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) asm volatile("" : "+v"(wh[ks]), "+v"(wl[ks]));
+        return;
+      }
+      int b = wbase_off;
+      asm volatile("" : "+v"(b));
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        xh[i][ks] = *reinterpret_cast<const h8*>(region + aoff[i][ks][0]);
-        xl[i][ks] = *reinterpret_cast<const h8*>(region + aoff[i][ks][1]);
+        wh[ks] = *reinterpret_cast<const h8*>(region + (b ^ (ks * 64)));
+        wl[ks] = *reinterpret_cast<const h8*>(region + (b ^ (ks * 64 + 32)));
       }
-  };
-  auto read_w = [&](const unsigned char* region, h8 (&wh)[2], h8 (&wl)[2]) {
+    };
+    // 12 MFMAs of one quadrant: two 32 x 32 accumulators
+    auto quadrant = [&](f32x16& c0, f32x16& c1) {
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      wh[ks] = *reinterpret_cast<const h8*>(region + woff[ks][0]);
-      wl[ks] = *reinterpret_cast<const h8*>(region + woff[ks][1]);
-    }
-  };
-  // 12 MFMAs of one quadrant: accumulators acc[2 * half + i][j], i = 0, 1
-  auto quadrant = [&](f32x16& c0, f32x16& c1, const h8 (&wh)[2], const h8 (&wl)[2]) {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks], xh[0][ks], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks], xh[1][ks], c1, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], xl[0][ks], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], xl[1][ks], c1, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], xh[0][ks], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], xh[1][ks], c1, 0, 0, 0);
-    }
-    __builtin_amdgcn_s_setprio(0);
-  };
+      for (int ks = 0; ks < 2; ++ks) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks], xh[0][ks], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks], xh[1][ks], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], xl[0][ks], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], xl[1][ks], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], xh[0][ks], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], xh[1][ks], c1, 0, 0, 0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+    };
 
-  // ---- prologue: K tiles 0 and 1 complete
-#pragma unroll
-  for (int kt = 0; kt < 2; ++kt)
-    if (kt < nk) {
-      stage(kt, P8_A0, va0, abase);
-      stage(kt, P8_W0, vw0, wsp);
-      stage(kt, P8_W1, vw1, wsp);
-      stage(kt, P8_A1, va1, abase);
-    }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  P8_BARRIER();
-  if (group == 1) P8_BARRIER();                                  // the second row group runs one barrier behind
-
-  // One K tile = four phases.  Counted waits: in steady state the four newest region requests (8 DMA instructions
-  // of this wave) stay in flight; the last two K tiles request less, so less may be left outstanding
-  // (TAIL 1 = tile nk - 2, TAIL 2 = tile nk - 1).  S12 / S34: whether phases 1-2 / 3-4 request a region (tile 0 does
-  // not: the prologue already did; the last tiles have nothing left to request) — compile-time, so the loop
-  // body is branch-free.
+    // One K tile = four phases.  Counted waits: in steady state the five newest region requests (10 DMA
+    // instructions of this wave) stay in flight; the last two K tiles request less, so less may be left
+    // outstanding (TAIL 1 = tile nks - 2, TAIL 2 = tile nks - 1).  S1 / S234: whether phase 1 / phases 2-4 request a
+    // region (tile 0's phase 1 does not: the prologue already did; the last tiles have nothing left to request) —
+    // compile-time, so the loop body is branch-free.  w0s = W0 ring slot of this K tile (kt % 3).
 #define P8_WAIT(a, b, c)                                                                       \
-  do {                                                                                         \
-    if constexpr (TAIL == 0) asm volatile("s_waitcnt vmcnt(" #a ")" ::: "memory");             \
-    else if constexpr (TAIL == 1) asm volatile("s_waitcnt vmcnt(" #b ")" ::: "memory");        \
-    else asm volatile("s_waitcnt vmcnt(" #c ")" ::: "memory");                                 \
-  } while (0)
-  auto ktile = [&](int kt, auto tail_c, auto s12_c, auto s34_c) {
-    constexpr int TAIL = decltype(tail_c)::value;
-    constexpr bool S12 = decltype(s12_c)::value, S34 = decltype(s34_c)::value;
-    const unsigned char* buf = smem_raw + (kt & 1) * P8_TILE;
-    // phase 1
-    read_a(buf + P8_A0);
-    read_w(buf + P8_W0, w0h, w0l);
-    if constexpr (S12) stage(kt + 1, P8_W1, vw1, wsp);
-    P8_WAIT(8, 8, 2);
-    P8_BARRIER();
-    quadrant(acc[0][0], acc[1][0], w0h, w0l);
-    P8_BARRIER();
-    // phase 2
-    read_w(buf + P8_W1, w1h, w1l);
-    if constexpr (S12) stage(kt + 1, P8_A1, va1, abase);
-    P8_WAIT(8, 8, 0);
-    P8_BARRIER();
-    quadrant(acc[0][1], acc[1][1], w1h, w1l);
-    P8_BARRIER();
-    // phase 3
-    read_a(buf + P8_A1);
-    if constexpr (S34) stage(kt + 2, P8_A0, va0, abase);
-    P8_WAIT(8, 6, 0);
-    P8_BARRIER();
-    quadrant(acc[2][1], acc[3][1], w1h, w1l);
-    P8_BARRIER();
-    // phase 4
-    if constexpr (S34) stage(kt + 2, P8_W0, vw0, wsp);
-    P8_WAIT(8, 4, 0);
-    P8_BARRIER();
-    quadrant(acc[2][0], acc[3][0], w0h, w0l);
-    P8_BARRIER();
-  };
+    do {                                                                                         \
+      if constexpr (TAIL == 0) asm volatile("s_waitcnt vmcnt(" #a ")" ::: "memory");             \
+      else if constexpr (TAIL == 1) asm volatile("s_waitcnt vmcnt(" #b ")" ::: "memory");        \
+      else asm volatile("s_waitcnt vmcnt(" #c ")" ::: "memory");                                 \
+    } while (0)
+    // accumulators a0 = i0 * TN + j0 and a1 of this lane <- parked block (64 bytes each), loads + wait in one statement
+    auto ldacc = [&](f32x16& c0, f32x16& c1, int a0, int a1) {
+      f32x4 q0, q1, q2, q3, q4, q5, q6, q7;
+      const unsigned char* p0 = park_src + a0 * 64;
+      const unsigned char* p1 = park_src + a1 * 64;
+      asm volatile("global_load_dwordx4 %0, %8, off\n\tglobal_load_dwordx4 %1, %8, off offset:16\n\t"
+                   "global_load_dwordx4 %2, %8, off offset:32\n\tglobal_load_dwordx4 %3, %8, off offset:48\n\t"
+                   "global_load_dwordx4 %4, %9, off\n\tglobal_load_dwordx4 %5, %9, off offset:16\n\t"
+                   "global_load_dwordx4 %6, %9, off offset:32\n\tglobal_load_dwordx4 %7, %9, off offset:48\n\t"
+                   "s_waitcnt vmcnt(0)"
+                   : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5), "=&v"(q6), "=&v"(q7)
+                   : "v"(p0), "v"(p1) : "memory");
+      c0 = __builtin_shufflevector(__builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7), __builtin_shufflevector(q2, q3, 0, 1, 2, 3, 4, 5, 6, 7),
+                                   0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+      c1 = __builtin_shufflevector(__builtin_shufflevector(q4, q5, 0, 1, 2, 3, 4, 5, 6, 7), __builtin_shufflevector(q6, q7, 0, 1, 2, 3, 4, 5, 6, 7),
+                                   0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    };
+    bool resume = PERSIST && is_tail;                              // first K tile of a tail piece: load accumulators per phase
+    int w0s = 0;
+    auto ktile = [&](int kt, auto tail_c, auto s1_c, auto s234_c) {
+      constexpr int TAIL = decltype(tail_c)::value;
+      constexpr bool S1 = decltype(s1_c)::value, S234 = decltype(s234_c)::value;
+      const int cur = (kt & 1) * P8_TILE, oth = P8_TILE - cur;
+      const unsigned char* buf = smem_raw + cur;
+      const unsigned char* w0 = smem_raw + P8_W0RING + w0s * P8_REGION;
+      const int w0_free = P8_W0RING + (w0s == 0 ? 2 : w0s - 1) * P8_REGION;   // slot (kt + 2) % 3: its K tile kt - 1 is done
+      // phase 1
+      read_a(buf + P8_A0);
+      read_w(w0);
+      if constexpr (S1) stage(kt + 1, oth + P8_A1, false, 1);
+      if (PERSIST && resume) ldacc(acc[0][0], acc[1][0], 0 * TN + 0, 1 * TN + 0);
+      P8_WAIT(10, 10, 2);
+      P8_KBARRIER();
+      quadrant(acc[0][0], acc[1][0]);
+      P8_KBARRIER();
+      // phase 2
+      read_w(buf + P8_W1);
+      if constexpr (S234) stage(kt + 2, w0_free, true, 0);
+      if (PERSIST && resume) ldacc(acc[0][1], acc[1][1], 0 * TN + 1, 1 * TN + 1);
+      P8_WAIT(10, 8, 0);
+      P8_KBARRIER();
+      quadrant(acc[0][1], acc[1][1]);
+      P8_KBARRIER();
+      // phase 3
+      read_a(buf + P8_A1);
+      if constexpr (S234) stage(kt + 2, cur + P8_A0, false, 0);
+      if (PERSIST && resume) ldacc(acc[2][1], acc[3][1], 2 * TN + 1, 3 * TN + 1);
+      P8_WAIT(10, 6, 0);
+      P8_KBARRIER();
+      quadrant(acc[2][1], acc[3][1]);
+      P8_KBARRIER();
+      // phase 4
+      read_w(w0);
+      if constexpr (S234) stage(kt + 2, cur + P8_W1, true, 1);
+      if (PERSIST && resume) ldacc(acc[2][0], acc[3][0], 2 * TN + 0, 3 * TN + 0);
+      P8_WAIT(10, 4, 0);
+      P8_KBARRIER();
+      quadrant(acc[2][0], acc[3][0]);
+      P8_KBARRIER();
+      w0s = w0s == 2 ? 0 : w0s + 1;
+      if (PERSIST && resume) {                                     // every parked value is in registers: release the slot
+        resume = false;
+        __syncthreads();
+        if (t == 0) __hip_atomic_store(ps.flag + (blockIdx.x - 8), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    };
 #undef P8_WAIT
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  using I2 = std::integral_constant<int, 2>;
-  if (nk >= 3) {
-    ktile(0, I0{}, std::false_type{}, std::true_type{});
-    for (int kt = 1; kt + 2 < nk; ++kt) ktile(kt, I0{}, std::true_type{}, std::true_type{});
-    ktile(nk - 2, I1{}, std::true_type{}, std::false_type{});
-    ktile(nk - 1, I2{}, std::false_type{}, std::false_type{});
-  } else {                                                       // nk == 2: everything came with the prologue
-    ktile(0, I1{}, std::false_type{}, std::false_type{});
-    ktile(1, I2{}, std::false_type{}, std::false_type{});
-  }
-  if (group == 0) P8_BARRIER();                                  // pairs with the extra barrier of group 1
-  P8_BARRIER();                                                  // every read of the operand tiles is over: LDS becomes epilogue patches
-
-  const EpiVec ev{vec_c, vec_res, vec_bias, unscale};
-  const int mw = m0 + group * 128, nw = n0 + wn * 64;
-  float* patch = reinterpret_cast<float*>(smem_raw) + wave * 32 * EPI_LDT;
-  static_assert(P8_LDS >= 8 * 32 * EPI_LDT * 4, "operand LDS must hold one patch per wave");
-  if (VAR & SVAR_CSPLIT) {
-    switch (p.act) {
-      case WD_ACT_RELU: EpiCsplitWalk<0, TM, TN, WD_ACT_RELU>::run(p, ev, mw, nw, lane, acc, patch); break;
-      case WD_ACT_SILU: EpiCsplitWalk<0, TM, TN, WD_ACT_SILU>::run(p, ev, mw, nw, lane, acc, patch); break;
-      case WD_ACT_GELU: EpiCsplitWalk<0, TM, TN, WD_ACT_GELU>::run(p, ev, mw, nw, lane, acc, patch); break;
-      default: EpiCsplitWalk<0, TM, TN, WD_ACT_NONE>::run(p, ev, mw, nw, lane, acc, patch); break;
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    if (nks >= 3) {
+      ktile(0, I0{}, std::false_type{}, std::true_type{});
+      for (int kt = 1; kt + 2 < nks; ++kt) ktile(kt, I0{}, std::true_type{}, std::true_type{});
+      ktile(nks - 2, I1{}, std::true_type{}, std::false_type{});
+      ktile(nks - 1, I2{}, std::false_type{}, std::false_type{});
+    } else if (nks == 2) {                                         // everything came with the prologue
+      ktile(0, I1{}, std::false_type{}, std::false_type{});
+      ktile(1, I2{}, std::false_type{}, std::false_type{});
+    } else {
+      ktile(0, I2{}, std::false_type{}, std::false_type{});
     }
-  } else {
-    switch (p.act) {
-      case WD_ACT_RELU: split_epilogue_lds<TM, TN, WD_ACT_RELU, false>(p, ev, mw, nw, lane, acc, patch); break;
-      case WD_ACT_SILU: split_epilogue_lds<TM, TN, WD_ACT_SILU, false>(p, ev, mw, nw, lane, acc, patch); break;
-      case WD_ACT_GELU: split_epilogue_lds<TM, TN, WD_ACT_GELU, false>(p, ev, mw, nw, lane, acc, patch); break;
-      default: split_epilogue_lds<TM, TN, WD_ACT_NONE, false>(p, ev, mw, nw, lane, acc, patch); break;
+    if (group == 0 && !(ABL & 24)) P8_BARRIER();                   // pairs with the extra barrier of group 1
+    P8_BARRIER();                                                  // every read of the operand tiles is over: LDS becomes epilogue patches
+
+    if (PERSIST && is_head) {
+      // park the raw accumulators for the next workgroup of the chain: plain coalesced stores, drained, then ONE
+      // agent-scope release and the flag (MI355X_MICROARCH.md, inter-workgroup visibility)
+      f32x4* lp = reinterpret_cast<f32x4*>(reinterpret_cast<unsigned char*>(ps.acc) + (size_t)blockIdx.x * P8_PARK_BYTES +
+                                           (unsigned)t * 512u);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            lp[(i * TN + j) * 4 + g] = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (t == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(ps.flag + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      continue;
+    }
+    if (ABL & 4) {                                                  // keep the accumulators live, store (almost) nothing
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
+      if (sum == 12345.678f) p.c[t] = sum;
+      continue;
+    }
+    const EpiVec ev{vec_c, vec_res, vec_bias, unscale};
+    const int mw = m0 + group * 128, nw = n0 + wn * 64;
+    float* patch = reinterpret_cast<float*>(smem_raw) + wave * 32 * EPI_LDT;
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));          // epilogue address arithmetic starts HERE (hipcc otherwise computes it before the K loop and keeps ~50 registers alive across it)
+    static_assert(P8_LDS >= 8 * 32 * EPI_LDT * 4, "operand LDS must hold one patch per wave");
+    if (VAR & SVAR_CSPLIT) {
+      switch (p.act) {
+        case WD_ACT_RELU: EpiCsplitWalk<0, TM, TN, WD_ACT_RELU>::run(p, ev, mw, nw, lane_e, acc, patch); break;
+        case WD_ACT_SILU: EpiCsplitWalk<0, TM, TN, WD_ACT_SILU>::run(p, ev, mw, nw, lane_e, acc, patch); break;
+        case WD_ACT_GELU: EpiCsplitWalk<0, TM, TN, WD_ACT_GELU>::run(p, ev, mw, nw, lane_e, acc, patch); break;
+        default: EpiCsplitWalk<0, TM, TN, WD_ACT_NONE>::run(p, ev, mw, nw, lane_e, acc, patch); break;
+      }
+    } else {
+      switch (p.act) {
+        case WD_ACT_RELU: split_epilogue_lds<TM, TN, WD_ACT_RELU, false>(p, ev, mw, nw, lane_e, acc, patch); break;
+        case WD_ACT_SILU: split_epilogue_lds<TM, TN, WD_ACT_SILU, false>(p, ev, mw, nw, lane_e, acc, patch); break;
+        case WD_ACT_GELU: split_epilogue_lds<TM, TN, WD_ACT_GELU, false>(p, ev, mw, nw, lane_e, acc, patch); break;
+        default: split_epilogue_lds<TM, TN, WD_ACT_NONE, false>(p, ev, mw, nw, lane_e, acc, patch); break;
+      }
     }
   }
 }
 
-template <int VAR>
-int launch_p8(const WdConvGemm& p, const void* wsp, float unscale, hipStream_t st) {
+constexpr long long P8_PARK_FLOATS = P8_PARK_BYTES / 4;
+
+int p8_workgroups() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+    n = prop.multiProcessorCount / 8 * 8;                          // one workgroup per CU, the same number on every XCD
+  }
+  return n;
+}
+
+template <int VAR, int ABL = 0, bool PERSIST = false>
+int launch_p8(const WdConvGemm& p, const void* wsp, float unscale, hipStream_t st, float* ws = nullptr, long long ws_floats = 0) {
   const int nbm = (p.m + 255) / 256, nbn = (p.n + 255) / 256;
   const long long nblk = (long long)nbm * nbn;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return WD_ERR_BAD_ARG;
@@ -272,26 +438,63 @@ int launch_p8(const WdConvGemm& p, const void* wsp, float unscale, hipStream_t s
   const int vec_bias = p.bias ? wd_aligned16(p.bias) : 0;
   int ngrp = 2;                                                   // column tiles walked in pairs: 512 weight rows live per group
   if (ngrp > nbn || nbn % ngrp) ngrp = nbn;
-  auto k = split_gemm_p8_kernel<VAR>;
+  P8Persist ps{nullptr, nullptr, nullptr, (int)nblk};
+  long long grid = nblk;
+  if (PERSIST) {
+    const int wgs = p8_workgroups();
+    if (wgs <= 0) return WD_ERR_LAUNCH;
+    if (nblk < wgs) return WD_ERR_UNSUPPORTED;                     // ranges shorter than a tile would chain serially
+    if (!ws || ws_floats < wd_p8_workspace_floats()) return WD_ERR_WORKSPACE;
+    ps.flag = reinterpret_cast<unsigned*>(ws);                     // first 4 KB: flags (zero between launches); [512, 516): zeros
+    ps.zero = ws + 512;
+    ps.acc = ws + 1024;
+    grid = wgs;
+  }
+  auto k = split_gemm_p8_kernel<VAR, ABL, PERSIST>;
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS) !=
         hipSuccess) return WD_ERR_LAUNCH;
     attr = true;
   }
-  WD_LAUNCH_GEMM(k, dim3((unsigned)nblk), dim3(512), P8_LDS, st, p, static_cast<const unsigned char*>(wsp), k16, unscale, nbn,
-                 vec_c, vec_res, vec_bias, ngrp, nbm);
+  WD_LAUNCH_GEMM(k, dim3((unsigned)grid), dim3(512), P8_LDS, st, p, static_cast<const unsigned char*>(wsp), k16, unscale, nbn,
+                 vec_c, vec_res, vec_bias, ngrp, nbm, ps);
   return wd_launch_status();
 }
 
 }  // namespace
 
+// workspace of the persistent form: 1024 flag words + one parked accumulator set per workgroup (fp32 elements)
+long long wd_p8_workspace_floats() {
+  const int wgs = p8_workgroups();
+  return wgs <= 0 ? 0 : 1024 + (long long)wgs * P8_PARK_FLOATS;
+}
+
 // cfg 64: plain 1x1 layer, both operands pre-split, K % 32 == 0.  csplit: output written as fp16 hi/lo groups.
-int wd_launch_p8(const WdConvGemm& p, const void* w, float unscale, bool csplit, hipStream_t st) {
-  if (p.k % 32 || p.k < 64 || p.lda % 8 || !wd_aligned16(p.a) || !wd_aligned16(w)) return WD_ERR_UNSUPPORTED;
+// persist (cfg 65): the work-unit form; ws = caller's workspace, zero-filled once before its first use.
+int wd_launch_p8(const WdConvGemm& p, const void* w, float unscale, bool csplit, hipStream_t st, int abl, bool persist,
+                 float* ws, long long ws_floats) {
+#ifdef WD_DEBUG_ABLATIONS
+  if (abl && !persist) {
+    if (csplit) return abl == 4 ? launch_p8<SVAR_CSPLIT, 4>(p, w, unscale, st) : WD_ERR_UNSUPPORTED;
+    switch (abl) {
+      case 1: return launch_p8<0, 1>(p, w, unscale, st);
+      case 2: return launch_p8<0, 2>(p, w, unscale, st);
+      case 3: return launch_p8<0, 3>(p, w, unscale, st);
+      case 4: return launch_p8<0, 4>(p, w, unscale, st);
+      case 7: return launch_p8<0, 7>(p, w, unscale, st);
+      case 15: return launch_p8<0, 15>(p, w, unscale, st);
+      case 16: return launch_p8<0, 16>(p, w, unscale, st);
+      default: return WD_ERR_UNSUPPORTED;
+    }
+  }
+#endif
+  if (abl) return WD_ERR_UNSUPPORTED;
+  if (p.k % 32 || p.k < 32 || p.lda % 8 || p.m % 8 || p.n % 8 || p.m < 8 || p.n < 8 || !wd_aligned16(p.a) || !wd_aligned16(w))
+    return WD_ERR_UNSUPPORTED;                                     // DMA row groups of 8 are clamped as a whole
   if (csplit) {
     if (p.res || p.n % 8 || p.ldc % 8 || (p.bias && !wd_aligned16(p.bias)) || !wd_aligned16(p.c)) return WD_ERR_BAD_ARG;
-    return launch_p8<SVAR_CSPLIT>(p, w, unscale, st);
+    return persist ? launch_p8<SVAR_CSPLIT, 0, true>(p, w, unscale, st, ws, ws_floats) : launch_p8<SVAR_CSPLIT>(p, w, unscale, st);
   }
-  return launch_p8<0>(p, w, unscale, st);
+  return persist ? launch_p8<0, 0, true>(p, w, unscale, st, ws, ws_floats) : launch_p8<0>(p, w, unscale, st);
 }

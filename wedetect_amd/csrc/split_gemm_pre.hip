@@ -523,16 +523,18 @@ bool glds_ok(const WdConvGemm& p, int bk) {
 }
 }  // namespace
 
-int wd_launch_p8(const WdConvGemm& p, const void* w, float unscale, bool csplit, hipStream_t st);   // split_gemm_p8.hip
+int wd_launch_p8(const WdConvGemm& p, const void* w, float unscale, bool csplit, hipStream_t st, int abl, bool persist, float* ws,
+                 long long ws_floats);   // split_gemm_p8.hip
 
 int wd_launch_presplit(const WdConvGemm& p, const void* w, float unscale, int cfg, int flags, hipStream_t st, int ksplits,
-                       float* ws) {
+                       float* ws, long long ws_floats) {
   const bool csplit = (flags & WD_SPLIT_C) != 0;
   if (!(flags & WD_SPLIT_A)) return WD_ERR_UNSUPPORTED;            // C-only split: not needed by any layer yet
   if (p.k % 8 || p.cin % 8 || p.lda % 8) return WD_ERR_BAD_ARG;
-  if (cfg == 64) {                       // 256 x 256 tiles, four phases per K tile of 32, counted DMA waits (split_gemm_p8.hip)
+  if (cfg == 64 || cfg == 65 || (cfg >= 640 && cfg < 672)) {   // 256 x 256 tiles, four phases per K tile of 32, counted DMA waits (split_gemm_p8.hip)
     if (!glds_ok(p, 32)) return WD_ERR_UNSUPPORTED;
-    return wd_launch_p8(p, w, unscale, csplit, st);
+    // 65: persistent work-unit form (needs the workspace); 640 + ablation mask: debug builds only
+    return wd_launch_p8(p, w, unscale, csplit, st, cfg >= 640 ? cfg - 640 : 0, cfg == 65, ws, ws_floats);
   }
   if (cfg == 63) {                       // direct-to-LDS, ping-pong wave groups, 256 x 128 tiles
     if (!glds_ok(p, 16)) return WD_ERR_UNSUPPORTED;

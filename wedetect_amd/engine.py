@@ -58,6 +58,11 @@ class ImageTower:
             split_k = os.environ.get("WEDETECT_SPLIT_K", "0") == "1"
         self.kws = (torch.empty(16 << 20, dtype=torch.float32, device=torch.device(device))
                     if precision == "fp16x3" and split_k else None)
+        # park workspace of the persistent 256 x 256 fp16x3 kernel (tiles cut between two CUs: split_gemm_p8.hip); its flag
+        # words must start zero and it is never lent to split-K launches
+        self.park = None
+        if precision == "fp16x3" and os.environ.get("WEDETECT_P8", "1") == "1" and L.p8_workspace_bytes() > 0:
+            self.park = torch.zeros(L.p8_workspace_bytes() // 4, dtype=torch.float32, device=torch.device(device))
         self.B, self.H, self.W = batch, height, width
         self.dev = torch.device(device)
         if height % 32 or width % 32:
@@ -140,8 +145,14 @@ class ImageTower:
             if ws is None:                      # first use: split once, keep resident
                 wt = self.P[w]
                 ws = self.Ws[w] = L.split_weights(wt.view(wt.shape[0], -1))
+        work = self.kws if ws is not None else None
+        if ws is not None and self.park is not None and (kw.get("split_flags", 0) & L.SPLIT_A):
+            plain = kw.get("kh", 1) == 1 and kw.get("kw", 1) == 1 and kw.get("stride", 1) == 1 and kw.get("pad", 0) == 0
+            if plain and L.gemm_config(self.B * kw["hin"] * kw["win"], kw["n"], kw["cin"], split=True, presplit=True,
+                                       park=True).endswith("/p8s"):
+                work = self.park
         L.conv_gemm(a, None if ws is not None else self.P[w], self.P[b] if b else None, c, batch=self.B,
-                    w_split=ws, workspace=self.kws if ws is not None else None, **kw)
+                    w_split=ws, workspace=work, **kw)
 
     def _conv(self, a, w, b, c, *, hin, win, cin, lda, n, ldc, k=1, stride=1, act=L.ACT_NONE, res=None, ldres=0,
               res_alpha=1.0, **kw):

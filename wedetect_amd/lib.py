@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libwedetect_hip.so")
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU = 0, 1, 2, 3
 OUT_ROWS, OUT_DECONV2X2 = 0, 1
 SPLIT_A, SPLIT_C = 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 EXPORTS = (
     "wd_abi_version", "wd_strerror", "wd_sizeof_conv_gemm", "wd_conv_gemm", "wd_conv_gemm_tuned", "wd_conv_gemm_config", "wd_stem_patchify", "wd_dwconv7",
@@ -27,7 +27,7 @@ EXPORTS = (
     "wd_topk_candidates", "wd_nms_gather", "wd_retrieval_max",
     "wd_split_weights_bytes", "wd_split_weights", "wd_conv_gemm_split", "wd_conv_gemm_split_ws", "wd_conv_gemm_split_config", "wd_layernorm_rows_split", "wd_letterbox_u8", "wd_retrieval_max_split", "wd_text_embed", "wd_attention_small", "wd_recall_scratch_floats", "wd_recall_match",
     "wd_max_sigmoid_attn", "wd_adaptive_maxpool_nhwc", "wd_cross_attention_small", "wd_time_next_gemm",
-    "wd_cv_resize_paste_u8", "wd_chw_to_hwc_u8",
+    "wd_cv_resize_paste_u8", "wd_chw_to_hwc_u8", "wd_p8_workspace_bytes",
 )
 
 
@@ -105,6 +105,8 @@ def _load():
     lib.wd_letterbox_u8.argtypes = [vp, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.wd_cv_resize_paste_u8.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.wd_chw_to_hwc_u8.argtypes = [vp, i32, vp, i32, i32, i32, vp]
+    lib.wd_p8_workspace_bytes.restype = i64
+    lib.wd_p8_workspace_bytes.argtypes = []
     lib.wd_conv_gemm_split_config.restype = C.c_char_p
     lib.wd_conv_gemm_split_config.argtypes = [i32, i32, i32, i32]
     if lib.wd_sizeof_conv_gemm() != C.sizeof(ConvGemm):
@@ -190,9 +192,15 @@ def split_weights(w: torch.Tensor):
     return out, 1.0 / scale
 
 
-def gemm_config(m: int, n: int, k: int, split: bool = False, conv: bool = False, presplit: bool = False) -> str:
+def p8_workspace_bytes() -> int:
+    """Bytes of the park workspace of the persistent 256 x 256 fp16x3 kernel (needs a device: CU count)."""
+    return int(LIB.wd_p8_workspace_bytes())
+
+
+def gemm_config(m: int, n: int, k: int, split: bool = False, conv: bool = False, presplit: bool = False,
+                park: bool = False) -> str:
     if split:
-        return LIB.wd_conv_gemm_split_config(m, n, k, 1 if conv else (2 if presplit else 0)).decode()
+        return LIB.wd_conv_gemm_split_config(m, n, k, 1 if conv else ((3 if park else 2) if presplit else 0)).decode()
     return LIB.wd_conv_gemm_config(m, n, k).decode()
 
 

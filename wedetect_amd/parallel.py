@@ -83,38 +83,54 @@ class RegionGatherer:
     ranks; overlapped it costs the step nothing.  The tower's output buffers may be overwritten
     as soon as ``submit`` returns (the staging copy is ordered before it on the same stream) — with or without a
     process group.  Every rank must submit the same B_local per step (pad the final short batch with count = 0
-    rows, or use ``gather_ragged`` for it)."""
+    rows, or use ``gather_ragged`` for it).
+
+    Per step TWO collectives: the embeddings block, and one int32 block [B_local, 2 R + 2] that carries everything
+    else the reference gathers (extract_embedding.py:1753-1756): per-region ``scales`` and ``bias`` (fp32 bit
+    patterns), the kept count and the image id — instead of four pickled object gathers."""
 
     def __init__(self, group=None):
         self.group = group
         self.slots = [None, None]
         self.turn = 0
-        self.pending = None               # (work handles, out_e, out_c)
+        self.pending = None               # (work handles, slot, has_extra)
 
-    def _slot(self, emb, cnt, world):
+    def _slot(self, emb, world):
         s = self.slots[self.turn]
+        b, r = emb.shape[0], emb.shape[1]
         if s is None or s["emb"].shape != emb.shape or s["emb"].dtype != emb.dtype or s["emb"].device != emb.device:
-            s = dict(emb=torch.empty_like(emb), cnt=torch.empty_like(cnt),
-                     out_e=torch.empty((world * emb.shape[0],) + tuple(emb.shape[1:]), dtype=emb.dtype, device=emb.device),
-                     out_c=torch.empty(world * cnt.shape[0], dtype=cnt.dtype, device=cnt.device))
+            s = dict(emb=torch.empty_like(emb), meta=torch.zeros(b, 2 * r + 2, dtype=torch.int32, device=emb.device),
+                     out_e=torch.empty((world * b,) + tuple(emb.shape[1:]), dtype=emb.dtype, device=emb.device),
+                     out_m=torch.empty(world * b, 2 * r + 2, dtype=torch.int32, device=emb.device))
             self.slots[self.turn] = s
         return s
 
-    def submit(self, embeddings: torch.Tensor, count: torch.Tensor) -> Optional[Dict[str, torch.Tensor]]:
-        """Starts the exchange of this step; returns the PREVIOUS step's gathered result (or None)."""
+    def submit(self, embeddings: torch.Tensor, count: torch.Tensor, scales: Optional[torch.Tensor] = None,
+               bias: Optional[torch.Tensor] = None, image_ids: Optional[torch.Tensor] = None) -> Optional[Dict[str, torch.Tensor]]:
+        """Starts the exchange of this step; returns the PREVIOUS step's gathered result (or None).  ``embeddings``
+        [B, R, D], ``count`` [B]; optional ``scales`` / ``bias`` [B, R] fp32 and ``image_ids`` [B] (< 2^31)."""
         prev = self.collect()
         single = not dist.is_available() or not dist.is_initialized()
         world = 1 if single else dist.get_world_size(self.group)
-        s = self._slot(embeddings, count, world)
+        s = self._slot(embeddings, world)
+        r = embeddings.shape[1]
         s["emb"].copy_(embeddings, non_blocking=True)
-        s["cnt"].copy_(count, non_blocking=True)
+        m = s["meta"]
+        if scales is not None:
+            m[:, :r].copy_(scales.contiguous().view(torch.int32), non_blocking=True)
+        if bias is not None:
+            m[:, r:2 * r].copy_(bias.contiguous().view(torch.int32), non_blocking=True)
+        m[:, 2 * r].copy_(count.to(torch.int32), non_blocking=True)
+        if image_ids is not None:
+            m[:, 2 * r + 1].copy_(image_ids.to(torch.int32), non_blocking=True)
+        extra = (scales is not None, bias is not None, image_ids is not None)
         if single:                                    # same contract without a process group: the caller's buffers
-            self.pending = (None, s["emb"], s["cnt"])  # are free again as soon as submit returns
+            self.pending = (None, dict(out_e=s["emb"], out_m=s["meta"]), extra)   # are free again as soon as submit returns
             self.turn ^= 1
             return prev
         h1 = dist.all_gather_into_tensor(s["out_e"], s["emb"], group=self.group, async_op=True)
-        h2 = dist.all_gather_into_tensor(s["out_c"], s["cnt"], group=self.group, async_op=True)
-        self.pending = ((h1, h2), s["out_e"], s["out_c"])
+        h2 = dist.all_gather_into_tensor(s["out_m"], s["meta"], group=self.group, async_op=True)
+        self.pending = ((h1, h2), s, extra)
         self.turn ^= 1
         return prev
 
@@ -123,12 +139,21 @@ class RegionGatherer:
         second ``submit`` after this call."""
         if self.pending is None:
             return None
-        handles, e, c = self.pending
+        handles, s, extra = self.pending
         self.pending = None
         if handles is not None:
             for h in handles:
                 h.wait()
-        return dict(embeddings=e, count=c)
+        e, m = s["out_e"], s["out_m"]
+        r = e.shape[1]
+        out = dict(embeddings=e, count=m[:, 2 * r])
+        if extra[0]:
+            out["scales"] = m[:, :r].view(torch.float32)
+        if extra[1]:
+            out["bias"] = m[:, r:2 * r].view(torch.float32)
+        if extra[2]:
+            out["image_ids"] = m[:, 2 * r + 1]
+        return out
 
 
 def gather_results(fields: Dict[str, torch.Tensor], group=None) -> Dict[str, torch.Tensor]:
