@@ -16,6 +16,9 @@ SHAPES = {
     "s2_pw2 204800x256x1024 res": dict(m=204800, n=256, k=1024, res=True),
     "s3_pw1 51200x2048x512 gelu": dict(m=51200, n=2048, k=512, gelu=True),
     "s3_pw2 51200x512x2048 res": dict(m=51200, n=512, k=2048, res=True),
+    "e3_pw1 csplit noact": dict(m=51200, n=2048, k=512, csplit=True),
+    "e3_pw1 fp32out gelu": dict(m=51200, n=2048, k=512, gelu=True, nosplit=True),
+    "e3_pw1 fp32out noact": dict(m=51200, n=2048, k=512),
     "s4_pw1 12800x4096x1024 gelu": dict(m=12800, n=4096, k=1024, gelu=True),
     "s4_pw2 12800x1024x4096 res": dict(m=12800, n=1024, k=4096, res=True),
 }
@@ -40,6 +43,7 @@ for name, sh in SHAPES.items():
     flags = L.SPLIT_A
     if sh.get("gelu"):
         kw.update(act=L.ACT_GELU)
+    if (sh.get("gelu") and not sh.get("nosplit")) or sh.get("csplit"):
         flags |= L.SPLIT_C
     c = torch.empty(m, n, device=dev)
     if sh.get("res"):

@@ -201,10 +201,12 @@ int launch_glds(const WdConvGemm& p, const void* wsp, float unscale, hipStream_t
     zero = static_cast<const float*>(zp);
   }
   // column-tile group of the raster order: 4 (measured: -3 % on the wide pwconv1 layers, whose 4 MB of
-  // weight panels otherwise compete with the activation panels for the 4 MB L2), or WD_GLDS_NGROUP
-  // (tuning hook); must divide nbn
-  static const int env_grp = [] { const char* e = getenv("WD_GLDS_NGROUP"); return e ? atoi(e) : 0; }();
-  int ngrp = env_grp > 0 ? env_grp : 4;
+  // weight panels otherwise compete with the activation panels for the 4 MB L2); must divide nbn
+  int ngrp = 4;
+#ifdef WD_DEBUG_ABLATIONS
+  static const int env_grp = [] { const char* e = getenv("WD_GLDS_NGROUP"); return e ? atoi(e) : 0; }();   // tuning hook, debug builds only
+  if (env_grp > 0) ngrp = env_grp;
+#endif
   if (ngrp > nbn || nbn % ngrp) ngrp = nbn;
   auto k = split_gemm_glds_kernel<BK, VAR>;
   static bool attr = false;
