@@ -293,6 +293,12 @@ int wd_stem_patchify(const uint8_t* img, float* out, int32_t batch, int32_t h, i
  * ---------------------------------------------------------------------------------- */
 int wd_dwconv7(const float* x, const float* w7, const float* bias, float* y,
                int32_t batch, int32_t h, int32_t w, int32_t c, void* stream);
+/* wd_dwconv7_ln — the same depthwise conv followed by LayerNorm over the channels of each pixel (eps, affine
+ * gamma / beta), one kernel: ConvNeXt Block's dwconv -> norm (mm_backbone.py:113-116).  c % 32 == 0.  split != 0:
+ * the normalised rows are written as fp16 hi/lo groups (as wd_layernorm_rows_split).  Results are bit-identical to
+ * wd_dwconv7 followed by wd_layernorm_rows(_split) in place. */
+int wd_dwconv7_ln(const float* x, const float* w7, const float* bias, float* y, const float* gamma, const float* beta,
+                  int32_t batch, int32_t h, int32_t w, int32_t c, float eps, int32_t split, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * wd_layernorm_rows — y[r,:] = (x[r,:]-mean)*rsqrt(var+eps)*gamma + beta over c channels,

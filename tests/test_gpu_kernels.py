@@ -422,3 +422,28 @@ def test_time_next_gemm_stamps_exactly_one_launch():
         run()                                              # cleared: ev[4], ev[5] keep their old stamps
         torch.cuda.synchronize()
         assert abs(ev[4].elapsed_time(ev[5])) < 1.0
+
+
+@pytest.mark.parametrize("b,h,w,c", [(2, 20, 20, 1024), (1, 40, 40, 512), (3, 17, 23, 96), (1, 8, 16, 32), (2, 33, 9, 192), (1, 5, 5, 1536)])
+@pytest.mark.parametrize("split", [False, True])
+def test_dwconv7_ln_fused_bit_identical_to_the_pair(b, h, w, c, split):
+    """wd_dwconv7_ln (one workgroup = an 8 x 16 pixel tile over ALL channels, rows normalised from L2 right after they
+    were written) == wd_dwconv7 followed by wd_layernorm_rows(_split) in place, bit for bit: ragged tiles, every LN
+    lane-group shape (NV 1..6), fp32 and fp16 hi/lo outputs."""
+    from wedetect_amd import lib as L
+    g = torch.Generator(device="cuda").manual_seed(c + h)
+    x = torch.randn(b * h * w, c, device="cuda", generator=g) * 2.0
+    w7 = torch.randn(49, c, device="cuda", generator=g) * 0.15
+    bias = torch.randn(c, device="cuda", generator=g) * 0.1
+    gam = torch.rand(c, device="cuda", generator=g) + 0.5
+    bet = torch.randn(c, device="cuda", generator=g) * 0.1
+    ref = torch.empty_like(x)
+    L.dwconv7(x, w7, bias, ref, b, h, w, c)
+    L.layernorm_rows(ref, ref, gam, bet, b * h * w, c, split=split)
+    for _ in range(2):
+        out = torch.full_like(x, 3.0)
+        L.dwconv7_ln(x, w7, bias, out, gam, bet, b, h, w, c, split=split)
+        torch.cuda.synchronize()
+        assert torch.equal(out.view(torch.int32), ref.view(torch.int32)), float((out - ref).abs().max())
+    with pytest.raises(L.WedetectHipError):
+        L.dwconv7_ln(x[:, :24].contiguous(), w7[:, :24].contiguous(), bias[:24], out[:, :24].contiguous(), gam[:24], bet[:24], b, h, w, 24)

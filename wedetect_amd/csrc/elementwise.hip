@@ -190,23 +190,19 @@ __global__ void __launch_bounds__(256) dwconv7_tiled_kernel(const float* __restr
 // ---------------------------------------------------------------------------------------
 // SPLIT: the output row is written as fp16 (hi, lo) groups — per 8 channels [8 x hi | 8 x lo] in
 // the 32 bytes the 8 floats would occupy — for a wd_conv_gemm_split(WD_SPLIT_A) consumer.
+// One row by a group of g lanes (gl = lane in the group); every lane of the group must call it (shuffles), row_ok
+// = false lanes contribute zeros and write nothing.  Shared by the stand-alone kernel and the depthwise-conv-fused
+// one: the same code, hence the same bits.
 template <int NV, bool SPLIT>
-__global__ void __launch_bounds__(256) layernorm_rows_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                             const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta, long long rows, int c,
-                                                             int ldx, int ldy, float eps, int g) {
-  const int t = threadIdx.x;
-  const int rows_per_block = 256 / g;
-  const long long row = (long long)blockIdx.x * rows_per_block + t / g;
-  const int gl = t % g;
-  const bool row_ok = row < rows;      // keep every lane alive for the shuffles
+__device__ __forceinline__ void ln_row(const float* __restrict__ xr, float* __restrict__ yr, const float* __restrict__ gamma,
+                                       const float* __restrict__ beta, int c, float eps, int g, int gl, bool row_ok) {
   const int nq = c >> 2;
   f32x4 v[NV];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int q = gl + i * g;
-    v[i] = (row_ok && q < nq) ? *reinterpret_cast<const f32x4*>(x + row * ldx + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    v[i] = (row_ok && q < nq) ? *reinterpret_cast<const f32x4*>(xr + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
   }
   s = wd_group_sum(s, g);
@@ -239,13 +235,123 @@ __global__ void __launch_bounds__(256) layernorm_rows_kernel(const float* __rest
         const h2 la = __builtin_convertvector(a - __builtin_convertvector(ha, f32x2), h2);
         const h2 lb = __builtin_convertvector(b - __builtin_convertvector(hb, f32x2), h2);
         // chunk q = channels 4q..4q+3: half (q & 1) of group q >> 1; hi at +0, lo at +16 bytes
-        unsigned char* gp = reinterpret_cast<unsigned char*>(y + row * ldy) + (size_t)(q >> 1) * 32 + (q & 1) * 8;
+        unsigned char* gp = reinterpret_cast<unsigned char*>(yr) + (size_t)(q >> 1) * 32 + (q & 1) * 8;
         *reinterpret_cast<u32x2*>(gp) = u32x2{__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)};
         *reinterpret_cast<u32x2*>(gp + 16) = u32x2{__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)};
       } else {
-        *reinterpret_cast<f32x4*>(y + row * ldy + q * 4) = o;
+        *reinterpret_cast<f32x4*>(yr + q * 4) = o;
       }
     }
+  }
+}
+
+template <int NV, bool SPLIT>
+__global__ void __launch_bounds__(256) layernorm_rows_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, long long rows, int c,
+                                                             int ldx, int ldy, float eps, int g) {
+  const int t = threadIdx.x;
+  const int rows_per_block = 256 / g;
+  const long long row = (long long)blockIdx.x * rows_per_block + t / g;
+  const bool row_ok = row < rows;      // keep every lane alive for the shuffles
+  const long long r = row_ok ? row : 0;
+  ln_row<NV, SPLIT>(x + r * ldx, y + r * ldy, gamma, beta, c, eps, g, t % g, row_ok);
+}
+
+// ---------------------------------------------------------------------------------------
+// depthwise 7x7 + LayerNorm in ONE kernel (ConvNeXt Block: dwconv -> permute -> norm, mm_backbone.py:113-116).
+// A workgroup owns an 8 x 16 pixel tile for ALL channels: it runs the LDS-tiled depthwise conv above over the
+// channel blocks of 32 (writing the pre-norm values to y), then normalises its own 128 rows — which it re-reads
+// from L2 where it has just put them — with the row code of the stand-alone LayerNorm (ln_row: identical bits),
+// writing fp32 or fp16 hi/lo rows in place.  HBM sees the input once and the normalised output once; the
+// stand-alone pair wrote the conv output, read it back and wrote it again.
+// ---------------------------------------------------------------------------------------
+template <int NV, bool SPLIT>
+__global__ void __launch_bounds__(256) dwconv7_ln_kernel(const float* __restrict__ x, const float* __restrict__ w7,
+                                                         const float* __restrict__ bias, float* __restrict__ y,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         int h, int w, int c, int tiles_h, int tiles_w, float eps, int g) {
+  __shared__ __attribute__((aligned(16))) float lds[DT_LDS_FLOATS];
+  float* tin = lds;
+  float* tw = lds + DT_IH * DT_IW * DT_CP;
+  const int t = threadIdx.x;
+  const int ncb = c / DT_CB;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_w; bid /= tiles_w;
+  const int ty = bid % tiles_h;
+  const long long b = bid / tiles_h;
+  const int h0 = ty * DT_TH, w0 = tx * DT_TW;
+  const int q = t & 7;                   // channel quad
+  const int wg = (t >> 3) & 3;           // 4-pixel strip inside the 16-wide tile
+  const int oy = t >> 5;                 // output row inside the tile
+  constexpr int NST = (DT_IH * DT_IW * 8 + 255) / 256;
+  for (int cb = 0; cb < ncb; ++cb) {
+    const int c0 = cb * DT_CB;
+    const float* xb = x + (b * h) * (long long)w * c + c0;
+    f32x4 stage[NST];
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const int e = t + i * 256;
+      const int pix = e >> 3;
+      const int py = pix / DT_IW, px = pix - py * DT_IW;
+      const int hi = h0 + py - 3, wi = w0 + px - 3;
+      const bool ok = e < DT_IH * DT_IW * 8 && (unsigned)hi < (unsigned)h && (unsigned)wi < (unsigned)w;
+      stage[i] = *reinterpret_cast<const f32x4*>(ok ? xb + ((long long)hi * w + wi) * c + (e & 7) * 4 : g_zero4e);
+    }
+    f32x4 wst[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = t + i * 256;
+      wst[i] = *reinterpret_cast<const f32x4*>(e < 49 * 8 ? w7 + (e >> 3) * c + c0 + (e & 7) * 4 : g_zero4e);
+    }
+    if (cb > 0) __syncthreads();                       // everyone is done reading the previous channel block's tile
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const int e = t + i * 256;
+      if (e < DT_IH * DT_IW * 8) *reinterpret_cast<f32x4*>(tin + (e >> 3) * DT_CP + (e & 7) * 4) = stage[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = t + i * 256;
+      if (e < 49 * 8) *reinterpret_cast<f32x4*>(tw + (e >> 3) * DT_CB + (e & 7) * 4) = wst[i];
+    }
+    __syncthreads();
+    f32x4 acc[4];
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c0 + q * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = bv;
+#pragma unroll 1
+    for (int kh = 0; kh < 7; ++kh) {
+      const float* row = tin + ((oy + kh) * DT_IW + wg * 4) * DT_CP + q * 4;
+      f32x4 in[10];
+#pragma unroll
+      for (int j = 0; j < 10; ++j) in[j] = *reinterpret_cast<const f32x4*>(row + j * DT_CP);
+#pragma unroll
+      for (int kw = 0; kw < 7; ++kw) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(tw + (kh * 7 + kw) * DT_CB + q * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += in[j + kw] * wv;
+      }
+    }
+    const int ho = h0 + oy;
+    if (ho < h) {
+      float* yr = y + ((b * h + ho) * (long long)w) * c + c0 + q * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int wo = w0 + wg * 4 + j;
+        if (wo < w) *reinterpret_cast<f32x4*>(yr + (long long)wo * c) = acc[j];
+      }
+    }
+  }
+  __syncthreads();                                     // the tile's pre-norm rows are in L2 (stores drained: vmcnt 0 at the barrier)
+  const int rpp = 256 / g;                             // rows per pass
+  const int gl = t % g, rl = t / g;
+  for (int r0 = 0; r0 < DT_TH * DT_TW; r0 += rpp) {
+    const int pix = r0 + rl;
+    const int ho = h0 + pix / DT_TW, wo = w0 + pix % DT_TW;
+    const bool ok = pix < DT_TH * DT_TW && ho < h && wo < w;
+    float* yr = y + ((b * h + (ok ? ho : h0)) * (long long)w + (ok ? wo : w0)) * c;
+    ln_row<NV, SPLIT>(yr, yr, gamma, beta, c, eps, g, gl, ok);
   }
 }
 
@@ -338,6 +444,37 @@ extern "C" int wd_dwconv7(const float* x, const float* w7, const float* bias, fl
   if (grid > 0x7fffffffLL) return WD_ERR_BAD_ARG;
   hipLaunchKernelGGL(dwconv7_kernel, dim3((unsigned)grid), dim3(256), 0, static_cast<hipStream_t>(stream), x, w7, bias,
                      y, h, w, c, nstrip, total);
+  return wd_launch_status();
+}
+
+// wd_dwconv7_ln: depthwise 7x7 + bias, then LayerNorm over the channels of every pixel, one kernel (c % 32 == 0).
+extern "C" int wd_dwconv7_ln(const float* x, const float* w7, const float* bias, float* y, const float* gamma,
+                             const float* beta, int32_t batch, int32_t h, int32_t w, int32_t c, float eps, int32_t split,
+                             void* stream) {
+  if (!x || !w7 || !bias || !y || !gamma || !beta || x == y) return WD_ERR_BAD_ARG;
+  if (batch <= 0 || h <= 0 || w <= 0 || c <= 0 || c % DT_CB || c > 2048) return WD_ERR_BAD_ARG;
+  if (!wd_aligned16(x) || !wd_aligned16(w7) || !wd_aligned16(bias) || !wd_aligned16(y) || !wd_aligned16(gamma) ||
+      !wd_aligned16(beta)) return WD_ERR_BAD_ARG;
+  const int th = (h + DT_TH - 1) / DT_TH, tw = (w + DT_TW - 1) / DT_TW;
+  const long long nblk = (long long)batch * th * tw;
+  if (nblk > 0x7fffffffLL) return WD_ERR_BAD_ARG;
+  const int nq = c / 4;
+  int g = 8;
+  while (g < 64 && g < nq) g <<= 1;
+  const int nv = (nq + g - 1) / g;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+#define WD_DWLN_CASE(NV)                                                                                               \
+  case NV:                                                                                                             \
+    if (split) hipLaunchKernelGGL((dwconv7_ln_kernel<NV, true>), dim3((unsigned)nblk), dim3(256), 0, st, x, w7, bias, y, \
+                                  gamma, beta, h, w, c, th, tw, eps, g);                                                \
+    else hipLaunchKernelGGL((dwconv7_ln_kernel<NV, false>), dim3((unsigned)nblk), dim3(256), 0, st, x, w7, bias, y,      \
+                            gamma, beta, h, w, c, th, tw, eps, g);                                                      \
+    break;
+  switch (nv) {
+    WD_DWLN_CASE(1) WD_DWLN_CASE(2) WD_DWLN_CASE(3) WD_DWLN_CASE(4) WD_DWLN_CASE(5) WD_DWLN_CASE(6) WD_DWLN_CASE(7) WD_DWLN_CASE(8)
+    default: return WD_ERR_UNSUPPORTED;
+  }
+#undef WD_DWLN_CASE
   return wd_launch_status();
 }
 

@@ -27,7 +27,7 @@ EXPORTS = (
     "wd_topk_candidates", "wd_nms_gather", "wd_retrieval_max",
     "wd_split_weights_bytes", "wd_split_weights", "wd_conv_gemm_split", "wd_conv_gemm_split_ws", "wd_conv_gemm_split_config", "wd_layernorm_rows_split", "wd_letterbox_u8", "wd_retrieval_max_split", "wd_text_embed", "wd_attention_small", "wd_recall_scratch_floats", "wd_recall_match",
     "wd_max_sigmoid_attn", "wd_adaptive_maxpool_nhwc", "wd_cross_attention_small", "wd_time_next_gemm",
-    "wd_cv_resize_paste_u8", "wd_chw_to_hwc_u8", "wd_p8_workspace_bytes",
+    "wd_cv_resize_paste_u8", "wd_chw_to_hwc_u8", "wd_p8_workspace_bytes", "wd_dwconv7_ln",
 )
 
 
@@ -105,6 +105,7 @@ def _load():
     lib.wd_letterbox_u8.argtypes = [vp, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.wd_cv_resize_paste_u8.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.wd_chw_to_hwc_u8.argtypes = [vp, i32, vp, i32, i32, i32, vp]
+    lib.wd_dwconv7_ln.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]
     lib.wd_p8_workspace_bytes.restype = i64
     lib.wd_p8_workspace_bytes.argtypes = []
     lib.wd_conv_gemm_split_config.restype = C.c_char_p
@@ -245,6 +246,12 @@ def chw_to_hwc_u8(src, dst) -> None:
     if not src.is_contiguous() or not dst.is_contiguous():
         raise WedetectHipError("chw_to_hwc_u8: contiguous tensors only")
     check(LIB.wd_chw_to_hwc_u8(_p(src), int(src.dtype == torch.float32), _p(dst), b, h, w, stream_ptr()), "wd_chw_to_hwc_u8")
+
+
+def dwconv7_ln(x, w7, bias, y, gamma, beta, batch, h, w, c, eps=1e-6, split=False) -> None:
+    """Depthwise 7x7 + LayerNorm fused (bit-identical to dwconv7 then layernorm_rows in place)."""
+    check(LIB.wd_dwconv7_ln(_p(x), _p(w7), _p(bias), _p(y), _p(gamma), _p(beta), batch, h, w, c, float(eps), int(bool(split)),
+                            stream_ptr()), "wd_dwconv7_ln")
 
 
 def l2norm_rows(x, y) -> None:
