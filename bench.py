@@ -388,6 +388,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     kept = int(res["count"].sum().item())
+    overflow = bool((res["count"] < 0).any().item())       # fp16x3 range guard (wd_topk_candidates reports -1)
 
     if rank == 0:
         summ = timer.summary()
@@ -427,7 +428,7 @@ def main():
                            "fp32 8.5e-6 / fp16x3 9.5e-6, scores 8.0e-7 / 9.2e-7 (tests/probe_split_precision.py); on device the "
                            "fp16x3 step is within 5e-5 (embeddings) / 1e-5 (scores) of the fp32 step at this size "
                            "(tests/test_gpu_precision.py); --precision fp32 runs native fp32 MFMA"} if split else {}),
-                       "kept_regions_last_step_rank0": kept,
+                       "kept_regions_last_step_rank0": kept, "fp16x3_range_guard_tripped": overflow,
                        "gemm_gflop_per_image": round(flops_img / 1e9, 2)},
             "roofline": {"kernel": dom_kernel, "bound": "mfma",
                          "achieved": round(dom["tflops"], 2), "peak": dom_peak, "unit": "TFLOP/s",

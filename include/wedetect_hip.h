@@ -340,6 +340,9 @@ int wd_dfl_decode(const float* dist, int32_t ld, float* boxes, int32_t batch, in
  * ---------------------------------------------------------------------------------- */
 int64_t wd_topk_workspace_bytes(int32_t batch, int64_t n_per_image, int32_t nms_pre);
 int32_t wd_topk_capacity(int32_t nms_pre);   /* power of two >= nms_pre */
+/* Non-finite guard: if an image's score row holds a NaN or an inf (what an fp16 overflow in an upstream fp16x3 layer
+ * turns into), out_count[image] = -1 and wd_nms_gather reports out_count = -1 for it: the host must not trust that
+ * image and re-run the step with fp32 kernels (wedetect_amd.engine.ImageTower does). */
 int wd_topk_candidates(const float* scores, int32_t batch, int64_t n_per_image, float thr,
                        int32_t nms_pre, int32_t* out_idx, float* out_score, int32_t* out_count,
                        void* workspace, int64_t workspace_bytes, void* stream);

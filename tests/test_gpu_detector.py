@@ -162,3 +162,45 @@ def test_retrieval_big_bank_properties():
         L.retrieval_max(e, t[sr.start:sr.stop].contiguous(), scale, bias, cnt, o, n_img, rows, len(sr), 768)
         parts.append(o)
     assert torch.equal(torch.cat(parts, dim=1), out), "class-sharded scoring must equal whole-bank scoring bit for bit"
+
+
+def test_fp16x3_range_guard_falls_back_to_fp32():
+    """a checkpoint whose GELU hidden activations exceed the fp16 range (one pwconv1 scaled by 1e5,
+    undone in the following pwconv2, so the network function is unchanged) turns into inf in the fp16 hi halves.  The
+    top-k kernel reports non-finite score rows (count -1), the tower switches to the fp32 MFMA kernels, re-runs, warns,
+    and the results equal a tower built in fp32 from the start; an unaffected checkpoint never trips the guard."""
+    from wedetect_amd import weights as W
+    from wedetect_amd.detector import DetDataSample, YOLOWorldDetector
+    sd = W.make_state_dict("nano")
+    hot = dict(sd)
+    k1, k2 = "backbone.image_model.model.stages.2.1.pwconv1", "backbone.image_model.model.stages.2.1.pwconv2.weight"
+    hot[k1 + ".weight"] = sd[k1 + ".weight"] * np.float32(3e5)
+    hot[k1 + ".bias"] = sd[k1 + ".bias"] * np.float32(3e5)
+    hot[k2] = sd[k2] / np.float32(3e5)                     # GELU is not homogeneous, but the scaled net is still a valid net
+    bank = torch.from_numpy(W.make_text_bank(20))
+    rgb = W.make_images(2, 128, 128, seed=5)
+    inputs = [torch.from_numpy(np.ascontiguousarray(im[..., ::-1].transpose(2, 0, 1))) for im in rgb]
+
+    def run(state, precision):
+        m = YOLOWorldDetector("nano", test_cfg=dict(max_per_img=50), max_classes=20, precision=precision)
+        m.load_state_dict({n: torch.from_numpy(v) for n, v in state.items()})
+        m.cuda().eval()
+        m.set_text_embeddings(bank)
+        out = m.test_step(dict(inputs=inputs, data_samples=[DetDataSample(), DetDataSample()]))
+        return m, out
+    import warnings
+    with warnings.catch_warnings(record=True) as wrec:
+        warnings.simplefilter("always")
+        m16, o16 = run(hot, "fp16x3")
+    assert any("fp16 range" in str(w.message) for w in wrec), "the fallback must be announced"
+    tower = m16._h.tower(2, 128, 128)
+    assert tower.precision == "fp32" and tower.overflowed and m16._h.precision == "fp32"
+    m32, o32 = run(hot, "fp32")
+    for a, b in zip(o16, o32):
+        assert len(a.pred_instances) == len(b.pred_instances) > 0
+        assert torch.equal(a.pred_instances.scores, b.pred_instances.scores) and torch.equal(a.pred_instances.labels, b.pred_instances.labels)
+        assert bool(torch.isfinite(a.pred_instances.bboxes).all())
+    with warnings.catch_warnings(record=True) as wrec:
+        warnings.simplefilter("always")
+        m_ok, _ = run(sd, "fp16x3")
+    assert not any("fp16 range" in str(w.message) for w in wrec) and m_ok._h.tower(2, 128, 128).precision == "fp16x3"

@@ -29,7 +29,9 @@ struct TopkState {                       // one per image, 64 bytes
   unsigned remaining;                    // still to take inside the selected bin
   unsigned count_gt;                     // elements with key > T (after pass 2)
   unsigned need_eq;                      // elements == T to take, lowest index first
-  unsigned pad[10];
+  unsigned nonfinite;                    // != 0: the score row holds NaN / inf (an upstream overflow: the fp16x3 GEMMs'
+                                         // operands must stay below 65504) -> the candidate count is reported as -1
+  unsigned pad[9];
 };
 
 __device__ __forceinline__ int bin_of(unsigned key, int pass) {
@@ -48,7 +50,7 @@ __global__ void __launch_bounds__(256) fill_u32_kernel(unsigned* __restrict__ p,
 // ---- level histogram ------------------------------------------------------------------
 template <int PASS>
 __global__ void __launch_bounds__(256) topk_hist_kernel(const float* __restrict__ scores, long long n, float thr,
-                                                        const TopkState* __restrict__ state,
+                                                        TopkState* __restrict__ state,
                                                         unsigned* __restrict__ hist) {
   __shared__ unsigned lh[HB];
   const int b = blockIdx.y;
@@ -64,6 +66,7 @@ __global__ void __launch_bounds__(256) topk_hist_kernel(const float* __restrict_
     if (i < n) {
       const float v = s[i];
       const unsigned key = __float_as_uint(v);
+      if (PASS == 0 && (key & 0x7F800000u) == 0x7F800000u) state[b].nonfinite = 1u;     // NaN or inf: sticky, benign race
       if (v > thr && in_prefix(key, prefix, PASS)) atomicAdd(&lh[bin_of(key, PASS)], 1u);
     }
   }
@@ -314,7 +317,7 @@ __global__ void __launch_bounds__(256) topk_unpack_kernel(const unsigned long lo
       out_score[(size_t)b * cap + i] = 0.f;
     }
   }
-  if (i == 0) out_count[b] = (int)want;
+  if (i == 0) out_count[b] = state[b].nonfinite ? -1 : (int)want;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -372,6 +375,10 @@ __global__ void __launch_bounds__(64) nms_kernel(const int* __restrict__ cand_id
   const float* mt = meta + (size_t)b * 8;
   const bool pre = mt[7] != 0.f;
   const int count = cand_count[b];
+  if (count < 0) {                         // non-finite scores upstream (wd_topk_candidates): nothing to trust in this image
+    if (lane == 0) out_count[b] = -1;
+    return;
+  }
   const int* ci = cand_idx + (size_t)b * cand_stride;
   const float* cs = cand_score + (size_t)b * cand_stride;
   const f32x4* bx = reinterpret_cast<const f32x4*>(boxes) + (size_t)b * n_anchor;

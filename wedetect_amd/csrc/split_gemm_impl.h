@@ -248,86 +248,12 @@ __device__ __forceinline__ void epi_lds_tile_csplit(const WdConvGemm& p, const E
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// C-split epilogue, compute-first form: bias + activation + fp16 hi/lo split run on the accumulators where they
-// lie (128 independent values per lane: the exact-erf GELU's dependent chains interleave freely), the two lane
-// halves then swap 8-byte pieces (v_permlane32_swap: lane L holds channels 8g + 0..3 of pixel L, lane L + 32
-// channels 8g + 4..7) so that lane L owns the 16-byte [hi x 8] chunk and lane L + 32 the [lo x 8] chunk of a group
-// — final bytes — and only then go through the wave's LDS patch to become full 128-byte row segments.  The form above
-// (transpose first, compute on 8 values after every patch read) kept the VALU work inside the LDS / store dependency
-// chain of each 32 x 32 tile: 35-40 % of the pwconv1 launches (profiles/r02_p8_ablations.txt).  Same arithmetic per
-// element, hence the same bits.
-template <int I, int J, int TM, int TN>
-__device__ __forceinline__ void epi_csplit_store_tile(const WdConvGemm& p, int mw, int nw, int lane,
-                                                      const f32x16 (&acc)[TM][TN], float* patch) {
-#pragma unroll
-  for (int g = 0; g < 4; ++g)
-    *reinterpret_cast<f32x4*>(patch + (lane & 31) * EPI_LDT + 8 * g + 4 * (lane >> 5)) =
-        f32x4{acc[I][J][4 * g], acc[I][J][4 * g + 1], acc[I][J][4 * g + 2], acc[I][J][4 * g + 3]};
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-  for (int ps = 0; ps < 2; ++ps) {
-    const int row = ps * 16 + (lane >> 2);
-    const int m = mw + I * 32 + row;
-    const int n = nw + J * 32 + 8 * (lane & 3);
-    const f32x4 v0 = *reinterpret_cast<const f32x4*>(patch + row * EPI_LDT + 8 * (lane & 3));
-    const f32x4 v1 = *reinterpret_cast<const f32x4*>(patch + row * EPI_LDT + 8 * (lane & 3) + 4);
-    if (m < p.m && n < p.n) {
-      unsigned char* cp = reinterpret_cast<unsigned char*>(p.c + (size_t)m * p.ldc) + (size_t)(n >> 3) * 32;
-      *reinterpret_cast<f32x4*>(cp) = v0;
-      *reinterpret_cast<f32x4*>(cp + 16) = v1;
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-template <int IJ, int TM, int TN>
-struct EpiCsplitStoreWalk {
-  static __device__ __forceinline__ void run(const WdConvGemm& p, int mw, int nw, int lane, const f32x16 (&acc)[TM][TN], float* patch) {
-    epi_csplit_store_tile<IJ / TN, IJ % TN, TM, TN>(p, mw, nw, lane, acc, patch);
-    EpiCsplitStoreWalk<IJ + 1, TM, TN>::run(p, mw, nw, lane, acc, patch);
-  }
-};
-template <int TM, int TN>
-struct EpiCsplitStoreWalk<TM * TN, TM, TN> {
-  static __device__ __forceinline__ void run(const WdConvGemm&, int, int, int, const f32x16 (&)[TM][TN], float*) {}
-};
-
-template <int TM, int TN, int ACT>
-__device__ __forceinline__ void split_epilogue_csplit_first(const WdConvGemm& p, const EpiVec& ev, int mw, int nw, int lane,
-                                                            f32x16 (&acc)[TM][TN], float* patch) {
-  // phase A: accumulators -> final fp16 hi / lo bytes, in place (the four floats 4g .. 4g+3 of a tile become one 16-byte chunk)
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int n = nw + j * 32 + 8 * g + 4 * (lane >> 5);
-      f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias && n < p.n) b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        f32x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = sact<ACT>(fmaf(acc[i][j][4 * g + r], ev.unscale, b4[r]));
-        u32x2 h, l;
-        split4(o, h, l);
-        const auto ra = __builtin_amdgcn_permlane32_swap(h[0], l[0], false, false);
-        const auto rb = __builtin_amdgcn_permlane32_swap(h[1], l[1], false, false);
-        acc[i][j][4 * g] = __builtin_bit_cast(float, (unsigned)ra[0]);
-        acc[i][j][4 * g + 1] = __builtin_bit_cast(float, (unsigned)rb[0]);
-        acc[i][j][4 * g + 2] = __builtin_bit_cast(float, (unsigned)ra[1]);
-        acc[i][j][4 * g + 3] = __builtin_bit_cast(float, (unsigned)rb[1]);
-      }
-      __builtin_amdgcn_sched_barrier(0);      // 16 values in flight at a time: more would spill beside 128 accumulators
-    }
-  }
-  // phase B: pure data movement, one 32 x 32 tile at a time through the wave's patch
-  EpiCsplitStoreWalk<0, TM, TN>::run(p, mw, nw, lane, acc, patch);
-}
-
+// Tried and dropped (round 2, profiles/r02_p8_ablations.txt): a compute-first form of this epilogue — bias + GELU +
+// fp16 split on the accumulators where they lie, 8-byte pieces swapped between the lane halves with
+// v_permlane32_swap so that every lane owns a final 16-byte [hi x 8] / [lo x 8] chunk, and only then the LDS
+// transpose — was 5-10 % SLOWER on the 51200 x 2048 x 512 pwconv1 launch (450-470 us against 404-426 us): beside 128
+// live accumulators the 16-value GELU batches spill, and the transposed form already overlaps its VALU work with the
+// stores of the previous 32 x 32 tile.
 template <int IJ, int TM, int TN, int ACT>
 struct EpiCsplitWalk {
   static __device__ __forceinline__ void run(const WdConvGemm& p, const EpiVec& ev, int mw, int nw, int lane,

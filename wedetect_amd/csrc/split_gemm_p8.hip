@@ -395,10 +395,10 @@ split_gemm_p8_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, 
     static_assert(P8_LDS >= 8 * 32 * EPI_LDT * 4, "operand LDS must hold one patch per wave");
     if (VAR & SVAR_CSPLIT) {
       switch (p.act) {
-        case WD_ACT_RELU: split_epilogue_csplit_first<TM, TN, WD_ACT_RELU>(p, ev, mw, nw, lane_e, acc, patch); break;
-        case WD_ACT_SILU: split_epilogue_csplit_first<TM, TN, WD_ACT_SILU>(p, ev, mw, nw, lane_e, acc, patch); break;
-        case WD_ACT_GELU: split_epilogue_csplit_first<TM, TN, WD_ACT_GELU>(p, ev, mw, nw, lane_e, acc, patch); break;
-        default: split_epilogue_csplit_first<TM, TN, WD_ACT_NONE>(p, ev, mw, nw, lane_e, acc, patch); break;
+        case WD_ACT_RELU: EpiCsplitWalk<0, TM, TN, WD_ACT_RELU>::run(p, ev, mw, nw, lane_e, acc, patch); break;
+        case WD_ACT_SILU: EpiCsplitWalk<0, TM, TN, WD_ACT_SILU>::run(p, ev, mw, nw, lane_e, acc, patch); break;
+        case WD_ACT_GELU: EpiCsplitWalk<0, TM, TN, WD_ACT_GELU>::run(p, ev, mw, nw, lane_e, acc, patch); break;
+        default: EpiCsplitWalk<0, TM, TN, WD_ACT_NONE>::run(p, ev, mw, nw, lane_e, acc, patch); break;
       }
     } else {
       switch (p.act) {

@@ -279,8 +279,11 @@ class SimpleYOLOWorldDetector(_DeviceModule):
             metas.append([dw, dh, 0.0, sc, sc, float(w), float(h), 0.0])
         tower = self._h.tower(len(imgs), self.img_size[0], self.img_size[1])
         meta = torch.tensor(metas, dtype=torch.float32, device=self._h.device)
-        res = tower.detect(x, tower.P["prompts"], meta, normalize_text=False, score_thr=0.0, with_embed=True)
-        counts = res["count"].tolist()                      # one D2H sync per batch
+        run = lambda: tower.detect(x, tower.P["prompts"], meta, normalize_text=False, score_thr=0.0, with_embed=True)
+        res = run()
+        counts = tower.checked_counts(res, run)             # one D2H sync per batch (+ the fp16x3 range guard)
+        if tower.overflowed:
+            self._h.precision = "fp32"                      # towers built later for other shapes start in fp32 too
         return res, counts, tower
 
 
@@ -651,9 +654,13 @@ class YOLOWorldDetector(_DeviceModule):
                 metas.append([px, py, 0.0, sx, sy, float(ori[1]), float(ori[0]), 1.0])
             tower = self._h.tower(len(idxs), hh, ww)
             meta = torch.tensor(metas, dtype=torch.float32, device=dev)
-            res = tower.detect(x, banks[idxs[0]].to(dev), meta, normalize_text=True, score_thr=self.test_cfg["score_thr"],
-                               iou_thr=self.test_cfg["nms"]["iou_threshold"], with_embed=False)
-            counts = res["count"].tolist()
+            bank = banks[idxs[0]].to(dev)
+            run = lambda: tower.detect(x, bank, meta, normalize_text=True, score_thr=self.test_cfg["score_thr"],
+                                       iou_thr=self.test_cfg["nms"]["iou_threshold"], with_embed=False)
+            res = run()
+            counts = tower.checked_counts(res, run)
+            if tower.overflowed:
+                self._h.precision = "fp32"
             for j, (i, n) in enumerate(zip(idxs, counts)):
                 inst = InstanceData(bboxes=res["bboxes"][j, :n].clone(), scores=res["scores"][j, :n].clone(),
                                     labels=res["labels"][j, :n].to(torch.int64))

@@ -64,6 +64,8 @@ class ImageTower:
         if precision == "fp16x3" and os.environ.get("WEDETECT_P8", "1") == "1" and L.p8_workspace_bytes() > 0:
             self.park = torch.zeros(L.p8_workspace_bytes() // 4, dtype=torch.float32, device=torch.device(device))
         self.B, self.H, self.W = batch, height, width
+        self.fuse_dwln = os.environ.get("WEDETECT_FUSE_DWLN", "1") == "1"
+        self.overflowed = False
         self.dev = torch.device(device)
         if height % 32 or width % 32:
             raise ValueError("input size must be a multiple of 32")
@@ -187,7 +189,7 @@ class ImageTower:
                            stride=2, pad=0, n=c, ldc=c, split_flags=fa)
             for j in range(a.depths[i]):
                 q = f"s{i}.{j}."
-                if c % 32 == 0:       # dwconv -> norm in one kernel (bit-identical to the pair; one HBM round trip less)
+                if c % 32 == 0 and self.fuse_dwln:   # dwconv -> norm in one kernel (bit-identical to the pair; one HBM round trip less)
                     L.dwconv7_ln(self.x[i], self.P[q + "dw_w"], self.P[q + "dw_b"], self.tmp, self.P[q + "ln_w"],
                                  self.P[q + "ln_b"], B, h, w, c, split=pre)
                 else:
@@ -353,6 +355,27 @@ class ImageTower:
         self.features(images_u8)
         scores = self.similarity(text, normalize=normalize_text)
         return self.postprocess(scores, score_thr, meta, iou_thr, with_embed)
+
+    def checked_counts(self, res: Dict[str, torch.Tensor], rerun) -> List[int]:
+        """Kept-row counts of a step on the host (the one D2H sync a caller needs anyway) with the fp16x3 range guard:
+        the fp16x3 GEMMs carry fp32 operands as fp16 (hi, lo) pairs, so an activation beyond 65504 becomes inf and ends
+        as NaN scores; the top-k kernel flags non-finite score rows by reporting the image's count as -1.  When that
+        happens this tower switches to the fp32 MFMA kernels — for good: a checkpoint that overflows once will again —
+        and ``rerun()`` (the caller's closure that repeats the step) is executed once more.  Raises if fp32 overflows too."""
+        counts = res["count"].tolist()
+        if min(counts, default=0) >= 0:
+            return counts
+        if self.precision == "fp32":
+            raise L.WedetectHipError("non-finite scores in fp32 mode: the checkpoint or the inputs produce inf / NaN")
+        import warnings
+        warnings.warn("wedetect_amd: an activation left the fp16 range (|x| >= 65504) in an fp16x3 layer; this tower now runs "
+                      "the fp32 MFMA kernels (ImageTower(precision='fp32') avoids the detour)")
+        self.precision = "fp32"
+        self.overflowed = True
+        counts = rerun()["count"].tolist()
+        if min(counts, default=0) < 0:
+            raise L.WedetectHipError("non-finite scores in fp32 mode: the checkpoint or the inputs produce inf / NaN")
+        return counts
 
 
 class GraphedDetect:
