@@ -16,7 +16,6 @@
  *     row stride ("ld", in floats) may exceed C so producers can write straight into a
  *     channel slice of a wider buffer (this is how the reference's torch.cat calls,
  *     yolo_world_pafpn.py:647,715,1127,1131, disappear).
- *   - all floating-point work is fp32 with fp32 accumulation (MFMA f32_16x16x4_f32).
  *   - index outputs are int32 (flat candidate index < 2^31: 33600 anchors x 1203 classes).
  */
 #ifndef WEDETECT_HIP_H
@@ -98,12 +97,14 @@ typedef struct WdConvGemm {
   int32_t c_batch_stride;      /* rows; 0 = plain row-major output                       */
   int32_t seg_rows, seg_end0, seg_end1;
   float seg_scale[3], seg_bias[3];
+  uint32_t* range_flag;        /* fp16x3 kernels only, may be NULL: *range_flag is set to 1 (sticky) when an accumulator
+                                * of this launch is inf / NaN, i.e. an operand left the fp16 range; never cleared here */
 } WdConvGemm;
 
 int wd_conv_gemm(const WdConvGemm* p, void* stream);
 
-/* Tuning hook: launch a specific experimental tile configuration (see conv_gemm.hip).
- * No argument validation beyond the config id; used by scripts/gemm_bench.py only. */
+/* Diagnostic: launch a specific tile configuration of the fp32 kernel (see conv_gemm.hip) for on-device A/B runs
+ * (scripts/gemm_bench.py).  Not used by the product path; wd_conv_gemm picks the production tile itself. */
 int wd_conv_gemm_tuned(const WdConvGemm* p, int32_t cfg, void* stream);
 
 /* ---- fp16x3 variant of wd_conv_gemm --------------------------------------------------------
@@ -112,7 +113,9 @@ int wd_conv_gemm_tuned(const WdConvGemm* p, int32_t cfg, void* stream);
  * fp32-equivalent accuracy (2^-22 relative per operand) at the fp16 matrix rate.  Replaces the
  * same reference sites as wd_conv_gemm (nn.Linear / nn.Conv2d in mm_backbone.py:112-125,
  * yolo_world_pafpn.py, yolo_world_head.py); the reference computes them in fp32.
- * Activations must be finite with |x| < 65504.  Weights are prepared once:
+ * Activations must be finite with |x| < 65504 (an fp16 hi half overflows to inf beyond): p->range_flag, when set,
+ * receives 1 if a launch produced non-finite accumulators, so the host can re-run with wd_conv_gemm (fp32).
+ * Weights are prepared once:
  *   wd_split_weights_bytes(n, k)  -> size of the split buffer (rows padded to 16 k)
  *   wd_split_weights(w, n, k, scale, out): out <- halves of w * scale, scale a power of two
  *     chosen by the caller so that max|w| * scale <= 2^14; pass w_unscale = 1 / scale below.

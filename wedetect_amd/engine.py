@@ -58,14 +58,20 @@ class ImageTower:
             split_k = os.environ.get("WEDETECT_SPLIT_K", "0") == "1"
         self.kws = (torch.empty(16 << 20, dtype=torch.float32, device=torch.device(device))
                     if precision == "fp16x3" and split_k else None)
-        # park workspace of the persistent 256 x 256 fp16x3 kernel (tiles cut between two CUs: split_gemm_p8.hip); its flag
-        # words must start zero and it is never lent to split-K launches
+        # 256 x 256 fp16x3 kernels for the big pre-split layers (split_gemm_p8.hip).  $WEDETECT_P8: "tile" (default) = one
+        # workgroup per output tile, picked by the library; "persist" = additionally offer the park workspace, which
+        # selects the persistent work-unit form where it applies (faster per launch in isolation — profiles/r02_p8_ab.txt —
+        # equal inside the step; its flag words must start zero and it is never lent to split-K launches); "0" = neither
+        # (the round-1 128 x 128 / ping-pong kernels, for A/B runs).
+        self.p8_mode = os.environ.get("WEDETECT_P8", "tile")
         self.park = None
-        if precision == "fp16x3" and os.environ.get("WEDETECT_P8", "1") == "1" and L.p8_workspace_bytes() > 0:
+        if precision == "fp16x3" and self.p8_mode == "persist" and L.p8_workspace_bytes() > 0:
             self.park = torch.zeros(L.p8_workspace_bytes() // 4, dtype=torch.float32, device=torch.device(device))
         self.B, self.H, self.W = batch, height, width
-        self.fuse_dwln = os.environ.get("WEDETECT_FUSE_DWLN", "1") == "1"
+        self.fuse_dwln = os.environ.get("WEDETECT_FUSE_DWLN", "0") == "1"      # measured slower at every stage (profiles/r02_dwln_ab.txt): opt-in
         self.overflowed = False
+        # sticky range flag of the fp16x3 GEMMs (WdConvGemm.range_flag): set by a launch whose accumulators are inf / NaN
+        self.range_flag = torch.zeros(1, dtype=torch.int32, device=torch.device(device))
         self.dev = torch.device(device)
         if height % 32 or width % 32:
             raise ValueError("input size must be a multiple of 32")
@@ -148,13 +154,16 @@ class ImageTower:
                 wt = self.P[w]
                 ws = self.Ws[w] = L.split_weights(wt.view(wt.shape[0], -1))
         work = self.kws if ws is not None else None
-        if ws is not None and self.park is not None and (kw.get("split_flags", 0) & L.SPLIT_A):
+        if ws is not None and (kw.get("split_flags", 0) & L.SPLIT_A):
             plain = kw.get("kh", 1) == 1 and kw.get("kw", 1) == 1 and kw.get("stride", 1) == 1 and kw.get("pad", 0) == 0
-            if plain and L.gemm_config(self.B * kw["hin"] * kw["win"], kw["n"], kw["cin"], split=True, presplit=True,
-                                       park=True).endswith("/p8s"):
+            m = self.B * kw["hin"] * kw["win"]
+            if plain and self.park is not None and L.gemm_config(m, kw["n"], kw["cin"], split=True, presplit=True,
+                                                                 park=True).endswith("/p8s"):
                 work = self.park
+            elif plain and self.p8_mode == "0" and kw["cin"] % 16 == 0:
+                kw = dict(kw, split_cfg=63 if m >= 131072 else 60)
         L.conv_gemm(a, None if ws is not None else self.P[w], self.P[b] if b else None, c, batch=self.B,
-                    w_split=ws, workspace=work, **kw)
+                    w_split=ws, workspace=work, range_flag=self.range_flag if ws is not None else None, **kw)
 
     def _conv(self, a, w, b, c, *, hin, win, cin, lda, n, ldc, k=1, stride=1, act=L.ACT_NONE, res=None, ldres=0,
               res_alpha=1.0, **kw):
@@ -358,13 +367,17 @@ class ImageTower:
 
     def checked_counts(self, res: Dict[str, torch.Tensor], rerun) -> List[int]:
         """Kept-row counts of a step on the host (the one D2H sync a caller needs anyway) with the fp16x3 range guard:
-        the fp16x3 GEMMs carry fp32 operands as fp16 (hi, lo) pairs, so an activation beyond 65504 becomes inf and ends
-        as NaN scores; the top-k kernel flags non-finite score rows by reporting the image's count as -1.  When that
-        happens this tower switches to the fp32 MFMA kernels — for good: a checkpoint that overflows once will again —
-        and ``rerun()`` (the caller's closure that repeats the step) is executed once more.  Raises if fp32 overflows too."""
+        the fp16x3 GEMMs carry fp32 operands as fp16 (hi, lo) pairs, so an activation beyond 65504 becomes inf.  Every
+        fp16x3 launch checks its accumulators in the epilogue and raises the tower's sticky ``range_flag`` on inf / NaN
+        (a later ReLU would otherwise turn the NaN into a plausible 0), and the top-k kernel reports non-finite score
+        rows as count -1.  When either happens this tower switches to the fp32 MFMA kernels — for good: a checkpoint
+        that overflows once will again — and ``rerun()`` (the caller's closure that repeats the step) is executed once
+        more.  Raises if fp32 produces non-finite scores too."""
         counts = res["count"].tolist()
-        if min(counts, default=0) >= 0:
+        tripped = self.precision == "fp16x3" and int(self.range_flag.item()) != 0
+        if min(counts, default=0) >= 0 and not tripped:
             return counts
+        self.range_flag.zero_()
         if self.precision == "fp32":
             raise L.WedetectHipError("non-finite scores in fp32 mode: the checkpoint or the inputs produce inf / NaN")
         import warnings

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libwedetect_hip.so")
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU = 0, 1, 2, 3
 OUT_ROWS, OUT_DECONV2X2 = 0, 1
 SPLIT_A, SPLIT_C = 1, 2
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 EXPORTS = (
     "wd_abi_version", "wd_strerror", "wd_sizeof_conv_gemm", "wd_conv_gemm", "wd_conv_gemm_tuned", "wd_conv_gemm_config", "wd_stem_patchify", "wd_dwconv7",
@@ -54,6 +54,7 @@ class ConvGemm(C.Structure):
         ("c_batch_stride", C.c_int32),
         ("seg_rows", C.c_int32), ("seg_end0", C.c_int32), ("seg_end1", C.c_int32),
         ("seg_scale", C.c_float * 3), ("seg_bias", C.c_float * 3),
+        ("range_flag", C.c_void_p),
     ]
 
 
@@ -145,7 +146,7 @@ def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
 def conv_gemm(a, w, bias, c, *, batch, hin, win, cin, lda, kh=1, kw=1, stride=1, pad=0, hout=None, wout=None,
               n, ldc, act=ACT_NONE, res=None, ldres=0, res_alpha=1.0, out_mode=OUT_ROWS,
               out_scale=1.0, out_bias=0.0, sigmoid=False, c_batch_stride=0, seg=None, tuned_cfg=None,
-              w_split=None, split_cfg=-1, split_flags=0, workspace=None, k_splits=0) -> None:
+              w_split=None, split_cfg=-1, split_flags=0, workspace=None, k_splits=0, range_flag=None) -> None:
     """``seg`` = (seg_rows, seg_end0, seg_end1, (s0, s1, s2), (b0, b1, b2)) or None.
     ``w_split`` = (split weight buffer, unscale) from :func:`split_weights` selects the fp16x3 kernel;
     ``split_flags`` = SPLIT_A / SPLIT_C: activations / output stored as fp16 hi/lo groups; ``workspace`` (a device
@@ -156,7 +157,7 @@ def conv_gemm(a, w, bias, c, *, batch, hin, win, cin, lda, kh=1, kw=1, stride=1,
                  lda=lda, kh=kh, kw=kw, stride=stride, pad=pad, hout=hout, wout=wout,
                  m=batch * hout * wout, n=n, k=kh * kw * cin, ldc=ldc, ldres=ldres, act=act, out_mode=out_mode,
                  res_alpha=res_alpha, out_scale=out_scale, out_bias=out_bias, sigmoid=int(bool(sigmoid)),
-                 c_batch_stride=c_batch_stride)
+                 c_batch_stride=c_batch_stride, range_flag=_p(range_flag))
     if seg is not None:
         p.seg_rows, p.seg_end0, p.seg_end1 = int(seg[0]), int(seg[1]), int(seg[2])
         p.seg_scale = (C.c_float * 3)(*[float(v) for v in seg[3]])
