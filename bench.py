@@ -63,19 +63,21 @@ KERNEL_SYMBOL = {
 
 
 def measured_traffic(tag):
-    """HBM bytes per launch from the committed PMC passes (profiles/r01_traffic.json for the fp32
-    build, profiles/r01_fp16x3_traffic.json for fp16x3: separate rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE runs of this same command, FETCH_SIZE doubled per MI355X_MICROARCH.md).  None when
-    no PMC record matches the kernel that ran."""
-    try:
-        name = "r01_fp16x3_traffic.json" if tag.startswith("fp16x3") else "r01_traffic.json"
-        rec = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
-        syms = KERNEL_SYMBOL[tag]
-        syms = [syms] if isinstance(syms, str) else syms
-        n = sum(rec[s]["launches"] for s in syms)
-        return round(sum(rec[s]["hbm_bytes_per_launch"] * rec[s]["launches"] for s in syms) / n)
-    except Exception:
+    """HBM bytes per launch from the committed PMC passes (profiles/r02_traffic.json for the current fp16x3 build,
+    profiles/r01_traffic.json for the fp32 build: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same
+    command, FETCH_SIZE doubled per MI355X_MICROARCH.md).  None when no PMC record matches the kernel that ran."""
+    syms = KERNEL_SYMBOL.get(tag)
+    if syms is None:
         return None
+    syms = [syms] if isinstance(syms, str) else syms
+    for name in (("r02_traffic.json", "r01_fp16x3_traffic.json") if tag.startswith("fp16x3") else ("r01_traffic.json",)):
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
+            n = sum(rec[s]["launches"] for s in syms)
+            return round(sum(rec[s]["hbm_bytes_per_launch"] * rec[s]["launches"] for s in syms) / n)
+        except Exception:
+            continue
+    return None
 HBM_PEAK_GBS = 8000.0
 
 

@@ -44,6 +44,10 @@ def test_matched_ious_bit_exact_vs_oracle_on_a_larger_set():
     got = matched_ious(gts, props, nums)
     ref = oe.matched_ious(gts, props, nums)
     assert got.shape == ref.shape and np.array_equal(got, ref)
+    # images are processed in chunks sized to a scratch budget: tiny budgets (one image per launch, a
+    # few images per launch) must give the same array
+    for budget in (1, 200_000, 1_000_000):
+        assert np.array_equal(matched_ious(gts, props, nums, scratch_budget=budget), ref), budget
 
 
 def test_retrieval_predictions_match_the_references_lines(tmp_path):

@@ -58,6 +58,13 @@ class ImageTower:
             split_k = os.environ.get("WEDETECT_SPLIT_K", "0") == "1"
         self.kws = (torch.empty(16 << 20, dtype=torch.float32, device=torch.device(device))
                     if precision == "fp16x3" and split_k else None)
+        # Batch-INVARIANT split-K (on by default, $WEDETECT_FIXED_SPLITK=0 turns it off): the 3x3 convs on maps of at most
+        # 20 x 20 pixels with K >= 2304 (BepC3 of the coarsest level, the level-2 head convs) always split K in two —
+        # decided by the layer alone, never by the batch, so results stay bit-identical across batch sizes.  Base B = 32:
+        # 96.6 -> 71.8 us (256 -> 256) and 175.6 -> 125.1 us (512 -> 256) per launch (profiles/r02_smallmap_ab.txt).
+        self.fixed_splitk = precision == "fp16x3" and os.environ.get("WEDETECT_FIXED_SPLITK", "1") == "1"
+        self.fws = (torch.empty(2 * batch * 400 * 256 + 64, dtype=torch.float32, device=torch.device(device))
+                    if self.fixed_splitk else None)
         # 256 x 256 fp16x3 kernels for the big pre-split layers (split_gemm_p8.hip).  $WEDETECT_P8: "tile" (default) = one
         # workgroup per output tile, picked by the library; "persist" = additionally offer the park workspace, which
         # selects the persistent work-unit form where it applies (faster per launch in isolation — profiles/r02_p8_ab.txt —
@@ -154,6 +161,10 @@ class ImageTower:
                 wt = self.P[w]
                 ws = self.Ws[w] = L.split_weights(wt.view(wt.shape[0], -1))
         work = self.kws if ws is not None else None
+        if (ws is not None and self.fixed_splitk and self.kws is None and kw.get("kh", 1) == 3 and kw.get("stride", 1) == 1
+                and kw["hin"] * kw["win"] <= 400 and 9 * kw["cin"] >= 2304 and kw["n"] % 4 == 0
+                and 2 * self.B * kw["hin"] * kw["win"] * kw["n"] <= self.fws.numel()):
+            work, kw = self.fws, dict(kw, k_splits=2)
         if ws is not None and (kw.get("split_flags", 0) & L.SPLIT_A):
             plain = kw.get("kh", 1) == 1 and kw.get("kw", 1) == 1 and kw.get("stride", 1) == 1 and kw.get("pad", 0) == 0
             m = self.B * kw["hin"] * kw["win"]

@@ -43,7 +43,7 @@ def set_recall_param(proposal_nums, iou_thrs):
 
 
 def matched_ious(gts: List[np.ndarray], proposals: List[np.ndarray], proposal_nums: np.ndarray,
-                 use_legacy_coordinate: bool = False, device="cuda") -> np.ndarray:
+                 use_legacy_coordinate: bool = False, device="cuda", scratch_budget: int = 64 << 20) -> np.ndarray:
     """[len(proposal_nums), total_gt] fp32: the ``_ious`` array of recall.py:70-92 before sorting."""
     n_img = len(gts)
     g_list = [np.zeros((0, 4), np.float32) if g is None else np.asarray(g, np.float32).reshape(-1, 4) for g in gts]
@@ -65,14 +65,32 @@ def matched_ious(gts: List[np.ndarray], proposals: List[np.ndarray], proposal_nu
     gt_d = cat(g_list).to(dev)
     pr_d = (cat(p_list) if int(p_off[-1]) else torch.zeros(1, 4)).to(dev)
     budgets = torch.from_numpy(proposal_nums.astype(np.int32)).to(dev)
-    per_block = int(L.LIB.wd_recall_scratch_floats(max_gt, min(max_p, int(proposal_nums.max()))))
-    scratch = torch.empty(max(per_block, 1) * n_img * nb, dtype=torch.float32, device=dev)
     out = torch.zeros(nb, total_gt, dtype=torch.float32, device=dev)
-    g_off_d, p_off_d = torch.from_numpy(g_off).to(dev), torch.from_numpy(p_off).to(dev)      # keep alive across the launch
-    L.check(L.LIB.wd_recall_match(gt_d.data_ptr(), g_off_d.data_ptr(), pr_d.data_ptr(),
-                                  p_off_d.data_ptr(), n_img, budgets.data_ptr(), nb,
-                                  scratch.data_ptr(), max(per_block, 1), out.data_ptr(), total_gt,
-                                  int(bool(use_legacy_coordinate)), L.stream_ptr()), "wd_recall_match")
+    # The kernel's scratch is (largest gt count x largest proposal count of the launch) per (image, budget) block.  Images
+    # are therefore processed in chunks: consecutive images are added while chunk-maximum x images x budgets stays under
+    # scratch_budget floats (COCO val in one piece would take 1.6 GB, LVIS-scale sets tens of GB).
+    cap_p = int(proposal_nums.max())
+    i0 = 0
+    while i0 < n_img:
+        i1, mg, mp = i0, 1, 1
+        while i1 < n_img:
+            mg2 = max(mg, g_list[i1].shape[0], 1)
+            mp2 = max(mp, min(p_list[i1].shape[0], cap_p), 1)
+            need = int(L.LIB.wd_recall_scratch_floats(mg2, mp2)) * (i1 + 1 - i0) * nb
+            if i1 > i0 and need > scratch_budget:
+                break
+            mg, mp, i1 = mg2, mp2, i1 + 1
+        per_block = max(int(L.LIB.wd_recall_scratch_floats(mg, mp)), 1)
+        n_c = i1 - i0
+        scratch = torch.empty(per_block * n_c * nb, dtype=torch.float32, device=dev)
+        g_loc = torch.from_numpy((g_off[i0:i1 + 1] - g_off[i0]).astype(np.int32)).to(dev)   # keep alive across the launch
+        p_loc = torch.from_numpy((p_off[i0:i1 + 1] - p_off[i0]).astype(np.int32)).to(dev)
+        if int(g_off[i1]) > int(g_off[i0]):
+            L.check(L.LIB.wd_recall_match(gt_d.data_ptr() + int(g_off[i0]) * 16, g_loc.data_ptr(),
+                                          pr_d.data_ptr() + int(p_off[i0]) * 16, p_loc.data_ptr(), n_c, budgets.data_ptr(), nb,
+                                          scratch.data_ptr(), per_block, out.data_ptr() + int(g_off[i0]) * 4, total_gt,
+                                          int(bool(use_legacy_coordinate)), L.stream_ptr()), "wd_recall_match")
+        i0 = i1
     return out.cpu().numpy()
 
 
