@@ -296,6 +296,98 @@ struct EpiLdsWalk<TM * TN, TM, TN, ACT, SPECIAL> {
                                              const f32x16 (&)[TM][TN], float*) {}
 };
 
+// Residual epilogue with the residual rows PREFETCHED (plain row-major fp32 output, no activation, vector-aligned C /
+// residual / bias, whole column tiles — the ConvNeXt pwconv2 case).  The walk above loads a tile's residual quads,
+// waits, adds, stores, and only then starts the next tile: with the output written in place over the residual the
+// loads of tile b + 1 sit behind the stores of tile b, eight dependent HBM round trips per wave, and the epilogue
+// of a 256 x 256 tile is latency-bound (a quarter of the pwconv2 launch).  Here the residual quads of the next D
+// accumulator tiles are already in flight while one is transposed and stored.  Same arithmetic, same order per
+// element as epi_quad: bit-identical output.
+template <int IJ, int TM, int TN>
+__device__ __forceinline__ void epi_res_load(const WdConvGemm& p, int mw, int nw, int lane, f32x4 (&rv)[4]) {
+  constexpr int I = IJ / TN, J = IJ % TN;
+  const int n = nw + J * 32 + 4 * (lane & 7);
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    int m = mw + I * 32 + ps * 8 + (lane >> 3);
+    m = m < p.m ? m : p.m - 1;                                   // rows past the end: any valid address, never stored
+    rv[ps] = *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldres + n);
+  }
+}
+
+template <int IJ, int TM, int TN, int D>
+struct EpiResWalk {
+  static __device__ __forceinline__ void run(const WdConvGemm& p, const EpiVec& ev, int mw, int nw, int lane,
+                                             const f32x16 (&acc)[TM][TN], float* patch, f32x4 (&rv)[D][4]) {
+    constexpr int I = IJ / TN, J = IJ % TN;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<f32x4*>(patch + (lane & 31) * EPI_LDT + 8 * g + 4 * (lane >> 5)) =
+          f32x4{acc[I][J][4 * g], acc[I][J][4 * g + 1], acc[I][J][4 * g + 2], acc[I][J][4 * g + 3]};
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    f32x4 v[4];
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps)
+      v[ps] = *reinterpret_cast<const f32x4*>(patch + (ps * 8 + (lane >> 3)) * EPI_LDT + 4 * (lane & 7));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int n = nw + J * 32 + 4 * (lane & 7);
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int m = mw + I * 32 + ps * 8 + (lane >> 3);
+      if (p.range_flag) {
+        const unsigned e = ((__float_as_uint(v[ps][0]) & 0x7F800000u) == 0x7F800000u) | ((__float_as_uint(v[ps][1]) & 0x7F800000u) == 0x7F800000u) |
+                           ((__float_as_uint(v[ps][2]) & 0x7F800000u) == 0x7F800000u) | ((__float_as_uint(v[ps][3]) & 0x7F800000u) == 0x7F800000u);
+        if (e) *p.range_flag = 1u;
+      }
+      float o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        o[r] = fmaf(v[ps][r], ev.unscale, b4[r]);
+        o[r] += p.res_alpha * rv[IJ % D][ps][r];
+      }
+      if (m < p.m) *reinterpret_cast<f32x4*>(p.c + (size_t)m * p.ldc + n) = f32x4{o[0], o[1], o[2], o[3]};
+    }
+    if constexpr (IJ + D < TM * TN) epi_res_load<IJ + D, TM, TN>(p, mw, nw, lane, rv[IJ % D]);
+    EpiResWalk<IJ + 1, TM, TN, D>::run(p, ev, mw, nw, lane, acc, patch, rv);
+  }
+};
+template <int TM, int TN, int D>
+struct EpiResWalk<TM * TN, TM, TN, D> {
+  static __device__ __forceinline__ void run(const WdConvGemm&, const EpiVec&, int, int, int, const f32x16 (&)[TM][TN],
+                                             float*, f32x4 (&)[D][4]) {}
+};
+template <int IJ, int TM, int TN, int D>
+struct EpiResPrime {
+  static __device__ __forceinline__ void run(const WdConvGemm& p, int mw, int nw, int lane, f32x4 (&rv)[D][4]) {
+    epi_res_load<IJ, TM, TN>(p, mw, nw, lane, rv[IJ]);
+    EpiResPrime<IJ + 1, TM, TN, D>::run(p, mw, nw, lane, rv);
+  }
+};
+template <int TM, int TN, int D>
+struct EpiResPrime<D, TM, TN, D> {
+  static __device__ __forceinline__ void run(const WdConvGemm&, int, int, int, f32x4 (&)[D][4]) {}
+};
+
+// the conditions under which the prefetching residual epilogue applies to a wave's tile (all wave-uniform)
+__device__ __forceinline__ bool epi_res_prefetch_ok(const WdConvGemm& p, const EpiVec& ev, int nw, int width) {
+  return p.res != nullptr && p.act == WD_ACT_NONE && ev.res && ev.c && (!p.bias || ev.bias) && nw + width <= p.n && (p.n & 3) == 0 &&
+         p.out_mode == WD_OUT_ROWS;
+}
+
+template <int TM, int TN, int D>
+__device__ __forceinline__ void split_epilogue_res_prefetch(const WdConvGemm& p, const EpiVec& ev, int mw, int nw, int lane,
+                                                            const f32x16 (&acc)[TM][TN], float* patch) {
+  f32x4 rv[D][4];
+  EpiResPrime<0, TM, TN, D>::run(p, mw, nw, lane, rv);
+  EpiResWalk<0, TM, TN, D>::run(p, ev, mw, nw, lane, acc, patch, rv);
+}
+
 template <int TM, int TN, int ACT, bool SPECIAL>
 __device__ __forceinline__ void split_epilogue_lds(const WdConvGemm& p, const EpiVec& ev, int mw, int nw, int lane,
                                                    const f32x16 (&acc)[TM][TN], float* patch) {

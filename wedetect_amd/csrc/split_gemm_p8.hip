@@ -36,6 +36,15 @@
 //   * LDS rows are unpadded 128 B with the 16-byte slot XOR-swizzled by (row / 2) & 7 — applied on the
 //     GLOBAL side of the DMA and on the ds_read address (LDS-DMA writes lane-linear); out-of-range
 //     rows are clamped to the last valid row (their outputs are never stored), so no zero page.
+//
+// Tried and dropped (round 2, profiles/r02_p8_sched.txt): the same four phases software-pipelined INSIDE the wave —
+// fragment registers used as two half sets (k16 step 0 / 1), the ds_reads of one step in flight behind the six MFMAs
+// of the other (inline-asm reads, hand-counted lgkmcnt), one barrier per phase placed between the 9th and 10th MFMA,
+// all eight waves in step (or the second row group's barrier three MFMAs later).  Bit-identical, no spills (208
+// registers), and 7-8 % SLOWER (stage-3 pwconv2 321-333 us against 298): with both waves of a SIMD in the same
+// position of the same stream, their read / DMA-issue bursts (an LDS-DMA instruction costs 60-185 issue cycles)
+// coincide instead of hiding behind the partner's MFMAs.  The staggered two-barrier form below keeps one wave of
+// every SIMD in its MFMA run while the other issues memory work, which is what the matrix pipe needs.
 #include "split_gemm_impl.h"
 
 long long wd_p8_workspace_floats();
@@ -210,6 +219,9 @@ split_gemm_p8_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, 
     P8_BARRIER();
     if (group == 1 && !(ABL & 24)) P8_BARRIER();                   // the second row group runs one barrier behind
 
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
     h8 xh[2][2] = {}, xl[2][2] = {}, wh[2] = {}, wl[2] = {};       // activation fragments [row block][k16 step]; weights [k16 step]
     auto read_a = [&](const unsigned char* region) {
       if (ABL & 2) {
@@ -335,10 +347,8 @@ split_gemm_p8_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, 
         if (t == 0) __hip_atomic_store(ps.flag + (blockIdx.x - 8), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     };
+
 #undef P8_WAIT
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>;
     if (nks >= 3) {
       ktile(0, I0{}, std::false_type{}, std::true_type{});
       for (int kt = 1; kt + 2 < nks; ++kt) ktile(kt, I0{}, std::true_type{}, std::true_type{});
@@ -400,6 +410,8 @@ split_gemm_p8_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, 
         case WD_ACT_GELU: EpiCsplitWalk<0, TM, TN, WD_ACT_GELU>::run(p, ev, mw, nw, lane_e, acc, patch); break;
         default: EpiCsplitWalk<0, TM, TN, WD_ACT_NONE>::run(p, ev, mw, nw, lane_e, acc, patch); break;
       }
+    } else if (epi_res_prefetch_ok(p, ev, nw, 64) && mw < p.m) {
+      split_epilogue_res_prefetch<TM, TN, 3>(p, ev, mw, nw, lane_e, acc, patch);
     } else {
       switch (p.act) {
         case WD_ACT_RELU: split_epilogue_lds<TM, TN, WD_ACT_RELU, false>(p, ev, mw, nw, lane_e, acc, patch); break;

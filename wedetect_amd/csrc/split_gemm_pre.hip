@@ -8,6 +8,8 @@
 #include <cstdlib>
 #include "split_gemm_impl.h"
 
+namespace { constexpr int EPI_RES_DEPTH = 2; }   // residual tiles in flight ahead of the one being stored (ping-pong kernel; the 128 x 128 kernel has registers for one)
+
 namespace {
 constexpr int VA = SVAR_XCD | SVAR_PIN | SVAR_LDSEPI | SVAR_ASPLIT;
 constexpr int VAC = VA | SVAR_CSPLIT;
@@ -173,6 +175,8 @@ split_gemm_glds_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp
       case WD_ACT_GELU: EpiCsplitWalk<0, TM, TN, WD_ACT_GELU>::run(p, ev, mw, nw, lane, acc, patch); break;
       default: EpiCsplitWalk<0, TM, TN, WD_ACT_NONE>::run(p, ev, mw, nw, lane, acc, patch); break;
     }
+  } else if (epi_res_prefetch_ok(p, ev, nw, TN * 32) && mw < p.m) {
+    split_epilogue_res_prefetch<TM, TN, 1>(p, ev, mw, nw, lane, acc, patch);
   } else {
     switch (p.act) {
       case WD_ACT_RELU: split_epilogue_lds<TM, TN, WD_ACT_RELU, false>(p, ev, mw, nw, lane, acc, patch); break;
@@ -478,6 +482,8 @@ split_gemm_pingpong_kernel(const WdConvGemm p, const unsigned char* __restrict__
       case WD_ACT_GELU: EpiCsplitWalk<0, TM, TN, WD_ACT_GELU>::run(p, ev, mw, nw, lane, acc, patch); break;
       default: EpiCsplitWalk<0, TM, TN, WD_ACT_NONE>::run(p, ev, mw, nw, lane, acc, patch); break;
     }
+  } else if (epi_res_prefetch_ok(p, ev, nw, TN * 32) && mw < p.m) {
+    split_epilogue_res_prefetch<TM, TN, EPI_RES_DEPTH>(p, ev, mw, nw, lane, acc, patch);
   } else {
     switch (p.act) {
       case WD_ACT_RELU: split_epilogue_lds<TM, TN, WD_ACT_RELU, false>(p, ev, mw, nw, lane, acc, patch); break;
@@ -528,11 +534,17 @@ bool glds_ok(const WdConvGemm& p, int bk) {
 int wd_launch_p8(const WdConvGemm& p, const void* w, float unscale, bool csplit, hipStream_t st, int abl, bool persist, float* ws,
                  long long ws_floats);   // split_gemm_p8.hip
 
+int wd_launch_p4(const WdConvGemm& p, const void* w, float unscale, bool csplit, hipStream_t st);   // split_gemm_p4.hip
+
 int wd_launch_presplit(const WdConvGemm& p, const void* w, float unscale, int cfg, int flags, hipStream_t st, int ksplits,
                        float* ws, long long ws_floats) {
   const bool csplit = (flags & WD_SPLIT_C) != 0;
   if (!(flags & WD_SPLIT_A)) return WD_ERR_UNSUPPORTED;            // C-only split: not needed by any layer yet
   if (p.k % 8 || p.cin % 8 || p.lda % 8) return WD_ERR_BAD_ARG;
+  if (cfg == 66) {                       // 128 x 256 tiles, four waves, two workgroups per CU (split_gemm_p4.hip)
+    if (!glds_ok(p, 16)) return WD_ERR_UNSUPPORTED;
+    return wd_launch_p4(p, w, unscale, csplit, st);
+  }
   if (cfg == 64 || cfg == 65 || (cfg >= 640 && cfg < 672)) {   // 256 x 256 tiles, four phases per K tile of 32, counted DMA waits (split_gemm_p8.hip)
     if (!glds_ok(p, 32)) return WD_ERR_UNSUPPORTED;
     // 65: persistent work-unit form (needs the workspace); 640 + ablation mask: debug builds only
