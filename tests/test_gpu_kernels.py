@@ -143,7 +143,8 @@ def test_stem_patchify(L):
     assert torch.equal(out.cpu(), ref), "patchify must be bit-exact (uint8 -> float, one division)"
 
 
-@pytest.mark.parametrize("c,h,w", [(32, 16, 16), (96, 9, 11), (128, 20, 20), (192, 5, 3), (512, 8, 8), (1536, 2, 2)])
+@pytest.mark.parametrize("c,h,w", [(32, 16, 16), (96, 9, 11), (128, 20, 20), (192, 5, 3), (512, 8, 8), (1536, 2, 2), (64, 64, 48), (32, 80, 37),
+                                   (128, 160, 160)])
 def test_dwconv7(L, c, h, w):
     b_ = 2
     x, wt, bias = rnd(23, b_, c, h, w), rnd(24, c, 1, 7, 7, scale=1 / 7), rnd(25, c)

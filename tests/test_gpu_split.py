@@ -326,6 +326,51 @@ def test_p8_kernel_bit_identical_to_the_128_tile_kernel(m, n, k, mode):
         assert torch.equal(c.view(torch.int32), outs[1].view(torch.int32))
 
 
+@pytest.mark.parametrize("m,n,k", [(272, 320, 16), (1008, 256, 32), (528, 512, 48), (2048, 768, 1024), (304, 48, 160), (144, 272, 64), (16, 16, 96),
+                                   (264, 320, 64)])
+@pytest.mark.parametrize("mode", ["gelu_csplit", "residual"])
+def test_p4_kernel_bit_identical_to_the_128_tile_kernel(m, n, k, mode):
+    """cfg 66 (128 x 256 tiles, four waves, two workgroups per CU, three-slot ring of k16 steps, one barrier per phase)
+    against cfg 60: partial row / column tiles (DMA row groups of 16 clamped as a whole), 1, 2, 3 (tail forms only), 4, 6,
+    10 and 64 K steps, both epilogues (the residual one prefetches).  Same per-accumulator MFMA order => same bits."""
+    from wedetect_amd import lib as L
+    x, g, b = _rand((m, k), 191, 2.0), _rand((k,), 192), _rand((k,), 193, 0.1)
+    w, bias = _rand((n, k), 194, k ** -0.5), _rand((n,), 195, 0.1)
+    ws = L.split_weights(w)
+    xs = torch.empty(m, k, device="cuda")
+    L.layernorm_rows(x, xs, g, b, m, k, split=True)
+    kw = dict(batch=1, hin=1, win=m, cin=k, lda=k, n=n, ldc=n)
+    if mode == "gelu_csplit":
+        kw.update(act=L.ACT_GELU)
+        flags = L.SPLIT_A | L.SPLIT_C
+    else:
+        kw.update(res=_rand((m, n), 196), ldres=n)
+        flags = L.SPLIT_A
+    outs = []
+    for cfg in (60, 66):
+        c = torch.full((m, n), 7.0, device="cuda")
+        if (m % 16 or n % 16) and cfg == 66:
+            with pytest.raises(L.WedetectHipError):
+                L.conv_gemm(xs, None, bias, c, w_split=ws, split_cfg=cfg, split_flags=flags, **kw)
+            return
+        L.conv_gemm(xs, None, bias, c, w_split=ws, split_cfg=cfg, split_flags=flags, **kw)
+        outs.append(c)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32)), f"max|d| {float((outs[0] - outs[1]).abs().max())}"
+    for _ in range(3):                                            # no race between runs
+        c = torch.full((m, n), 7.0, device="cuda")
+        L.conv_gemm(xs, None, bias, c, w_split=ws, split_cfg=66, split_flags=flags, **kw)
+        assert torch.equal(c.view(torch.int32), outs[1].view(torch.int32))
+    if mode == "residual":                                        # in place over the residual, as the engine runs pwconv2
+        c = kw["res"].clone()
+        kw2 = dict(kw, res=c)
+        L.conv_gemm(xs, None, bias, c, w_split=ws, split_cfg=66, split_flags=flags, **kw2)
+        assert torch.equal(c.view(torch.int32), outs[1].view(torch.int32))
+        c = kw["res"].clone()
+        L.conv_gemm(xs, None, bias, c, w_split=ws, split_cfg=64 if k % 32 == 0 and m % 8 == 0 and n % 8 == 0 else 60, split_flags=flags, **dict(kw, res=c))
+        assert torch.equal(c.view(torch.int32), outs[1].view(torch.int32))
+
+
 @pytest.mark.parametrize("m,n,k,mode", [(51200, 512, 2048, "residual"), (51200, 2048, 512, "gelu_csplit"), (65536 + 8, 256, 96, "residual"),
                                          (66000, 512, 32, "gelu_csplit"), (131064, 256, 64, "residual")])
 def test_p8_persistent_kernel_bit_identical_and_repeatable(m, n, k, mode):

@@ -185,6 +185,98 @@ __global__ void __launch_bounds__(256) dwconv7_tiled_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------
+// depthwise 7x7, LDS-tiled, 1 x 8 output strips (c % 32 == 0): one workgroup = TH x 16 output pixels x 32
+// channels, TH x 16 threads; a thread slides a 1 x 8 strip of one channel quad over the 7 kernel rows:
+// 14 + 7 ds_read_b128 per 56 fp32x4 FMAs (the 1 x 4 strips of the kernel above: 10 + 7 per 28 — that kernel is
+// LDS-bound).  Pixels are 128 B apart with NO padding; the tile's row pitch is 23 pixels (one dummy pixel per
+// row), which makes the reads of the lane layout q + 8 (strip + 2 row) conflict-free for ds_read_b128's 16-lane
+// groups.  Per output the same accumulation order as every other depthwise kernel here (bias, then taps kh-major):
+// identical bits.
+// ---------------------------------------------------------------------------------------
+constexpr int DS_IW = DT_TW + 6, DS_IWP = 23;
+
+template <int TH>
+__global__ void __launch_bounds__(TH * 16) dwconv7_strip_kernel(const float* __restrict__ x, const float* __restrict__ w7,
+                                                                const float* __restrict__ bias, float* __restrict__ y,
+                                                                int h, int w, int c, int tiles_h, int tiles_w) {
+  constexpr int NT = TH * 16, IH = TH + 6;
+  __shared__ __attribute__((aligned(16))) float lds[IH * DS_IWP * DT_CB + 49 * DT_CB];
+  float* tin = lds;
+  float* tw = lds + IH * DS_IWP * DT_CB;
+  const int t = threadIdx.x;
+  const int ncb = c / DT_CB;
+  int bid = blockIdx.x;
+  const int cb = bid % ncb; bid /= ncb;
+  const int tx = bid % tiles_w; bid /= tiles_w;
+  const int ty = bid % tiles_h;
+  const long long b = bid / tiles_h;
+  const int h0 = ty * TH, w0 = tx * DT_TW, c0 = cb * DT_CB;
+  const float* xb = x + (b * h) * (long long)w * c + c0;
+
+  // stage the halo tile (8 lanes = the 32 channels of one pixel); every global load before the first LDS store
+  constexpr int NST = (IH * DS_IW * 8 + NT - 1) / NT, NWS = (49 * 8 + NT - 1) / NT;
+  f32x4 stage[NST];
+#pragma unroll
+  for (int i = 0; i < NST; ++i) {
+    const int e = t + i * NT;
+    const int pix = e >> 3;
+    const int py = pix / DS_IW, px = pix - py * DS_IW;
+    const int hi = h0 + py - 3, wi = w0 + px - 3;
+    const bool ok = e < IH * DS_IW * 8 && (unsigned)hi < (unsigned)h && (unsigned)wi < (unsigned)w;
+    stage[i] = *reinterpret_cast<const f32x4*>(ok ? xb + ((long long)hi * w + wi) * c + (e & 7) * 4 : g_zero4e);
+  }
+  f32x4 wst[NWS];
+#pragma unroll
+  for (int i = 0; i < NWS; ++i) {
+    const int e = t + i * NT;
+    wst[i] = *reinterpret_cast<const f32x4*>(e < 49 * 8 ? w7 + (e >> 3) * c + c0 + (e & 7) * 4 : g_zero4e);
+  }
+#pragma unroll
+  for (int i = 0; i < NST; ++i) {
+    const int e = t + i * NT;
+    const int pix = e >> 3;
+    const int py = pix / DS_IW, px = pix - py * DS_IW;
+    if (e < IH * DS_IW * 8) *reinterpret_cast<f32x4*>(tin + (py * DS_IWP + px) * DT_CB + (e & 7) * 4) = stage[i];
+  }
+#pragma unroll
+  for (int i = 0; i < NWS; ++i) {
+    const int e = t + i * NT;
+    if (e < 49 * 8) *reinterpret_cast<f32x4*>(tw + (e >> 3) * DT_CB + (e & 7) * 4) = wst[i];
+  }
+  __syncthreads();
+
+  const int q = t & 7;                   // channel quad
+  const int strip = (t >> 3) & 1;        // 8-pixel strip inside the 16-wide tile
+  const int oy = t >> 4;                 // output row inside the tile
+  f32x4 acc[8];
+  const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c0 + q * 4);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = bv;
+#pragma unroll 1
+  for (int kh = 0; kh < 7; ++kh) {
+    const float* row = tin + ((oy + kh) * DS_IWP + strip * 8) * DT_CB + q * 4;
+    f32x4 in[14];
+#pragma unroll
+    for (int j = 0; j < 14; ++j) in[j] = *reinterpret_cast<const f32x4*>(row + j * DT_CB);
+#pragma unroll
+    for (int kw = 0; kw < 7; ++kw) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(tw + (kh * 7 + kw) * DT_CB + q * 4);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += in[j + kw] * wv;
+    }
+  }
+  const int ho = h0 + oy;
+  if (ho < h) {
+    float* yr = y + ((b * h + ho) * (long long)w) * c + c0 + q * 4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int wo = w0 + strip * 8 + j;
+      if (wo < w) *reinterpret_cast<f32x4*>(yr + (long long)wo * c) = acc[j];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // LayerNorm over the channel axis of each row.  A group of G lanes (power of two, 8..64)
 // owns one row; each lane holds NV float4.  Two-pass (mean, then centred variance), fp32.
 // ---------------------------------------------------------------------------------------
@@ -430,6 +522,15 @@ extern "C" int wd_dwconv7(const float* x, const float* w7, const float* bias, fl
   if (!x || !w7 || !bias || !y || x == y) return WD_ERR_BAD_ARG;
   if (batch <= 0 || h <= 0 || w <= 0 || c <= 0 || (c & 3)) return WD_ERR_BAD_ARG;
   if (!wd_aligned16(x) || !wd_aligned16(w7) || !wd_aligned16(bias) || !wd_aligned16(y)) return WD_ERR_BAD_ARG;
+  if (c % DT_CB == 0 && h % 16 == 0 && h >= 64) {   // tall tiles only where they tile the map exactly: the 8-row form of this kernel (128 threads) lost to the 1 x 4 kernel on the 40 x 40 and 20 x 20 maps (76 vs 68 us, 58 vs 52 us)
+    // 16 x 16 tiles of 1 x 8 strips: 160 x 160 map 264 -> 222-240 us, 80 x 80 128 -> 110 us (profiles/r02_dwconv_ab.txt)
+    const int th = h / 16, tw = (w + DT_TW - 1) / DT_TW;
+    const long long nblk = (long long)batch * th * tw * (c / DT_CB);
+    if (nblk > 0x7fffffffLL) return WD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(dwconv7_strip_kernel<16>, dim3((unsigned)nblk), dim3(256), 0, static_cast<hipStream_t>(stream), x, w7,
+                       bias, y, h, w, c, th, tw);
+    return wd_launch_status();
+  }
   if (c % DT_CB == 0) {
     const int th = (h + DT_TH - 1) / DT_TH, tw = (w + DT_TW - 1) / DT_TW;
     const long long nblk = (long long)batch * th * tw * (c / DT_CB);

@@ -24,6 +24,13 @@
 //     to three phases back: vmcnt(9) in steady state, never 0) and that this phase's reads are complete.
 //   * per-accumulator MFMA order: k ascending, lo.hi -> hi.lo -> hi.hi inside a k16 step — the order of every
 //     other fp16x3 kernel: bit-identical results.
+//
+// Measured (profiles/r02_p4_ab.txt, us per launch, this kernel / the 256 x 256 kernel): stage-3 pwconv1 387 / 420,
+// stage-4 pwconv1 333 / 352, stage-2 pwconv1 521 / 540 (ping-pong 550), stage-3 pwconv2 338 / 299.  One workgroup per
+// CU alone runs 487 us on the stage-3 pwconv1 shape, two run 392: the second workgroup buys 1.24 x, not 2 x — the
+// store stream of one workgroup's epilogue and the LDS-DMA stream of the other's K loop share the CU's vector-memory
+// path.  In the step the C-split layers on this kernel are worth 0.4 % (44.95 vs 45.14 ms), so it is NOT the
+// production choice: explicit configuration 66 only (scripts/p8_bench.py, tests).
 #include "split_gemm_impl.h"
 
 namespace {
