@@ -103,9 +103,7 @@ __device__ __forceinline__ void epi_quad(const WdConvGemm& p, const EpiRow& er, 
                                          const f32x4 v) {
   if (n >= p.n) return;
   if (p.range_flag) {          // an fp16 operand half that overflowed to inf shows up as an inf / NaN accumulator
-    const unsigned e = ((__float_as_uint(v[0]) & 0x7F800000u) == 0x7F800000u) | ((__float_as_uint(v[1]) & 0x7F800000u) == 0x7F800000u) |
-                       ((__float_as_uint(v[2]) & 0x7F800000u) == 0x7F800000u) | ((__float_as_uint(v[3]) & 0x7F800000u) == 0x7F800000u);
-    if (e) *p.range_flag = 1u;
+    if (wd_any_nonfinite4(v[0], v[1], v[2], v[3])) *p.range_flag = 1u;
   }
   const bool full = n + 3 < p.n;
   f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
@@ -230,11 +228,7 @@ __device__ __forceinline__ void epi_lds_tile_csplit(const WdConvGemm& p, const E
     const f32x4 v1 = *reinterpret_cast<const f32x4*>(patch + row * EPI_LDT + 8 * (lane & 3) + 4);
     if (m < p.m && n < p.n) {
       if (p.range_flag) {
-        unsigned e = 0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          e |= ((__float_as_uint(v0[r]) & 0x7F800000u) == 0x7F800000u) | ((__float_as_uint(v1[r]) & 0x7F800000u) == 0x7F800000u);
-        if (e) *p.range_flag = 1u;
+        if (wd_any_nonfinite4(v0[0], v0[1], v0[2], v0[3]) | wd_any_nonfinite4(v1[0], v1[1], v1[2], v1[3])) *p.range_flag = 1u;
       }
       f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
       if (p.bias) {
@@ -341,9 +335,7 @@ struct EpiResWalk {
     for (int ps = 0; ps < 4; ++ps) {
       const int m = mw + I * 32 + ps * 8 + (lane >> 3);
       if (p.range_flag) {
-        const unsigned e = ((__float_as_uint(v[ps][0]) & 0x7F800000u) == 0x7F800000u) | ((__float_as_uint(v[ps][1]) & 0x7F800000u) == 0x7F800000u) |
-                           ((__float_as_uint(v[ps][2]) & 0x7F800000u) == 0x7F800000u) | ((__float_as_uint(v[ps][3]) & 0x7F800000u) == 0x7F800000u);
-        if (e) *p.range_flag = 1u;
+        if (wd_any_nonfinite4(v[ps][0], v[ps][1], v[ps][2], v[ps][3])) *p.range_flag = 1u;
       }
       float o[4];
 #pragma unroll
