@@ -57,6 +57,7 @@ KERNEL_SYMBOL = {
     # one bench tag, two instantiations: pwconv1 (output written as fp16 hi/lo groups) and pwconv2
     "fp16x3 128x128x16/4w/glds/plain": ["split_gemm_glds_kernel<16, 2048>", "split_gemm_glds_kernel<16, 0>"],
     "fp16x3 256x128x16/8w/pingpong/plain": ["split_gemm_pingpong_kernel<2048, 3, 2>", "split_gemm_pingpong_kernel<0, 3, 2>"],
+    "fp16x3 128x256x16/4w/p4/plain": ["split_gemm_p4_kernel<2048>", "split_gemm_p4_kernel<0>"],
     "fp16x3 256x256x32/8w/p8s/plain": ["split_gemm_p8_kernel<2048, 0, true>", "split_gemm_p8_kernel<0, 0, true>"],
     "fp16x3 256x256x32/8w/p8/plain": ["split_gemm_p8_kernel<2048, 0, false>", "split_gemm_p8_kernel<0, 0, false>"],
 }
@@ -403,7 +404,7 @@ def main():
         # fp16x3 issues three fp16 MFMA passes per fp32-accurate product: the roof for ALGORITHMIC
         # flops is the fp16 dense peak / 3; the fraction of the raw fp16 peak is reported beside it.
         dom_peak = round(F16_MFMA_PEAK_TFLOPS / SPLIT_PASSES, 1) if dom_split else F32_MFMA_PEAK_TFLOPS
-        dom_fn = ("split_gemm_p8" if "/p8" in dom_tag else "split_gemm_glds" if "glds" in dom_tag
+        dom_fn = ("split_gemm_p8" if "/p8" in dom_tag else "split_gemm_p4" if "/p4" in dom_tag else "split_gemm_glds" if "glds" in dom_tag
                   else "split_gemm_pingpong" if "pingpong" in dom_tag else "split_gemm")
         dom_kernel = (f"{dom_fn}_kernel<{dom_tag}> (3 x v_mfma_f32_32x32x16_f16 per product)" if dom_split
                       else f"conv_gemm_kernel<{dom_tag}> (fp32 MFMA 16x16x4)")

@@ -111,17 +111,21 @@ extern "C" int64_t wd_p8_workspace_bytes(void) { return 4 * wd_p8_workspace_floa
 //   stage 3 pwconv2 51200 x 512 x 2048   405 / 393 / 344 / 333      stage 4 pwconv1 12800 x 4096 x 1024  372 / 375 / 349 / 317
 //   stage 3 pwconv1 51200 x 2048 x 512   406 / 443 / 406 / 402      stage 4 pwconv2 12800 x 1024 x 4096  414 / 351 / 294 /  -
 //   stage 2 pwconv2 204800 x 256 x 1024  434 / 436 / 442 / 398      stage 2 pwconv1 204800 x 1024 x 256  527 / 567 / 539 / 544
-//   65  256 x 256 x 32 persistent (split_gemm_p8.hip): whole column tiles, K >= 512, at least one tile per CU
-//   64  the same tile, one workgroup per tile: whole column tiles, K >= 512, at least 128 tiles
-//   63  256 x 128 x 16 ping-pong: very long m (stages 1-2)
+// (after the round-2 epilogue work, profiles/r02_p8_ab.txt second part: stage 2 pwconv1 511 / 481 / 490 for cfg 63 / 64 / 66,
+//  stage 1 pwconv1 819200 x 512 x 128: 740 / 799 / 695)
+//   65  256 x 256 x 32 persistent (split_gemm_p8.hip): whole column tiles, K >= 256, at least one tile per CU
+//   64  the same tile, one workgroup per tile: whole column tiles, K >= 256, at least 128 tiles
+//   66  128 x 256 x 16, two workgroups per CU (split_gemm_p4.hip): whole column tiles, shorter K, very long m (stage 1 pwconv1)
+//   63  256 x 128 x 16 ping-pong: very long m with narrow n (stage 1 pwconv2)
 //   60  128 x 128 x 16 direct-to-LDS: everything else
 static int pick_presplit_cfg(int m, int n, int k, bool park) {
-  if (k % 32 == 0 && k >= 512 && m % 8 == 0 && n % 256 == 0) {
+  if (k % 32 == 0 && k >= 256 && m % 8 == 0 && n % 256 == 0) {
     const long long tiles = (long long)((m + 255) / 256) * (n / 256);
     const long long wgs = wd_p8_workspace_floats() > 0 ? (wd_p8_workspace_floats() - 1024) / (128 * 512) : 256;
     if (park && tiles >= wgs) return 65;
     if (tiles >= 128) return 64;
   }
+  if (k % 16 == 0 && n % 256 == 0 && m % 16 == 0 && m >= 131072) return 66;   // short K, very long m (stage-1 pwconv1)
   return m >= 131072 ? 63 : 60;
 }
 
@@ -131,6 +135,7 @@ extern "C" const char* wd_conv_gemm_split_config(int32_t m, int32_t n, int32_t k
     switch (pick_presplit_cfg(m, n, k, is_conv == 3)) {
       case 65: return "fp16x3 256x256x32/8w/p8s";
       case 64: return "fp16x3 256x256x32/8w/p8";
+      case 66: return "fp16x3 128x256x16/4w/p4";
       case 63: return "fp16x3 256x128x16/8w/pingpong";
       default: return "fp16x3 128x128x16/4w/glds";
     }
