@@ -5,7 +5,7 @@
 // Why another structure.  The 128 x 128 direct-to-LDS kernel (split_gemm_pre.hip) pays one
 // workgroup barrier and one full vmcnt(0) drain per 12 MFMAs and reads 8 ds_read_b128 per 12
 // MFMAs; its matrix pipe is busy a third of the time.  Here a wave owns 128 x 64 outputs (eight
-// 32 x 32 accumulators = 128 registers), so a K tile of 32 costs 20 ds_read_b128 per 48 MFMAs,
+// 32 x 32 accumulators = 128 registers), so a K tile of 32 costs 24 ds_read_b128 per 48 MFMAs,
 // and global -> LDS traffic per MFMA halves.  The K loop never drains the DMA queue:
 //
 //   * LDS (144 KB): two K-tile buffers of 48 KB, each cut into three 16 KB regions (128 rows x 128 B)
@@ -17,9 +17,10 @@
 //       phase 1  read A0 (8 x ds_read_b128) + W0 (4)   quadrant (rows 0-63,  cols 0-31)
 //       phase 2  read W1 (4)                           quadrant (rows 0-63,  cols 32-63)
 //       phase 3  read A1 (8)                           quadrant (rows 64-127, cols 32-63)
-//       phase 4  read W0 again (4)                     quadrant (rows 64-127, cols 0-31)
-//     One activation and ONE weight fragment set (48 registers) next to the 128 accumulator registers; W0 is
-//     read twice rather than held (16 registers that the persistent form needs), hence its third slot.
+//       phase 4  (W0 is still in registers)            quadrant (rows 64-127, cols 0-31)
+//     One activation and two weight fragment sets (64 registers) next to the 128 accumulator registers (198 in
+//     all; the persistent form 234, no scratch).  W0 keeps its three-slot ring from the form that re-read it in
+//     phase 4 (same speed within noise, 4 more reads per K tile): a request two K tiles ahead never waits for a slot.
 //     The per-accumulator MFMA sequence (k ascending, lo.hi -> hi.lo -> hi.hi inside a k16 step) is the
 //     one of every other fp16x3 kernel: results are bit-identical to theirs.
 //   * every phase also re-fills one region that went dead two phases earlier (tile t: phase 1: A1 of tile
@@ -223,6 +224,7 @@ split_gemm_p8_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, 
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
     h8 xh[2][2] = {}, xl[2][2] = {}, wh[2] = {}, wl[2] = {};       // activation fragments [row block][k16 step]; weights [k16 step]
+    h8 w0h[2] = {}, w0l[2] = {};                                   // W0 stays in registers from phase 1 to phase 4
     auto read_a = [&](const unsigned char* region) {
       if (ABL & 2) {
 #pragma unroll
@@ -241,31 +243,31 @@ split_gemm_p8_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, 
           xl[i][ks] = *reinterpret_cast<const h8*>(region + i * 4096 + (b ^ (ks * 64 + 32)));
         }
     };
-    auto read_w = [&](const unsigned char* region) {
+    auto read_w = [&](const unsigned char* region, h8 (&fh)[2], h8 (&fl)[2]) {
       if (ABL & 2) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) asm volatile("" : "+v"(wh[ks]), "+v"(wl[ks]));
+        for (int ks = 0; ks < 2; ++ks) asm volatile("" : "+v"(fh[ks]), "+v"(fl[ks]));
         return;
       }
       int b = wbase_off;
       asm volatile("" : "+v"(b));
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        wh[ks] = *reinterpret_cast<const h8*>(region + (b ^ (ks * 64)));
-        wl[ks] = *reinterpret_cast<const h8*>(region + (b ^ (ks * 64 + 32)));
+        fh[ks] = *reinterpret_cast<const h8*>(region + (b ^ (ks * 64)));
+        fl[ks] = *reinterpret_cast<const h8*>(region + (b ^ (ks * 64 + 32)));
       }
     };
     // 12 MFMAs of one quadrant: two 32 x 32 accumulators
-    auto quadrant = [&](f32x16& c0, f32x16& c1) {
+    auto quadrant = [&](f32x16& c0, f32x16& c1, const h8 (&fh)[2], const h8 (&fl)[2]) {
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks], xh[0][ks], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks], xh[1][ks], c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], xl[0][ks], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], xl[1][ks], c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], xh[0][ks], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], xh[1][ks], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[ks], xh[0][ks], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[ks], xh[1][ks], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ks], xl[0][ks], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ks], xl[1][ks], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ks], xh[0][ks], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ks], xh[1][ks], c1, 0, 0, 0);
       }
       __builtin_amdgcn_s_setprio(0);
     };
@@ -309,20 +311,20 @@ split_gemm_p8_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, 
       const int w0_free = P8_W0RING + (w0s == 0 ? 2 : w0s - 1) * P8_REGION;   // slot (kt + 2) % 3: its K tile kt - 1 is done
       // phase 1
       read_a(buf + P8_A0);
-      read_w(w0);
+      read_w(w0, w0h, w0l);
       if constexpr (S1) stage(kt + 1, oth + P8_A1, false, 1);
       if (PERSIST && resume) ldacc(acc[0][0], acc[1][0], 0 * TN + 0, 1 * TN + 0);
       P8_WAIT(10, 10, 2);
       P8_KBARRIER();
-      quadrant(acc[0][0], acc[1][0]);
+      quadrant(acc[0][0], acc[1][0], w0h, w0l);
       P8_KBARRIER();
       // phase 2
-      read_w(buf + P8_W1);
+      read_w(buf + P8_W1, wh, wl);
       if constexpr (S234) stage(kt + 2, w0_free, true, 0);
       if (PERSIST && resume) ldacc(acc[0][1], acc[1][1], 0 * TN + 1, 1 * TN + 1);
       P8_WAIT(10, 8, 0);
       P8_KBARRIER();
-      quadrant(acc[0][1], acc[1][1]);
+      quadrant(acc[0][1], acc[1][1], wh, wl);
       P8_KBARRIER();
       // phase 3
       read_a(buf + P8_A1);
@@ -330,15 +332,14 @@ split_gemm_p8_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, 
       if (PERSIST && resume) ldacc(acc[2][1], acc[3][1], 2 * TN + 1, 3 * TN + 1);
       P8_WAIT(10, 6, 0);
       P8_KBARRIER();
-      quadrant(acc[2][1], acc[3][1]);
+      quadrant(acc[2][1], acc[3][1], wh, wl);
       P8_KBARRIER();
-      // phase 4
-      read_w(w0);
+      // phase 4: W0 is still in registers
       if constexpr (S234) stage(kt + 2, cur + P8_W1, true, 1);
       if (PERSIST && resume) ldacc(acc[2][0], acc[3][0], 2 * TN + 0, 3 * TN + 0);
       P8_WAIT(10, 4, 0);
       P8_KBARRIER();
-      quadrant(acc[2][0], acc[3][0]);
+      quadrant(acc[2][0], acc[3][0], w0h, w0l);
       P8_KBARRIER();
       w0s = w0s == 2 ? 0 : w0s + 1;
       if (PERSIST && resume) {                                     // every parked value is in registers: release the slot
