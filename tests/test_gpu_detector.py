@@ -204,3 +204,32 @@ def test_fp16x3_range_guard_falls_back_to_fp32():
         warnings.simplefilter("always")
         m_ok, _ = run(sd, "fp16x3")
     assert not any("fp16 range" in str(w.message) for w in wrec) and m_ok._h.tower(2, 128, 128).precision == "fp16x3"
+
+
+def test_small_batches_replay_a_hipgraph_and_match_the_eager_step():
+    """batches of at most ``graph_max_batch`` images (4 by default; the reference runs batch 1)
+    go through a hipGraph captured on first use.  Same buffers, same kernels: bit-identical to the eager step, on the
+    first call (capture + replay) and on later ones (replay with new inputs); a larger batch stays eager."""
+    from wedetect_amd import weights as W
+    from wedetect_amd.detector import SimpleYOLOWorldDetector
+    sd_np = W.make_state_dict("nano", num_prompts=32)
+    def make():
+        m = SimpleYOLOWorldDetector("nano", prompt_dim=768, num_prompts=32, num_proposals=100)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in W.to_uni_keys(sd_np).items()}, strict=False)
+        return m.cuda().eval()
+    graphed, eager = make(), make()
+    eager._h.graph_max_batch = 0
+    assert graphed._h.graph_max_batch >= 3
+    imgs = _images()
+    for batch in (imgs, imgs[::-1], imgs[:1], imgs[1:2]):
+        a, b = graphed(batch), eager(batch)
+        assert len(a) == len(b) == len(batch)
+        for x, y in zip(a, b):
+            assert x.keys() == y.keys()
+            for k in x:
+                assert torch.equal(x[k], y[k]), f"graph replay differs from the eager step in {k}"
+    assert len(graphed._h._graphs) == 2 and len(eager._h._graphs) == 0      # one graph per (tower = batch size)
+    graphed._h.graph_max_batch = 2
+    n = len(graphed._h._graphs)
+    graphed(imgs)                                                           # 3 images > 2: eager, no new graph
+    assert len(graphed._h._graphs) == n

@@ -19,6 +19,7 @@ device / the built library raises.
 """
 from __future__ import annotations
 
+import os
 from collections import OrderedDict
 from typing import Callable, Dict, List, Optional, Sequence, Tuple, Union
 
@@ -114,6 +115,10 @@ class _TowerHolder:
         self._sd: Optional[Dict[str, np.ndarray]] = None
         self._packed = None
         self._towers = {}
+        self._graphs = {}
+        # batches up to this size replay the step from a captured hipGraph (launch-bound: ~380 launches per step);
+        # 0 = always eager
+        self.graph_max_batch = int(os.environ.get("WEDETECT_GRAPH_MAX_BATCH", "4"))
         self.device = None
 
     def load(self, sd, strict: bool):
@@ -133,6 +138,7 @@ class _TowerHolder:
         self._sd = {k: sd[k] for k in want}
         self._packed = None
         self._towers.clear()
+        self._graphs.clear()
         return _IncompatibleKeys(missing, unexpected)
 
     def state(self) -> "OrderedDict[str, torch.Tensor]":
@@ -150,11 +156,29 @@ class _TowerHolder:
         key = (batch, height, width)
         if key not in self._towers:
             if len(self._towers) >= 4:                       # each tower owns its activation buffers
-                self._towers.pop(next(iter(self._towers)))
+                old = self._towers.pop(next(iter(self._towers)))
+                self._graphs = {k: g for k, g in self._graphs.items() if g.tower is not old}
             self._towers[key] = ImageTower(self.arch, self._packed, batch, height, width, device=self.device,
                                            max_classes=self.max_classes, max_out=self.max_out, nms_pre=self.nms_pre,
                                            precision=self.precision)
         return self._towers[key]
+
+    def detect(self, tower, images_u8, text, meta, **kw):
+        """``tower.detect`` for the detector classes.  Small batches (the reference runs batch 1 everywhere) are
+        launch-bound, so the step is replayed from a hipGraph captured on first use (engine.GraphedDetect: inputs are
+        copied into the graph's static buffers, results are the tower's usual buffers — bit-identical to the eager
+        step, tests/test_gpu_detector.py).  A graph belongs to one (tower, arithmetic mode, bank size, thresholds); the
+        range guard's switch to fp32 therefore captures anew."""
+        if tower.B > self.graph_max_batch:
+            return tower.detect(images_u8, text, meta, **kw)
+        key = (id(tower), tower.precision, int(text.shape[0]), tuple(sorted(kw.items())))
+        g = self._graphs.get(key)
+        if g is None:
+            from .engine import GraphedDetect
+            if len(self._graphs) >= 8:
+                self._graphs.pop(next(iter(self._graphs)))
+            g = self._graphs[key] = GraphedDetect(tower, int(text.shape[0]), **kw)
+        return g(images_u8, text, meta)
 
 
 class _DeviceModule(torch.nn.Module):
@@ -279,7 +303,7 @@ class SimpleYOLOWorldDetector(_DeviceModule):
             metas.append([dw, dh, 0.0, sc, sc, float(w), float(h), 0.0])
         tower = self._h.tower(len(imgs), self.img_size[0], self.img_size[1])
         meta = torch.tensor(metas, dtype=torch.float32, device=self._h.device)
-        run = lambda: tower.detect(x, tower.P["prompts"], meta, normalize_text=False, score_thr=0.0, with_embed=True)
+        run = lambda: self._h.detect(tower, x, tower.P["prompts"], meta, normalize_text=False, score_thr=0.0, with_embed=True)
         res = run()
         counts = tower.checked_counts(res, run)             # one D2H sync per batch (+ the fp16x3 range guard)
         if tower.overflowed:
@@ -655,8 +679,8 @@ class YOLOWorldDetector(_DeviceModule):
             tower = self._h.tower(len(idxs), hh, ww)
             meta = torch.tensor(metas, dtype=torch.float32, device=dev)
             bank = banks[idxs[0]].to(dev)
-            run = lambda: tower.detect(x, bank, meta, normalize_text=True, score_thr=self.test_cfg["score_thr"],
-                                       iou_thr=self.test_cfg["nms"]["iou_threshold"], with_embed=False)
+            run = lambda: self._h.detect(tower, x, bank, meta, normalize_text=True, score_thr=self.test_cfg["score_thr"],
+                                         iou_thr=self.test_cfg["nms"]["iou_threshold"], with_embed=False)
             res = run()
             counts = tower.checked_counts(res, run)
             if tower.overflowed:
