@@ -228,7 +228,7 @@ __device__ __forceinline__ void epi_lds_tile_csplit(const WdConvGemm& p, const E
     const f32x4 v1 = *reinterpret_cast<const f32x4*>(patch + row * EPI_LDT + 8 * (lane & 3) + 4);
     if (m < p.m && n < p.n) {
       if (p.range_flag) {
-        if (wd_any_nonfinite4(v0[0], v0[1], v0[2], v0[3]) | wd_any_nonfinite4(v1[0], v1[1], v1[2], v1[3])) *p.range_flag = 1u;
+        if (wd_any_nonfinite4(v0[0] + v0[1], v0[2] + v0[3], v1[0] + v1[1], v1[2] + v1[3])) *p.range_flag = 1u;
       }
       f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
       if (p.bias) {
