@@ -263,6 +263,14 @@ int wd_recall_match(const float* gts, const int32_t* gt_off, const float* props,
 /* wd_layernorm_rows with the output written as fp16 (hi, lo) groups (see WD_SPLIT_A); c % 8 == 0. */
 int wd_layernorm_rows_split(const float* x, void* y, const float* gamma, const float* beta, int64_t rows, int32_t c,
                             int32_t ldx, int32_t ldy, float eps, void* stream);
+/* The same with a SPACE-TO-DEPTH output for the 2 x 2 / stride-2 downsample convolutions of ConvNeXt (LayerNorm2d ->
+ * Conv2d(k 2, s 2), mm_backbone.py downsample_layers): x is a [batch, h, w, c] map (h, w even), pixel (b, py, px) is
+ * written to row (b, py / 2, px / 2) of a [batch * h/2 * w/2, 4 c] matrix at columns ((py & 1) * 2 + (px & 1)) * c —
+ * the (kh, kw, cin) order of the convolution's GEMM rows — so that the convolution runs as a plain pre-split GEMM
+ * (wd_conv_gemm_split with WD_SPLIT_A, kh = kw = 1, k = 4 c) on the DMA-fed kernels.  Same values as
+ * wd_layernorm_rows_split, other addresses; not in place. */
+int wd_layernorm_rows_split_s2d(const float* x, void* y, const float* gamma, const float* beta, int32_t batch, int32_t h,
+                                int32_t w, int32_t c, float eps, void* stream);
 
 /* Profiling hook.  The next GEMM kernel that wd_conv_gemm / wd_conv_gemm_tuned / wd_conv_gemm_split(_ws) /
  * wd_retrieval_max_split launches from the CALLING THREAD stamps its own begin and end into the two

@@ -448,3 +448,39 @@ def test_dwconv7_ln_fused_bit_identical_to_the_pair(b, h, w, c, split):
         assert torch.equal(out.view(torch.int32), ref.view(torch.int32)), float((out - ref).abs().max())
     with pytest.raises(L.WedetectHipError):
         L.dwconv7_ln(x[:, :24].contiguous(), w7[:, :24].contiguous(), bias[:24], out[:, :24].contiguous(), gam[:24], bet[:24], b, h, w, 24)
+
+
+@pytest.mark.parametrize("b,h,w,c,n", [(2, 16, 24, 128, 256), (1, 40, 40, 256, 512), (3, 6, 10, 64, 96), (32, 20, 20, 64, 256)])
+def test_downsample_as_plain_gemm_on_space_to_depth_layernorm_rows(b, h, w, c, n):
+    """ConvNeXt downsample (LayerNorm2d -> Conv2d k2 s2, mm_backbone.py downsample_layers): wd_layernorm_rows_split_s2d
+    writes the convolution's GEMM rows ((kh, kw, cin) columns), so the layer runs as a plain pre-split GEMM with K = 4 c.
+    Same operands in the same K order: bit-identical to LayerNorm + the 2 x 2 / stride-2 conv kernel, and equal to torch."""
+    from wedetect_amd import lib as L
+    g = torch.Generator(device="cuda").manual_seed(b * 1000 + c)
+    x = torch.randn(b * h * w, c, device="cuda", generator=g) * 1.5 + 0.2
+    gam = torch.rand(c, device="cuda", generator=g) + 0.5
+    bet = torch.randn(c, device="cuda", generator=g) * 0.1
+    wt = torch.randn(n, c, 2, 2, device="cuda", generator=g) * (4 * c) ** -0.5
+    bias = torch.randn(n, device="cuda", generator=g) * 0.1
+    w_rows = wt.permute(0, 2, 3, 1).reshape(n, 4 * c).contiguous()          # (kh, kw, cin): pack._conv_rows
+    ws = L.split_weights(w_rows)
+    m_out = b * (h // 2) * (w // 2)
+    # conv path
+    t1 = torch.empty(b * h * w, c, device="cuda")
+    L.layernorm_rows(x, t1, gam, bet, b * h * w, c, split=True)
+    y1 = torch.empty(m_out, n, device="cuda")
+    L.conv_gemm(t1, None, bias, y1, w_split=ws, batch=b, hin=h, win=w, cin=c, lda=c, kh=2, kw=2, stride=2, pad=0, n=n, ldc=n,
+                split_flags=L.SPLIT_A)
+    # space-to-depth path
+    t2 = torch.empty(m_out, 4 * c, device="cuda")
+    L.layernorm_rows_split_s2d(x, t2, gam, bet, b, h, w, c)
+    y2 = torch.empty(m_out, n, device="cuda")
+    L.conv_gemm(t2, None, bias, y2, w_split=ws, batch=b, hin=h // 2, win=w // 2, cin=4 * c, lda=4 * c, n=n, ldc=n,
+                split_flags=L.SPLIT_A)
+    torch.cuda.synchronize()
+    assert torch.equal(y1.view(torch.int32), y2.view(torch.int32)), float((y1 - y2).abs().max())
+    ln = F.layer_norm(x.double(), (c,), gam.double(), bet.double(), 1e-6).view(b, h, w, c).permute(0, 3, 1, 2)
+    ref = F.conv2d(ln, wt.double(), bias.double(), stride=2).permute(0, 2, 3, 1).reshape(m_out, n)
+    assert_close("downsample s2d", y2, ref.float().cpu().numpy(), 2e-5, 2e-5)
+    with pytest.raises(L.WedetectHipError):
+        L.layernorm_rows_split_s2d(x[: 3 * 5 * c // c], t2, gam, bet, 1, 3, 5, c)          # odd map

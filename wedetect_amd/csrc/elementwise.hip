@@ -341,13 +341,25 @@ template <int NV, bool SPLIT>
 __global__ void __launch_bounds__(256) layernorm_rows_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, long long rows, int c,
-                                                             int ldx, int ldy, float eps, int g) {
+                                                             int ldx, int ldy, float eps, int g, int s2d_h, int s2d_w) {
   const int t = threadIdx.x;
   const int rows_per_block = 256 / g;
   const long long row = (long long)blockIdx.x * rows_per_block + t / g;
   const bool row_ok = row < rows;      // keep every lane alive for the shuffles
   const long long r = row_ok ? row : 0;
-  ln_row<NV, SPLIT>(x + r * ldx, y + r * ldy, gamma, beta, c, eps, g, t % g, row_ok);
+  float* yr = y + r * ldy;
+  if (s2d_w > 0) {
+    // space-to-depth output (wd_layernorm_rows_split_s2d): pixel (b, py, px) of an h x w map -> row (b, py / 2, px / 2) of
+    // the [B * h/2 * w/2, 4 c] matrix, columns [((py & 1) * 2 + (px & 1)) * c, + c): the (kh, kw, cin) order of a 2 x 2 /
+    // stride-2 convolution's GEMM rows, so that the convolution becomes a plain GEMM
+    const int px = (int)(r % s2d_w);
+    const long long q = r / s2d_w;
+    const int py = (int)(q % s2d_h);
+    const long long b = q / s2d_h;
+    const long long drow = (b * (s2d_h >> 1) + (py >> 1)) * (s2d_w >> 1) + (px >> 1);
+    yr = y + drow * ldy + ((py & 1) * 2 + (px & 1)) * c;
+  }
+  ln_row<NV, SPLIT>(x + r * ldx, yr, gamma, beta, c, eps, g, t % g, row_ok);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -581,7 +593,7 @@ extern "C" int wd_dwconv7_ln(const float* x, const float* w7, const float* bias,
 
 template <bool SPLIT>
 static int launch_layernorm(const float* x, float* y, const float* gamma, const float* beta, int64_t rows, int32_t c,
-                            int32_t ldx, int32_t ldy, float eps, void* stream) {
+                            int32_t ldx, int32_t ldy, float eps, void* stream, int s2d_h = 0, int s2d_w = 0) {
   if (!x || !y || !gamma || !beta || rows <= 0 || c <= 0 || (c & 3) || c > 2048) return WD_ERR_BAD_ARG;
   if (ldx < c || ldy < c || (ldx & 3) || (ldy & 3)) return WD_ERR_BAD_ARG;
   if (SPLIT && ((c & 7) || (ldy & 7))) return WD_ERR_BAD_ARG;
@@ -597,7 +609,7 @@ static int launch_layernorm(const float* x, float* y, const float* gamma, const 
 #define WD_LN_CASE(NV)                                                                                              \
   case NV:                                                                                                          \
     hipLaunchKernelGGL((layernorm_rows_kernel<NV, SPLIT>), dim3((unsigned)grid), dim3(256), 0, st, x, y, gamma,     \
-                       beta, (long long)rows, c, ldx, ldy, eps, g);                                                 \
+                       beta, (long long)rows, c, ldx, ldy, eps, g, s2d_h, s2d_w);                                   \
     break;
   switch (nv) {
     WD_LN_CASE(1) WD_LN_CASE(2) WD_LN_CASE(3) WD_LN_CASE(4) WD_LN_CASE(5) WD_LN_CASE(6) WD_LN_CASE(7) WD_LN_CASE(8)
@@ -615,6 +627,12 @@ extern "C" int wd_layernorm_rows(const float* x, float* y, const float* gamma, c
 extern "C" int wd_layernorm_rows_split(const float* x, void* y, const float* gamma, const float* beta, int64_t rows,
                                        int32_t c, int32_t ldx, int32_t ldy, float eps, void* stream) {
   return launch_layernorm<true>(x, static_cast<float*>(y), gamma, beta, rows, c, ldx, ldy, eps, stream);
+}
+
+extern "C" int wd_layernorm_rows_split_s2d(const float* x, void* y, const float* gamma, const float* beta, int32_t batch,
+                                           int32_t h, int32_t w, int32_t c, float eps, void* stream) {
+  if (batch <= 0 || h <= 0 || w <= 0 || (h & 1) || (w & 1) || x == y) return WD_ERR_BAD_ARG;
+  return launch_layernorm<true>(x, static_cast<float*>(y), gamma, beta, (int64_t)batch * h * w, c, c, 4 * c, eps, stream, h, w);
 }
 
 extern "C" int wd_l2norm_rows(const float* x, float* y, int64_t rows, int32_t c, void* stream) {

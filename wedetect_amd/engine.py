@@ -71,6 +71,7 @@ class ImageTower:
         # equal inside the step; its flag words must start zero and it is never lent to split-K launches); "0" = neither
         # (the round-1 128 x 128 / ping-pong kernels, for A/B runs).
         self.p8_mode = os.environ.get("WEDETECT_P8", "tile")
+        self.s2d_down = os.environ.get("WEDETECT_S2D_DOWN", "1") != "0"     # downsample convs as plain GEMMs on space-to-depth LayerNorm rows
         self.park = None
         if precision == "fp16x3" and self.p8_mode == "persist" and L.p8_workspace_bytes() > 0:
             self.park = torch.zeros(L.p8_workspace_bytes() // 4, dtype=torch.float32, device=torch.device(device))
@@ -203,10 +204,19 @@ class ImageTower:
             if i > 0:
                 cp = a.dims[i - 1]
                 hp, wp = self.hw[i - 1]
-                L.layernorm_rows(self.x[i - 1], self.tmp, self.P[f"down{i}.ln_w"], self.P[f"down{i}.ln_b"],
-                                 self.M[i - 1], cp, split=pre)
-                self._gemm(self.tmp, f"down{i}.w", f"down{i}.b", self.x[i], hin=hp, win=wp, cin=cp, lda=cp, kh=2, kw=2,
-                           stride=2, pad=0, n=c, ldc=c, split_flags=fa)
+                if pre and hp % 2 == 0 and wp % 2 == 0 and self.s2d_down:
+                    # LayerNorm writes the 2 x 2 / stride-2 convolution's GEMM rows directly (space-to-depth, (kh, kw, cin)
+                    # column order = the packed weight's): the downsample runs as a plain pre-split GEMM with K = 4 cp on
+                    # the DMA-fed kernels instead of the register-staged conv loader.  Same K order, same bits.
+                    L.layernorm_rows_split_s2d(self.x[i - 1], self.tmp, self.P[f"down{i}.ln_w"], self.P[f"down{i}.ln_b"],
+                                               B, hp, wp, cp)
+                    self._gemm(self.tmp, f"down{i}.w", f"down{i}.b", self.x[i], hin=h, win=w, cin=4 * cp, lda=4 * cp, n=c,
+                               ldc=c, split_flags=fa)
+                else:
+                    L.layernorm_rows(self.x[i - 1], self.tmp, self.P[f"down{i}.ln_w"], self.P[f"down{i}.ln_b"],
+                                     self.M[i - 1], cp, split=pre)
+                    self._gemm(self.tmp, f"down{i}.w", f"down{i}.b", self.x[i], hin=hp, win=wp, cin=cp, lda=cp, kh=2, kw=2,
+                               stride=2, pad=0, n=c, ldc=c, split_flags=fa)
             for j in range(a.depths[i]):
                 q = f"s{i}.{j}."
                 if c % 32 == 0 and self.fuse_dwln:   # dwconv -> norm in one kernel (bit-identical to the pair; one HBM round trip less)

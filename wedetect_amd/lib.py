@@ -19,13 +19,13 @@ LIB_PATH = os.path.join(_HERE, "libwedetect_hip.so")
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU = 0, 1, 2, 3
 OUT_ROWS, OUT_DECONV2X2 = 0, 1
 SPLIT_A, SPLIT_C = 1, 2
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 EXPORTS = (
     "wd_abi_version", "wd_strerror", "wd_sizeof_conv_gemm", "wd_conv_gemm", "wd_conv_gemm_tuned", "wd_conv_gemm_config", "wd_stem_patchify", "wd_dwconv7",
     "wd_layernorm_rows", "wd_l2norm_rows", "wd_dfl_decode", "wd_topk_workspace_bytes", "wd_topk_capacity",
     "wd_topk_candidates", "wd_nms_gather", "wd_retrieval_max",
-    "wd_split_weights_bytes", "wd_split_weights", "wd_conv_gemm_split", "wd_conv_gemm_split_ws", "wd_conv_gemm_split_config", "wd_layernorm_rows_split", "wd_letterbox_u8", "wd_retrieval_max_split", "wd_text_embed", "wd_attention_small", "wd_recall_scratch_floats", "wd_recall_match",
+    "wd_split_weights_bytes", "wd_split_weights", "wd_conv_gemm_split", "wd_conv_gemm_split_ws", "wd_conv_gemm_split_config", "wd_layernorm_rows_split", "wd_layernorm_rows_split_s2d", "wd_letterbox_u8", "wd_retrieval_max_split", "wd_text_embed", "wd_attention_small", "wd_recall_scratch_floats", "wd_recall_match",
     "wd_max_sigmoid_attn", "wd_adaptive_maxpool_nhwc", "wd_cross_attention_small", "wd_time_next_gemm",
     "wd_cv_resize_paste_u8", "wd_chw_to_hwc_u8", "wd_p8_workspace_bytes", "wd_dwconv7_ln",
 )
@@ -93,6 +93,7 @@ def _load():
     lib.wd_conv_gemm_split.argtypes = [C.POINTER(ConvGemm), vp, f32, i32, i32, vp]
     lib.wd_conv_gemm_split_ws.argtypes = [C.POINTER(ConvGemm), vp, f32, i32, i32, vp, i64, i32, vp]
     lib.wd_layernorm_rows_split.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, f32, vp]
+    lib.wd_layernorm_rows_split_s2d.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]
     lib.wd_retrieval_max_split.argtypes = [vp, vp, f32, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.wd_recall_scratch_floats.restype = i64
     lib.wd_recall_scratch_floats.argtypes = [i32, i32]
@@ -220,6 +221,13 @@ def layernorm_rows(x, y, gamma, beta, rows, c, ldx=None, ldy=None, eps=1e-6, spl
     fn = LIB.wd_layernorm_rows_split if split else LIB.wd_layernorm_rows
     check(fn(_p(x), _p(y), _p(gamma), _p(beta), rows, c, ldx or c, ldy or c, eps, stream_ptr()),
           "wd_layernorm_rows_split" if split else "wd_layernorm_rows")
+
+
+def layernorm_rows_split_s2d(x, y, gamma, beta, batch, h, w, c, eps=1e-6) -> None:
+    """LayerNorm over the channels of an NHWC map, written as fp16 hi/lo groups in SPACE-TO-DEPTH order: the
+    [batch * h/2 * w/2, 4 c] GEMM rows of a 2 x 2 / stride-2 convolution ((kh, kw, cin) column order)."""
+    check(LIB.wd_layernorm_rows_split_s2d(_p(x), _p(y), _p(gamma), _p(beta), batch, h, w, c, eps, stream_ptr()),
+          "wd_layernorm_rows_split_s2d")
 
 
 def letterbox_u8(src, h, w, bounds_h, kk_h, ksize_h, bounds_v, kk_v, ksize_v, tmp, dst, dst_h, dst_w, new_w, new_h,
