@@ -391,7 +391,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     kept = int(res["count"].sum().item())
-    overflow = bool((res["count"] < 0).any().item()) or int(tower.range_flag.item()) != 0     # fp16x3 range guard
+    overflow = bool((res["count"] < 0).any().item()) or bool(tower.range_flags.any().item())     # fp16x3 range guards
 
     if rank == 0:
         summ = timer.summary()

@@ -233,3 +233,59 @@ def test_small_batches_replay_a_hipgraph_and_match_the_eager_step():
     n = len(graphed._h._graphs)
     graphed(imgs)                                                           # 3 images > 2: eager, no new graph
     assert len(graphed._h._graphs) == n
+
+
+def test_neck_input_layers_run_fp16x3_under_their_own_guard():
+    """The five neck layers that read the backbone residual streams directly ran the fp32 kernel unconditionally in round 1
+    (their inputs are not bounded by construction).  They now run fp16x3 with a range flag of their own: a checkpoint whose
+    residual stream leaves the fp16 range trips it, ONLY those layers are pinned to fp32 (the tower stays fp16x3), the step is
+    repeated and equals a tower that pinned them from the start, bit for bit."""
+    import warnings
+    from wedetect_amd import weights as W
+    from wedetect_amd.engine import ImageTower
+    from wedetect_amd.pack import pack
+    sd = W.make_state_dict("nano", num_prompts=0)
+    hot = dict(sd)
+    k = "backbone.image_model.model.stages.3.0.pwconv2"      # blow up the LAST residual stream (c4) only: it feeds reduce_layer0
+    hot[k + ".weight"] = sd[k + ".weight"] * np.float32(4e6)
+    hot[k + ".bias"] = sd[k + ".bias"] * np.float32(4e6)
+    r = "neck.reduce_layer0.block.conv.weight"                # ... and let the layer that reads it scale it back, so that
+    hot[r] = sd[r] / np.float32(4e6)                          # everything downstream sees ordinary magnitudes
+    x = torch.from_numpy(W.make_images(2, 128, 128, seed=8)).cuda()
+    text = torch.from_numpy(W.make_text_bank(20)).cuda()
+
+    def tower_for(state, guard):
+        import os
+        old = os.environ.get("WEDETECT_NECK_GUARD")
+        os.environ["WEDETECT_NECK_GUARD"] = guard
+        try:
+            return ImageTower("nano", pack(state, "nano"), 2, 128, 128, max_classes=20)
+        finally:
+            if old is None:
+                del os.environ["WEDETECT_NECK_GUARD"]
+            else:
+                os.environ["WEDETECT_NECK_GUARD"] = old
+    def step(t):
+        meta = t.identity_meta()
+        run = lambda: t.detect(x, text, meta, normalize_text=True, score_thr=0.001, with_embed=True)
+        res = run()
+        counts = t.checked_counts(res, run)
+        return {k2: v.clone() for k2, v in res.items()}, counts
+    # a tame checkpoint: guarded layers stay fp16x3, nothing trips, results within fp32 tolerance of the pinned tower
+    tg, tp = tower_for(sd, "1"), tower_for(sd, "0")
+    assert not tg.neck_pin and tp.neck_pin
+    rg, cg = step(tg)
+    rp, cp = step(tp)
+    assert not tg.neck_pin and tg.precision == "fp16x3" and cg == cp
+    assert_close("guarded vs pinned embeddings", tg.embed, to_np(tp.embed), 2e-4, 2e-4)
+    # the hot checkpoint: c4 ~ 1e6
+    th, tq = tower_for(hot, "1"), tower_for(hot, "0")
+    with warnings.catch_warnings(record=True) as wrec:
+        warnings.simplefilter("always")
+        rh, ch = step(th)
+    assert any("neck input layer" in str(w.message) for w in wrec)
+    assert th.neck_pin and th.precision == "fp16x3" and not th.overflowed
+    rq, cq = step(tq)
+    assert ch == cq and tq.precision == "fp16x3"
+    for k2 in rh:
+        assert torch.equal(rh[k2], rq[k2]), k2

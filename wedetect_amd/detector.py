@@ -171,7 +171,7 @@ class _TowerHolder:
         range guard's switch to fp32 therefore captures anew."""
         if tower.B > self.graph_max_batch:
             return tower.detect(images_u8, text, meta, **kw)
-        key = (id(tower), tower.precision, int(text.shape[0]), tuple(sorted(kw.items())))
+        key = (id(tower), tower.precision, tower.neck_pin, int(text.shape[0]), tuple(sorted(kw.items())))
         g = self._graphs.get(key)
         if g is None:
             from .engine import GraphedDetect

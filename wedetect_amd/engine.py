@@ -79,7 +79,14 @@ class ImageTower:
         self.fuse_dwln = os.environ.get("WEDETECT_FUSE_DWLN", "0") == "1"      # measured slower at every stage (profiles/r02_dwln_ab.txt): opt-in
         self.overflowed = False
         # sticky range flag of the fp16x3 GEMMs (WdConvGemm.range_flag): set by a launch whose accumulators are inf / NaN
-        self.range_flag = torch.zeros(1, dtype=torch.int32, device=torch.device(device))
+        self.range_flags = torch.zeros(2, dtype=torch.int32, device=torch.device(device))
+        self.range_flag = self.range_flags[0:1]
+        # The five neck layers that read the ConvNeXt residual streams c1..c4 directly are the only GEMMs whose inputs are
+        # not bounded by construction (neither LayerNorm outputs nor activations of a BN-folded conv).  They run fp16x3
+        # under their OWN range flag; if it ever trips, only they are pinned to the fp32 MFMA kernel (neck_pin) and the
+        # step is repeated — the rest of the tower keeps fp16x3.  $WEDETECT_NECK_GUARD=0 pins them from the start.
+        self.range_flag2 = self.range_flags[1:2]
+        self.neck_pin = precision != "fp16x3" or os.environ.get("WEDETECT_NECK_GUARD", "1") == "0"
         self.dev = torch.device(device)
         if height % 32 or width % 32:
             raise ValueError("input size must be a multiple of 32")
@@ -156,7 +163,8 @@ class ImageTower:
         residual streams c1..c4 directly — the only GEMM inputs that are neither LayerNorm outputs nor
         activations of a BN-folded conv, hence not bounded by construction (fp16 halves overflow at 65504)."""
         ws = None
-        if self.precision == "fp16x3" and not fp32:
+        guarded = fp32 and self.precision == "fp16x3" and not self.neck_pin
+        if self.precision == "fp16x3" and (not fp32 or guarded):
             ws = self.Ws.get(w)
             if ws is None:                      # first use: split once, keep resident
                 wt = self.P[w]
@@ -175,7 +183,8 @@ class ImageTower:
             elif plain and self.p8_mode == "0" and kw["cin"] % 16 == 0:
                 kw = dict(kw, split_cfg=63 if m >= 131072 else 60)
         L.conv_gemm(a, None if ws is not None else self.P[w], self.P[b] if b else None, c, batch=self.B,
-                    w_split=ws, workspace=work, range_flag=self.range_flag if ws is not None else None, **kw)
+                    w_split=ws, workspace=work,
+                    range_flag=(self.range_flag2 if guarded else self.range_flag) if ws is not None else None, **kw)
 
     def _conv(self, a, w, b, c, *, hin, win, cin, lda, n, ldc, k=1, stride=1, act=L.ACT_NONE, res=None, ldres=0,
               res_alpha=1.0, **kw):
@@ -395,10 +404,20 @@ class ImageTower:
         that overflows once will again — and ``rerun()`` (the caller's closure that repeats the step) is executed once
         more.  Raises if fp32 produces non-finite scores too."""
         counts = res["count"].tolist()
-        tripped = self.precision == "fp16x3" and int(self.range_flag.item()) != 0
+        flags = self.range_flags.tolist() if self.precision == "fp16x3" else [0, 0]
+        if flags[1] and not self.neck_pin:
+            # a residual stream left the fp16 range in one of the neck layers that read it directly: pin those five layers to
+            # the fp32 kernel (as round 1 did unconditionally) and repeat; everything else stays fp16x3
+            import warnings
+            warnings.warn("wedetect_amd: a backbone residual stream left the fp16 range in a neck input layer; those layers now "
+                          "run the fp32 MFMA kernel")
+            self.neck_pin = True
+            self.range_flags.zero_()
+            return self.checked_counts(rerun(), rerun)
+        tripped = flags[0] != 0
         if min(counts, default=0) >= 0 and not tripped:
             return counts
-        self.range_flag.zero_()
+        self.range_flags.zero_()
         if self.precision == "fp32":
             raise L.WedetectHipError("non-finite scores in fp32 mode: the checkpoint or the inputs produce inf / NaN")
         import warnings
