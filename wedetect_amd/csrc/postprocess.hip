@@ -358,7 +358,7 @@ __device__ __forceinline__ f32x4 clamp_box(f32x4 bx, const float* mt) {
   return r;
 }
 
-constexpr int NMS_MAX_OUT = 1024;
+constexpr int NMS_MAX_OUT = 1024, NMS_BUCKETS = 2048;
 
 __global__ void __launch_bounds__(64) nms_kernel(const int* __restrict__ cand_idx, const float* __restrict__ cand_score,
                                                  const int* __restrict__ cand_count, int cand_stride,
@@ -368,9 +368,14 @@ __global__ void __launch_bounds__(64) nms_kernel(const int* __restrict__ cand_id
                                                  int* __restrict__ out_labels, int* __restrict__ out_anchors,
                                                  int* __restrict__ out_count) {
   __shared__ f32x4 kept_box[NMS_MAX_OUT];
-  __shared__ __attribute__((aligned(16))) int kept_label[NMS_MAX_OUT];
+  __shared__ int kept_label[NMS_MAX_OUT];
+  // kept boxes are chained per class bucket (label & (NMS_BUCKETS - 1)): a candidate only walks the kept boxes of its
+  // own bucket — with 80 classes and 300 kept boxes about four entries instead of all 300 (the scan of the whole
+  // kept list was most of this kernel when many candidates overlap a kept box and the loop runs over hundreds of chunks)
+  __shared__ short kept_next[NMS_MAX_OUT];
+  __shared__ short bucket_head[NMS_BUCKETS];
   const int b = blockIdx.x, lane = threadIdx.x;
-  for (int i = lane; i < NMS_MAX_OUT; i += 64) kept_label[i] = -2;      // never equals a candidate label
+  for (int i = lane; i < NMS_BUCKETS; i += 64) bucket_head[i] = -1;
   __syncthreads();
   const float* mt = meta + (size_t)b * 8;
   const bool pre = mt[7] != 0.f;
@@ -412,14 +417,11 @@ __global__ void __launch_bounds__(64) nms_kernel(const int* __restrict__ cand_id
     if (base + 64 < count) fetch(base + 64);
     if (valid && pre) box = rescale_box(box, mt);
     bool alive = valid;
-    // candidates vs. the kept list: labels are scanned four at a time (one broadcast
-    // ds_read_b128); the IoU test only runs on a class match (slots >= nk hold label -2)
-    for (int j = 0; j < nk; j += 4) {
-      const int4 l4 = *reinterpret_cast<const int4*>(&kept_label[j]);
-      if (alive && l4.x == label && iou_gt(kept_box[j], box, iou_thr)) alive = false;
-      if (alive && l4.y == label && iou_gt(kept_box[j + 1], box, iou_thr)) alive = false;
-      if (alive && l4.z == label && iou_gt(kept_box[j + 2], box, iou_thr)) alive = false;
-      if (alive && l4.w == label && iou_gt(kept_box[j + 3], box, iou_thr)) alive = false;
+    // candidates vs. the kept boxes of their class bucket (any order: a candidate dies if ANY kept box of its class
+    // overlaps it by more than the threshold)
+    if (alive) {
+      for (int e = bucket_head[label & (NMS_BUCKETS - 1)]; e >= 0; e = kept_next[e])
+        if (kept_label[e] == label && iou_gt(kept_box[e], box, iou_thr)) { alive = false; break; }
     }
     // sequential resolution inside the chunk, visiting only the candidates that are still alive
     unsigned long long mask = __ballot(alive);
@@ -432,6 +434,8 @@ __global__ void __launch_bounds__(64) nms_kernel(const int* __restrict__ cand_id
       if (lane == p) {
         kept_box[nk] = box;
         kept_label[nk] = label;
+        kept_next[nk] = bucket_head[label & (NMS_BUCKETS - 1)];
+        bucket_head[label & (NMS_BUCKETS - 1)] = (short)nk;
         f32x4 o = box;
         if (!pre) o = rescale_box(o, mt);
         o = clamp_box(o, mt);
