@@ -19,6 +19,9 @@ SHAPES = {
     "e3_pw1 csplit noact": dict(m=51200, n=2048, k=512, csplit=True),
     "e3_pw1 fp32out gelu": dict(m=51200, n=2048, k=512, gelu=True, nosplit=True),
     "e3_pw1 fp32out noact": dict(m=51200, n=2048, k=512),
+    "e1_pw1 csplit noact (stage 1)": dict(m=819200, n=512, k=128, csplit=True),
+    "e1_pw1 fp32out gelu (stage 1)": dict(m=819200, n=512, k=128, gelu=True, nosplit=True),
+    "e1_pw1 fp32out noact (stage 1)": dict(m=819200, n=512, k=128),
     "s4_pw1 12800x4096x1024 gelu": dict(m=12800, n=4096, k=1024, gelu=True),
     "s4_pw2 12800x1024x4096 res": dict(m=12800, n=1024, k=4096, res=True),
 }
