@@ -466,3 +466,23 @@ def test_region_gatherer_single_process_does_not_alias_the_callers_buffers():
     last = rg.collect()
     seen.append((float(last["embeddings"][0, 0, 0]), int(last["count"][0])))
     assert seen == [(0.0, 0), (1.0, 1), (2.0, 2), (3.0, 3)]
+
+
+def test_presplit_kernel_selection_table():
+    """The production kernel of every pre-split plain layer of the ConvNeXt-Base tower at the benchmark batch
+    (wd_conv_gemm_split_config: DESIGN.md §4, profiles/r02_p8_ab.txt) — a host-side table, no device needed.  The kernels are
+    bit-identical to each other (tests/test_gpu_split.py), so this guards speed, not results."""
+    from wedetect_amd import lib as L
+    want = {
+        (819200, 512, 128): "p4",             # stage-1 pwconv1: short K, 1.7 GB of output -> two workgroups per CU
+        (819200, 128, 512): "pingpong",       # stage-1 pwconv2: n = 128
+        (204800, 1024, 256): "p8", (204800, 256, 1024): "p8",
+        (51200, 2048, 512): "p8", (51200, 512, 2048): "p8",
+        (12800, 4096, 1024): "p8", (12800, 1024, 4096): "p8",
+        (204800, 256, 512): "p8", (51200, 512, 1024): "p8", (12800, 1024, 2048): "p8",     # downsample convs as plain GEMMs
+        (1600, 2048, 512): "glds",            # batch 1: too few tiles for the 256 x 256 kernel
+        (51200, 2048, 528): "glds",           # K % 32 != 0 (still % 16 == 0)
+    }
+    for (m, n, k), tag in want.items():
+        got = L.gemm_config(m, n, k, split=True, presplit=True)
+        assert got.endswith("/" + tag), ((m, n, k), got)
