@@ -2,7 +2,10 @@
 """bench.py — images/s of the WeDetect hot path on MI355X (BASELINE.json configs[1]).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched under torch.distributed.run, one rank per GPU, RCCL backend)
+    N > 1: one rank per GPU over RCCL.  Started under torch.distributed.run (RANK / WORLD_SIZE in the environment) it
+    is one of the N ranks; started plainly (`python bench.py --gpus 8`) it launches the N ranks itself — the same
+    torch.distributed.run command line the reference's dist_test.sh:11-22 / extract_embedding.py:1665-1669 use — and
+    relays their single JSON line.  It never reports n_gpus < N.
 
 One step = one pass of the hot path over one batch of synthetic images already resident in
 HBM as uint8 NHWC: ConvNeXt-Base tower + CSPRepBiFPAN neck + YOLO-World head (region
@@ -64,29 +67,37 @@ KERNEL_SYMBOL = {
 
 
 def measured_traffic(tag):
-    """HBM bytes per launch from the committed PMC passes (profiles/r02_traffic.json for the current fp16x3 build,
-    profiles/r01_traffic.json for the fp32 build: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same
-    command, FETCH_SIZE doubled per MI355X_MICROARCH.md).  None when no PMC record matches the kernel that ran."""
+    """HBM bytes per launch from the committed PMC passes (profiles/r03_traffic.json, else r02_traffic.json, for the fp16x3
+    build; profiles/r01_traffic.json for the fp32 build: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same
+    command, FETCH_SIZE doubled per MI355X_MICROARCH.md) — PMC passes cannot run inside the timed process, so the figure
+    comes from a file, and its PROVENANCE is returned with it: the file, the commit and kernel-source hash it was taken
+    at, and whether that hash equals the sources of the library that is running now.  (None, None) when no PMC record
+    matches the kernel that ran."""
+    from wedetect_amd.build import source_hash
     syms = KERNEL_SYMBOL.get(tag)
     if syms is None:
-        return None
+        return None, None
     syms = [syms] if isinstance(syms, str) else syms
-    for name in (("r02_traffic.json", "r01_fp16x3_traffic.json") if tag.startswith("fp16x3") else ("r01_traffic.json",)):
+    for name in (("r03_traffic.json", "r02_traffic.json", "r01_fp16x3_traffic.json") if tag.startswith("fp16x3") else ("r01_traffic.json",)):
         try:
-            rec = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
+            doc = json.load(open(os.path.join(ROOT, "profiles", name)))
+            rec = doc["kernels"]
             n = sum(rec[s]["launches"] for s in syms)
-            return round(sum(rec[s]["hbm_bytes_per_launch"] * rec[s]["launches"] for s in syms) / n)
+            val = round(sum(rec[s]["hbm_bytes_per_launch"] * rec[s]["launches"] for s in syms) / n)
+            now = source_hash()
+            return val, {"file": f"profiles/{name}", "commit": doc.get("commit"), "kernel_source_sha256": doc.get("kernel_source_sha256"),
+                         "running_kernel_source_sha256": now, "taken_on_these_sources": doc.get("kernel_source_sha256") == now}
         except Exception:
             continue
-    return None
+    return None, None
 HBM_PEAK_GBS = 8000.0
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)      # SURVEY.md 8(d): >= 50 timed iterations after >= 10 warm-ups
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--arch", default="base")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--size", type=int, default=640)
@@ -103,7 +114,7 @@ def parse():
     ap.add_argument("--no-fp32-reference", action="store_true",
                     help="skip the short native-fp32 run that is reported beside an fp16x3 result (N = 1 only)")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the host-fed (PCIe-inclusive) leg (N = 1 only)")
-    ap.add_argument("--cpu-images", type=int, default=8)
+    ap.add_argument("--cpu-runs", type=int, default=5, help="timed CPU-oracle passes per leg (median reported; 3 warm-ups)")
     return ap.parse_args()
 
 
@@ -183,9 +194,10 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(arch, size, classes, n_images):
-    """The oracle (CPU port of the reference's PyTorch path) on a bounded sample: n_images
-    single-image passes of the same workload, all host cores."""
+def cpu_baseline(arch, size, classes, runs):
+    """The oracle (CPU port of the reference's PyTorch path) on a bounded sample, SURVEY.md 8(d) protocol: all usable
+    host cores, the same synthetic workload at B = 1 (3 warm-ups + ``runs`` timed passes) and B = 8 (1 warm-up + 3 timed
+    passes), MEDIAN reported.  ``value`` is the better of the two legs in images/s."""
     from oracle import postprocess as opp
     from oracle import ref_cpu as orc
     from wedetect_amd import weights as W
@@ -194,19 +206,26 @@ def cpu_baseline(arch, size, classes, n_images):
     a = get_arch(arch)
     sd = orc.to_torch(W.make_state_dict(arch))
     text = torch.from_numpy(W.make_text_bank(classes))
-    imgs = W.make_images(n_images + 1, size, size)
-    times = []
+    imgs = W.make_images(8, size, size)
+
+    def one_pass(b, i0):
+        t0 = time.perf_counter()
+        _, p = orc.forward_features(sd, a, imgs[i0:i0 + b])
+        flat = orc.head_flat(sd, p, text, normalize_text=True)
+        for i in range(b):
+            opp.mmdet_predict_image(flat["boxes"][i].numpy(), flat["scores"][i].numpy(), None, (1.0, 1.0), (size, size))
+        return time.perf_counter() - t0
+    legs = {}
     with torch.no_grad():
-        for i in range(n_images + 1):
-            t0 = time.perf_counter()
-            _, p = orc.forward_features(sd, a, imgs[i:i + 1])
-            flat = orc.head_flat(sd, p, text, normalize_text=True)
-            opp.mmdet_predict_image(flat["boxes"][0].numpy(), flat["scores"][0].numpy(), None, (1.0, 1.0), (size, size))
-            times.append(time.perf_counter() - t0)
-    t = float(np.mean(times[1:]))      # first pass = warm-up
-    return dict(value=round(1.0 / t, 4), unit="images/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{n_images} single-image passes of the same {arch}@{size} K={classes} path "
-                       f"(oracle/ref_cpu.py + oracle/postprocess.py, fp32, torch {torch.__version__}) after 1 warm-up")
+        for b, warm, timed in ((1, 3, runs), (8, 1, 3)):
+            ts = [one_pass(b, i % (8 // b) * b) for i in range(warm + timed)][warm:]
+            legs[f"b{b}"] = {"images_per_s": round(b / float(np.median(ts)), 4), "median_s_per_pass": round(float(np.median(ts)), 4),
+                             "timed_passes": timed, "warmups": warm}
+    best = max(legs.values(), key=lambda v: v["images_per_s"])
+    return dict(value=best["images_per_s"], unit="images/s", cores=torch.get_num_threads(), kind="port", legs=legs,
+                sample=f"the same {arch}@{size} K={classes} path (oracle/ref_cpu.py + oracle/postprocess.py: network, mmcv-form NMS; "
+                       f"fp32, torch {torch.__version__}) at batch 1 ({runs} timed passes after 3 warm-ups) and batch 8 (3 after 1); "
+                       f"median per leg, value = the faster leg")
 
 
 def fp32_reference_run(args, tower, images, text, meta, uni, steps=5):
@@ -293,13 +312,39 @@ def host_fed_run(tower, images, text, meta, uni, steps):
             "kept_rows_last_image": int(h_out["count"][-1])}
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, rendezvous on
+    127.0.0.1) and pass their output through — rank 0 prints the one JSON line, everything else goes to stderr."""
+    import socket
+    import subprocess
+    share = os.environ.get("WEDETECT_BENCH_SHARE_GPU") == "1"
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n and not share:
+        print(f"bench.py: --gpus {n} asked but {have} HIP device(s) visible; refusing to report a smaller job as n_gpus={n} "
+              f"(WEDETECT_BENCH_SHARE_GPU=1 WEDETECT_BENCH_BACKEND=gloo is the single-GPU dry run)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ, WEDETECT_BENCH_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // n)))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE {world}")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE {world}: the job must have exactly the asked number of ranks")
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     # dry-run hooks for a single-GPU box: WEDETECT_BENCH_SHARE_GPU=1 puts every rank on device 0 and
     # WEDETECT_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device)
@@ -408,6 +453,8 @@ def main():
                   else "split_gemm_pingpong" if "pingpong" in dom_tag else "split_gemm")
         dom_kernel = (f"{dom_fn}_kernel<{dom_tag}> (3 x v_mfma_f32_32x32x16_f16 per product)" if dom_split
                       else f"conv_gemm_kernel<{dom_tag}> (fp32 MFMA 16x16x4)")
+        traffic, traffic_src = (measured_traffic(dom_tag) if (B, S, K, args.arch, args.mode) == (32, 640, 80, "base", "detect")
+                                else (None, None))
         out = {
             "metric": f"images/s at {S}x{S} (WeDetect-{args.arch.capitalize()} image tower + {K}-class similarity + top-k/NMS)",
             "value": round(world * B * args.steps / dt, 3),
@@ -439,8 +486,8 @@ def main():
                          **({"peak_note": f"fp16 dense MFMA peak {F16_MFMA_PEAK_TFLOPS} / {SPLIT_PASSES} passes per product",
                              "mfma_issued_tflops": round(SPLIT_PASSES * dom["tflops"], 1),
                              "frac_of_fp16_peak": round(SPLIT_PASSES * dom["tflops"] / F16_MFMA_PEAK_TFLOPS, 4)} if dom_split else {}),
-                         "traffic": measured_traffic(dom_tag) if (B, S, K, args.arch, args.mode) == (32, 640, 80, "base", "detect") else None,
-                         "traffic_unit": "HBM bytes per launch (PMC, separate rocprofv3 passes)",
+                         "traffic": traffic, "traffic_provenance": traffic_src,
+                         "traffic_unit": "HBM bytes per launch (PMC, separate rocprofv3 passes; see traffic_provenance)",
                          "timing": "HIP events stamped by each kernel's own dispatch (hipExtLaunchKernelGGL via "
                                    f"wd_time_next_gemm) on the launch stream, every GEMM launch of the last {n_inst} of the "
                                    f"{args.steps} timed steps (stamping all steps would slow the step it measures by 2.4 %)",
@@ -458,11 +505,11 @@ def main():
             # the same workload with native fp32 MFMA arithmetic, measured in this run (same images, weights, bank)
             out["fp32_mode"] = fp32_reference_run(args, tower, images, text, meta, uni)
         if world == 1 and not args.no_host_fed:
-            out["host_fed"] = host_fed_run(tower, images, text, meta, uni, args.steps)
+            out["host_fed"] = host_fed_run(tower, images, text, meta, uni, min(args.steps, 20))
         if per_rank is not None:
             out["per_rank"] = per_rank
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.arch, S, K, args.cpu_images)
+            out["cpu_baseline"] = cpu_baseline(args.arch, S, K, args.cpu_runs)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

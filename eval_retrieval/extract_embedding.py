@@ -7,9 +7,11 @@
 One process per GPU over RCCL; the image list is sharded contiguously per rank exactly like the reference's
 ``InferenceSampler`` (1620-1644); each rank runs the Uni detector (letterbox, tower, top-k, NMS, embedding gather all
 on the device, real batches instead of the reference's first-image-of-each-batch); the class names go through the
-XLM-R text tower in chunks of 80 (1708-1713).  The final exchange is ONE ragged ``all_gather_into_tensor`` of the
-fixed-shape result blocks ([N_local, 300, 768] embeddings + counts + scales + bias + ids) instead of four pickled
-``all_gather_object`` calls (1753-1756); rank 0 writes ``{dataset}_{model}.pth`` in the reference's format
+XLM-R text tower in chunks of 80 (1708-1713).  The exchange replaces the four pickled ``all_gather_object`` calls
+(1753-1756) by a pipelined ``all_gather_into_tensor`` of each step's fixed-shape result block ([B, 300, 768]
+embeddings + counts + scales + bias + ids, ``parallel.StreamedRecordCollector``): device memory stays at two staging
+slots whatever the size of the image set, and only rank 0 keeps anything — the kept rows, on the host, as the
+reference does; rank 0 writes ``{dataset}_{model}.pth`` in the reference's format
 (1763-1774: ``{"image_embedding": [{image_id, embedding, scale, bias}], "text_embedding"}``), which
 ``retrieval_metric.py`` reads unchanged.
 
@@ -34,7 +36,7 @@ if ROOT not in sys.path:
 from generate_proposal import load_uni_detector  # noqa: E402
 from wedetect_amd.apis import load_checkpoint_file  # noqa: E402
 from wedetect_amd.evaluate import retrieval_records, save_retrieval_file  # noqa: E402
-from wedetect_amd.parallel import gather_ragged, shard_range  # noqa: E402
+from wedetect_amd.parallel import StreamedRecordCollector, shard_range  # noqa: E402
 from wedetect_amd.text import XLMRobertaLanguageBackbone  # noqa: E402
 
 DATASETS = {
@@ -134,38 +136,32 @@ def run(args, tokenizer=None):
     loader = torch.utils.data.DataLoader(dataset, batch_size=args.batch_size, num_workers=args.num_workers,
                                          pin_memory=False, drop_last=False, collate_fn=collate_fn, shuffle=False)
     r = model.num_proposals
-    n_local = len(dataset)
-    emb = torch.zeros(n_local, r, 768, dtype=torch.float32, device=dev)
-    scl = torch.zeros(n_local, r, dtype=torch.float32, device=dev)
-    bia = torch.zeros(n_local, r, dtype=torch.float32, device=dev)
-    cnt = torch.zeros(n_local, dtype=torch.int32, device=dev)
-    ids = torch.zeros(n_local, dtype=torch.int64, device=dev)
-    at = 0
+    # every rank runs the same number of steps (the first ranks of the split hold one image more): ranks whose shard
+    # is exhausted contribute count-0 blocks
+    n_steps = -(-len(shard_range(len(full.images), world, 0)) // args.batch_size)
+    collector = StreamedRecordCollector(args.batch_size, r, 768, dev)
     try:
         from tqdm import tqdm
         it = tqdm(loader, disable=rank != 0)
     except ImportError:
         it = loader
+    steps = 0
     with torch.no_grad():
         for inputs in it:
-            b = len(inputs)
             res, counts, tower = model.forward_batch([x["image"] for x in inputs])
             ls = torch.tensor(tower.lvl_logit_scale, dtype=torch.float32, device=dev)
             cb = torch.tensor(tower.lvl_bias, dtype=torch.float32, device=dev)
             lvl = tower.level_of(res["anchors"])
-            emb[at:at + b] = res["embeddings"]
-            scl[at:at + b] = ls[lvl]
-            bia[at:at + b] = cb[lvl]
-            cnt[at:at + b] = res["count"]
-            ids[at:at + b] = torch.tensor([x["id"] for x in inputs], dtype=torch.int64, device=dev)
-            at += b
+            collector.step(res["embeddings"], res["count"], ls[lvl], cb[lvl],
+                           torch.tensor([x["id"] for x in inputs], dtype=torch.int64, device=dev))
+            steps += 1
+        for _ in range(steps, n_steps):
+            collector.pad_step()
+    records = collector.finish()
     dist.barrier()
-    merged = gather_ragged(dict(image_id=ids, embedding=emb, scale=scl, bias=bia, count=cnt))
     out_path = args.output or f"{args.dataset}_{args.model}.pth"
     if rank == 0:
         print(f"Evaluating {args.dataset} ...")
-        records = retrieval_records(merged["image_id"].tolist(), merged["embedding"], merged["count"], merged["scale"],
-                                    merged["bias"])
         save_retrieval_file(out_path, records, text_embeddings)
         print(f"wrote {out_path}: {len(records)} images, {tuple(text_embeddings.shape)} text bank")
     dist.barrier()

@@ -367,21 +367,47 @@ int wd_topk_candidates(const float* scores, int32_t batch, int64_t n_per_image, 
  *                          (yolo_world_head.py:728-746);
  *   pre_nms_rescale == 0 : Uni order — NMS in network pixels, then (box - pad) / scale and
  *                          clamp (generate_proposal.py:1106-1115, 1210).
- *   A box i suppresses a later box j of the same class iff
- *       inter / (area_i + area_j - inter) > iou_thr        (fp32, IEEE division)
+ *   In every form a box i suppresses a later, not yet suppressed box j that it is compared
+ *   with iff   inter / (area_i + area_j - inter) > iou_thr     (fp32, IEEE division,
+ *   area = (x2-x1)*(y2-y1), inter = max(0,.)*max(0,.)) — the loop of torchvision's
+ *   nms_kernel_impl and of mmcv's nms_cpu (offset 0).  nms_mode selects WHICH boxes are
+ *   compared, per image, from its candidate count n (the libraries' own branch conditions):
+ *     WD_NMS_VANILLA      same label only, boxes as given (== torchvision _batched_nms_vanilla).
+ *     WD_NMS_TORCHVISION  torchvision.ops.batched_nms (torchvision/ops/boxes.py), the call at
+ *                         generate_proposal.py:1210: 4*n > mode_param -> vanilla; otherwise
+ *                         _batched_nms_coordinate_trick: boxes + label*(max over all 4n
+ *                         coordinates + 1) in fp32, then class-AGNOSTIC NMS.  mode_param = 4000
+ *                         (CPU tensors; 20000 reproduces a run on a GPU).  torchvision compares
+ *                         the fp32 IoU with a C++ double threshold: pass iou_thr rounded DOWN to
+ *                         fp32 (largest float <= the Python value) for the same decisions.
+ *     WD_NMS_MMCV         mmcv.ops.batched_nms 2.1.0 (mmcv/ops/nms.py) as reached from mmdet's
+ *                         _bbox_post_process (yolo_world_head.py:740-744, config/wedetect_base.py:18-25):
+ *                         ALWAYS boxes + label*(max+1) in fp32; n < mode_param (split_thr,
+ *                         default 10000) -> one class-agnostic NMS, else NMS per class on the
+ *                         offset boxes.  float threshold: pass iou_thr rounded to nearest.
+ *   (The offset forms quantise the boxes — 0.008 px at label 79, 0.125 px at label 1202 on
+ *   1280-px coordinates — and the agnostic ones let boxes of different classes meet when
+ *   coordinates fall below -1; both effects are reproduced, not corrected.)
  *   Outputs (row stride max_out): out_boxes [batch,max_out,4], out_scores, out_labels
  *   (int32), out_anchors (int32), out_count [batch]; if embed != NULL also
  *   out_embed [batch, max_out, embed_dim] = embed[b, anchor, :].
+ *   Workspace: wd_nms_workspace_bytes(batch) bytes, 4-byte aligned (per-image coordinate
+ *   bounds of the offset forms; may be NULL for WD_NMS_VANILLA).
  * Replaces torchvision.ops.batched_nms(...)[:300] (generate_proposal.py:1210),
  * mmdet _bbox_post_process -> mmcv.ops.batched_nms + max_per_img
  * (yolo_world_head.py:740-744), and the index gathers at generate_proposal.py:1208-1217.
  * ---------------------------------------------------------------------------------- */
+#define WD_NMS_VANILLA 0
+#define WD_NMS_TORCHVISION 1
+#define WD_NMS_MMCV 2
+int64_t wd_nms_workspace_bytes(int32_t batch);
 int wd_nms_gather(const int32_t* cand_idx, const float* cand_score, const int32_t* cand_count,
                   int32_t cand_stride, const float* boxes, int32_t n_anchor, int32_t k,
-                  const float* meta, float iou_thr, int32_t max_out,
+                  const float* meta, float iou_thr, int32_t max_out, int32_t nms_mode, int32_t mode_param,
                   const float* embed, int32_t embed_dim,
                   float* out_boxes, float* out_scores, int32_t* out_labels, int32_t* out_anchors,
-                  int32_t* out_count, float* out_embed, int32_t batch, void* stream);
+                  int32_t* out_count, float* out_embed, int32_t batch,
+                  void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * wd_retrieval_max — object-retrieval similarity with fused epilogue:

@@ -12,13 +12,25 @@ Reference sites:
   predict_by_feat per-image loop   wedetect/models/dense_heads/yolo_world_head.py:680-748
   un-letterbox + clamp             generate_proposal.py:1106-1115
   retrieval similarity             eval_retrieval/retrieval_metric.py:367-377
-  batched NMS: torchvision.ops.batched_nms (call generate_proposal.py:1210) and
-  mmcv.ops.batched_nms (call via _bbox_post_process, yolo_world_head.py:740-744) —
-  third-party native code, absent here: **parity unpinned**.  Restated from their
-  documented behaviour: per class, greedy in descending score; box i suppresses a
-  later box j of the same class iff  inter / (area_i + area_j - inter) > thr  with
-  area = (x2-x1)*(y2-y1), inter = max(0, .)*max(0, .), fp32, evaluated left to right;
-  kept indices are returned in descending-score order.
+  batched NMS — third-party native code, absent from /root/reference and from this image
+  (**parity unpinned**: no binary to run against), restated from the PUBLISHED sources, branch
+  for branch, in the section "third-party NMS" below:
+    torchvision.ops.batched_nms   (call generate_proposal.py:1210)    torchvision/ops/boxes.py:
+        batched_nms / _batched_nms_coordinate_trick / _batched_nms_vanilla, CPU kernel
+        torchvision/csrc/ops/cpu/nms_kernel.cpp: nms_kernel_impl
+    mmcv.ops.batched_nms 2.1.0    (call mmdet BaseDenseHead._bbox_post_process, reached from
+        yolo_world_head.py:740-744 with config/wedetect_base.py:18-25 nms=dict(type='nms',
+        iou_threshold=0.7))       mmcv/ops/nms.py: batched_nms / nms / NMSop.forward, CPU kernel
+        mmcv/ops/csrc/pytorch/cpu/nms.cpp: nms_cpu
+  Both CPU kernels take the boxes in descending score (their internal sorts are given the
+  defined total order: stable), and box i suppresses a later, not yet suppressed box j iff
+  inter / (area_i + area_j - inter) > thr, area = (x2-x1)*(y2-y1), inter = max(0,.)*max(0,.),
+  fp32, evaluated left to right.  Class awareness is NOT a label test in either library:
+  it is the coordinate offset  boxes + label * (boxes.max() + 1)  (fp32: it quantises the
+  boxes — 0.008 px at label 79, 0.125 px at label 1202 on 1280-px coordinates) followed by a
+  class-agnostic NMS, except that torchvision switches to a per-class loop on the ORIGINAL
+  boxes above 4000 box coordinates on the CPU (20000 on a GPU) and mmcv to a per-class loop
+  on the OFFSET boxes from split_thr = 10000 candidates.
 """
 from __future__ import annotations
 
@@ -71,8 +83,10 @@ def _iou_f32(bi: np.ndarray, bj: np.ndarray) -> np.ndarray:
 
 def batched_nms(boxes: np.ndarray, scores: np.ndarray, labels: np.ndarray, thr: float,
                 max_keep: Optional[int] = None, stats: Optional[dict] = None) -> np.ndarray:
-    """Class-aware greedy NMS.  Inputs must already be in the defined total order
-    (they are: the output of filter_scores_and_topk).  Returns kept candidate indices
+    """Label-test form of class-aware greedy NMS == torchvision's _batched_nms_vanilla on sorted input (one global
+    loop instead of one per class; tests/test_cpu.py checks the two equal).  It is what WD_NMS_VANILLA computes; the
+    reference's call sites go through torchvision_batched_nms / mmcv_batched_nms below.  Inputs must already be in the
+    defined total order (they are: the output of filter_scores_and_topk).  Returns kept candidate indices
     in that order.  ``max_keep`` stops early — identical to slicing the full result,
     because whether a box is kept depends only on earlier kept boxes.
 
@@ -112,6 +126,137 @@ def batched_nms(boxes: np.ndarray, scores: np.ndarray, labels: np.ndarray, thr: 
     return np.asarray(keep, dtype=np.int64)
 
 
+# ------------------------------------------------------------------------------------------ third-party NMS
+TV_TRICK_MAX_NUMEL = {"cpu": 4000, "cuda": 20000}     # torchvision/ops/boxes.py: batched_nms
+MMCV_SPLIT_THR = 10000                                   # mmcv/ops/nms.py: batched_nms, nms_cfg default
+
+
+def _merge_stats(stats: Optional[dict], iou_margin: float, pair_gap: float) -> None:
+    if stats is None:
+        return
+    stats["iou_margin"] = min(stats.get("iou_margin", 1.0), iou_margin)
+    stats["pair_gap"] = min(stats.get("pair_gap", 1.0), pair_gap)
+
+
+def nms_greedy(boxes: np.ndarray, scores: np.ndarray, thr: float, compare: str = "f32",
+               stats: Optional[dict] = None, max_keep: Optional[int] = None) -> np.ndarray:
+    """Class-AGNOSTIC greedy NMS, the loop both CPU kernels run:
+      torchvision/csrc/ops/cpu/nms_kernel.cpp nms_kernel_impl  (``compare="double"``: ``iou_threshold`` is a C++
+          double there, the fp32 ``ovr`` is promoted for ``ovr > iou_threshold``; order = stable sort of the scores)
+      mmcv/ops/csrc/pytorch/cpu/nms.cpp nms_cpu, offset = 0     (``compare="f32"``: ``float iou_threshold``)
+    Returns kept indices into ``boxes`` in descending score (ties: index ascending).  ``max_keep`` stops early — equal
+    to slicing the full result, a box's fate depends on earlier kept boxes only."""
+    boxes = np.ascontiguousarray(boxes, dtype=f32)
+    scores = np.ascontiguousarray(scores, dtype=f32)
+    n = boxes.shape[0]
+    if n == 0:
+        return np.zeros(0, dtype=np.int64)
+    order = np.argsort(-scores, kind="stable")
+    bs = boxes[order]
+    areas = (bs[:, 2] - bs[:, 0]) * (bs[:, 3] - bs[:, 1])
+    t64, t32 = float(thr), f32(thr)
+    suppressed = np.zeros(n, dtype=bool)
+    keep: List[int] = []
+    iou_margin, pair_gap = 1.0, 1.0
+    for _i in range(n):
+        if suppressed[_i]:
+            continue
+        keep.append(_i)
+        if max_keep is not None and len(keep) >= max_keep:
+            break
+        rest = np.nonzero(~suppressed[_i + 1:])[0] + _i + 1
+        if not rest.size:
+            continue
+        bi, bj = bs[_i], bs[rest]
+        w = np.maximum(f32(0), np.minimum(bi[2], bj[:, 2]) - np.maximum(bi[0], bj[:, 0]))
+        h = np.maximum(f32(0), np.minimum(bi[3], bj[:, 3]) - np.maximum(bi[1], bj[:, 1]))
+        inter = w * h
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ovr = inter / (areas[_i] + areas[rest] - inter)
+        sup = (ovr.astype(np.float64) > t64) if compare == "double" else (ovr > t32)
+        suppressed[rest[sup]] = True
+        if stats is not None:
+            o64 = ovr.astype(np.float64)
+            o64 = o64[np.isfinite(o64)]
+            if o64.size:
+                iou_margin = min(iou_margin, float(np.min(np.abs(o64 - (t64 if compare == "double" else float(t32))))))
+            if np.any(sup):
+                ss = scores[order]
+                pair_gap = min(pair_gap, float(np.min(ss[_i].astype(np.float64) - ss[rest[sup]].astype(np.float64))))
+    _merge_stats(stats, iou_margin, pair_gap)
+    return order[np.asarray(keep, dtype=np.int64)]
+
+
+def coordinate_offsets(boxes: np.ndarray, idxs: np.ndarray) -> np.ndarray:
+    """``max_coordinate = boxes.max(); offsets = idxs.to(boxes) * (max_coordinate + torch.tensor(1).to(boxes));
+    boxes_for_nms = boxes + offsets[:, None]`` — the same three lines in torchvision/ops/boxes.py
+    (_batched_nms_coordinate_trick) and mmcv/ops/nms.py (batched_nms).  All fp32."""
+    boxes = np.ascontiguousarray(boxes, dtype=f32)
+    max_coordinate = boxes.max()
+    offsets = idxs.astype(f32) * (max_coordinate + f32(1))
+    return boxes + offsets[:, None]
+
+
+def torchvision_batched_nms(boxes: np.ndarray, scores: np.ndarray, idxs: np.ndarray, iou_threshold: float,
+                            device_type: str = "cpu", stats: Optional[dict] = None,
+                            max_keep: Optional[int] = None) -> np.ndarray:
+    """torchvision.ops.batched_nms (torchvision/ops/boxes.py), the function generate_proposal.py:1210 calls:
+    ``if boxes.numel() > (4000 if boxes.device.type == "cpu" else 20000): _batched_nms_vanilla else
+    _batched_nms_coordinate_trick``.  ``max_keep`` is the caller's ``[:num_proposals]`` applied early where that
+    is exact (the agnostic call); the vanilla branch runs every class to the end, as upstream."""
+    boxes = np.ascontiguousarray(boxes, dtype=f32)
+    scores = np.ascontiguousarray(scores, dtype=f32)
+    if boxes.size > TV_TRICK_MAX_NUMEL[device_type]:
+        # _batched_nms_vanilla: nms() per class on the boxes as given
+        keep_mask = np.zeros(scores.shape[0], dtype=bool)
+        for class_id in np.unique(idxs):
+            curr_indices = np.nonzero(idxs == class_id)[0]
+            curr_keep = nms_greedy(boxes[curr_indices], scores[curr_indices], iou_threshold, "double", stats)
+            keep_mask[curr_indices[curr_keep]] = True
+        keep_indices = np.nonzero(keep_mask)[0]
+        out = keep_indices[np.argsort(-scores[keep_indices], kind="stable")]
+        return out if max_keep is None else out[:max_keep]
+    # _batched_nms_coordinate_trick
+    if boxes.size == 0:
+        return np.zeros(0, dtype=np.int64)
+    return nms_greedy(coordinate_offsets(boxes, idxs), scores, iou_threshold, "double", stats, max_keep)
+
+
+def mmcv_batched_nms(boxes: np.ndarray, scores: np.ndarray, idxs: np.ndarray, nms_cfg: dict,
+                     stats: Optional[dict] = None, max_keep: Optional[int] = None) -> np.ndarray:
+    """mmcv.ops.batched_nms (mmcv/ops/nms.py, 2.1.0) for ``nms_cfg = dict(type='nms', iou_threshold=...)``
+    [+ ``split_thr``, ``class_agnostic``]; returns ``keep`` (the ``dets`` it also returns are boxes[keep] | scores[keep]).
+    ``nms`` -> NMSop.forward: score_threshold 0, max_num -1, offset 0 -> ext_module.nms = nms_cpu.
+    ``max_keep`` is mmdet's ``results[:cfg.max_per_img]`` (BaseDenseHead._bbox_post_process) applied early where exact."""
+    cfg = dict(nms_cfg)
+    class_agnostic = cfg.pop("class_agnostic", False)
+    assert cfg.pop("type", "nms") == "nms"
+    split_thr = cfg.pop("split_thr", MMCV_SPLIT_THR)
+    thr = cfg.pop("iou_threshold")
+    assert not cfg, f"unsupported nms_cfg keys {sorted(cfg)}"
+    boxes = np.ascontiguousarray(boxes, dtype=f32)
+    scores = np.ascontiguousarray(scores, dtype=f32)
+    boxes_for_nms = boxes if class_agnostic else coordinate_offsets(boxes, idxs)
+    if boxes_for_nms.shape[0] < split_thr:
+        return nms_greedy(boxes_for_nms, scores, thr, "f32", stats, max_keep)
+    total_mask = np.zeros(scores.shape[0], dtype=bool)
+    for id_ in np.unique(idxs):
+        mask = np.nonzero(idxs == id_)[0]
+        keep = nms_greedy(boxes_for_nms[mask], scores[mask], thr, "f32", stats)
+        total_mask[mask[keep]] = True
+    keep = np.nonzero(total_mask)[0]
+    keep = keep[np.argsort(-scores[keep], kind="stable")]
+    return keep if max_keep is None else keep[:max_keep]
+
+
+def _finish_stats(stats: dict, scores: np.ndarray, keep: np.ndarray) -> dict:
+    ks = scores[keep].astype(np.float64)
+    stats.setdefault("iou_margin", 1.0)
+    stats.setdefault("pair_gap", 1.0)
+    stats["kept_gap"] = float(np.min(-np.diff(ks))) if ks.size > 1 else 1.0
+    return stats
+
+
 def cut_gap(scores: np.ndarray, score_thr: float, topk: int) -> float:
     """Score gap at the ``nms_pre`` cut of filter_scores_and_topk: (last candidate taken) - (first one left out); 1.0
     when every valid candidate fits."""
@@ -138,14 +283,16 @@ def unletterbox(boxes: np.ndarray, pad_xy: Tuple[float, float], ratio: float,
 def uni_predict_image(boxes: np.ndarray, embed: np.ndarray, scores: np.ndarray,
                       level_of: np.ndarray, logit_scale: np.ndarray, contrast_bias: np.ndarray,
                       num_proposals: int = 300, nms_pre: int = 30000, iou_thr: float = 0.7,
-                      score_thr: float = 0.0) -> Dict[str, np.ndarray]:
+                      score_thr: float = 0.0, device_type: str = "cpu") -> Dict[str, np.ndarray]:
     """One image of SimpleYOLOWorldDetector.head_predict (generate_proposal.py:1197-1217,
     with the extra outputs of extract_embedding.py:1247-1259).  Boxes stay in
-    letterboxed network coordinates (NMS runs before the un-letterbox there)."""
+    letterboxed network coordinates (NMS runs before the un-letterbox there);
+    ``torchvision.ops.batched_nms(bbox, scores, labels, 0.7)[:num_proposals]`` (1210)."""
     s, labels, anchors = filter_scores_and_topk(scores, score_thr, nms_pre)
     cand_boxes = boxes[anchors]
     stats: dict = {}
-    keep = batched_nms(cand_boxes, s, labels, iou_thr, max_keep=num_proposals, stats=stats)
+    keep = torchvision_batched_nms(cand_boxes, s, labels, iou_thr, device_type, stats, max_keep=num_proposals)
+    _finish_stats(stats, s, keep)
     stats["cut_gap"] = cut_gap(scores, score_thr, nms_pre)
     a = anchors[keep]
     lv = level_of[a]
@@ -169,21 +316,24 @@ def clamp_boxes(b: np.ndarray, ori_hw) -> np.ndarray:
 
 
 def mmdet_predict_image_from_candidates(cand_boxes, s, labels, pad_param, scale_factor, ori_hw,
-                                        iou_thr: float = 0.7, max_per_img: int = 300):
+                                        iou_thr: float = 0.7, max_per_img: int = 300, nms_cfg: Optional[dict] = None):
     """Tail of predict_by_feat once candidates exist (yolo_world_head.py:724-746): rescale
-    to original pixels, THEN NMS, [:max_per_img], clamp.  pad_param = (top, bottom, left,
-    right); scale_factor = (w, h)."""
+    to original pixels, THEN mmdet's _bbox_post_process (``if with_nms and results.bboxes.numel() > 0:
+    batched_nms(bboxes, scores, labels, cfg.nms)``; ``results[:cfg.max_per_img]``), clamp.
+    pad_param = (top, bottom, left, right); scale_factor = (w, h)."""
     b = cand_boxes.astype(f32)
     pad = (0.0, 0.0) if pad_param is None else (pad_param[2], pad_param[0])
     b = rescale_boxes(b, pad, scale_factor)
     stats: dict = {}
-    keep = batched_nms(b, s, labels, iou_thr, max_keep=max_per_img, stats=stats)
+    cfg = dict(type="nms", iou_threshold=iou_thr) if nms_cfg is None else nms_cfg
+    keep = mmcv_batched_nms(b, s, labels, cfg, stats, max_keep=max_per_img) if b.size else np.zeros(0, np.int64)
+    _finish_stats(stats, np.asarray(s, dtype=f32), keep)
     return dict(bboxes=clamp_boxes(b[keep], ori_hw), keep=keep, margins=stats)
 
 
 def mmdet_predict_image(boxes: np.ndarray, scores: np.ndarray, pad_param, scale_factor,
                         ori_hw: Tuple[int, int], score_thr: float = 0.001, nms_pre: int = 30000,
-                        iou_thr: float = 0.7, max_per_img: int = 300) -> Dict[str, np.ndarray]:
+                        iou_thr: float = 0.7, max_per_img: int = 300, nms_cfg: Optional[dict] = None) -> Dict[str, np.ndarray]:
     """One image of YOLOWorldHead.predict_by_feat, multi_label=True
     (yolo_world_head.py:680-748): filter/top-k, rescale to original pixels, THEN NMS,
     [:max_per_img], clamp."""
@@ -191,7 +341,7 @@ def mmdet_predict_image(boxes: np.ndarray, scores: np.ndarray, pad_param, scale_
     if s.shape[0] == 0:
         return dict(bboxes=np.zeros((0, 4), f32), scores=s, labels=labels, anchors=anchors)
     r = mmdet_predict_image_from_candidates(boxes[anchors], s, labels, pad_param, scale_factor, ori_hw,
-                                            iou_thr, max_per_img)
+                                            iou_thr, max_per_img, nms_cfg)
     keep = r["keep"]
     r["margins"]["cut_gap"] = cut_gap(scores, score_thr, nms_pre)
     return dict(bboxes=r["bboxes"], scores=s[keep], labels=labels[keep], anchors=anchors[keep], margins=r["margins"])

@@ -21,7 +21,7 @@ def run():
     elif stage == "topk":
         from wedetect_amd import lib as L
         L.topk_candidates(tower.scores, 1, tower.ntot * 80, 0.001, tower.nms_pre, tower.cand_idx, tower.cand_score, tower.cand_count, tower.topk_ws)
-    elif stage == "post": tower.postprocess(tower.scores.view(1, tower.ntot, 80), 0.001, meta)
+    elif stage == "post": tower.postprocess(tower.scores.view(1, tower.ntot, 80), 0.001, meta, nms="mmcv")
     elif stage == "all": tower.detect(x, text, meta, normalize_text=True, score_thr=0.001, with_embed=True)
 tower.detect(x, text, meta, normalize_text=True, score_thr=0.001, with_embed=True)
 torch.cuda.synchronize()

@@ -12,8 +12,12 @@ Runs only in the build container (needs /root/reference; CPU).  It
   5. writes small .npz fixtures (checksums, sampled elements, final detections).
 
 Only data is written: no reference source text is copied.  torchvision is absent, so
-``torchvision.ops.batched_nms`` is bound to the oracle's restatement while the
-reference's head_predict runs (NMS parity stays "unpinned", see oracle/__init__.py).
+``torchvision.ops.batched_nms`` is bound to the oracle's restatement of THAT function
+(oracle.postprocess.torchvision_batched_nms: coordinate trick up to 4000 box coordinates,
+per-class loop above) while the reference's head_predict runs; the mmdet-path records
+(``mm.img*``) come from the oracle's restatement of mmdet's _bbox_post_process ->
+mmcv.ops.batched_nms (mmdet / mmcv are absent too).  NMS parity therefore stays
+"unpinned" (no binary to run against), see oracle/__init__.py.
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
 """
@@ -47,7 +51,7 @@ torch.manual_seed(0)
 
 # ------------------------------------------------------------------ reference import helpers
 def _nms_stub(boxes, scores, idxs, iou_threshold):
-    keep = opp.batched_nms(boxes.numpy(), scores.numpy(), idxs.numpy(), float(iou_threshold))
+    keep = opp.torchvision_batched_nms(boxes.numpy(), scores.numpy(), idxs.numpy(), float(iou_threshold), "cpu")
     return torch.from_numpy(keep)
 
 
@@ -401,11 +405,47 @@ def case_filter_topk(gp):
     np.savez_compressed(os.path.join(OUT, "filter_topk.npz"), **fx)
 
 
+def nms_hand_cases():
+    """Hand-derived vectors for the two library forms (expected keeps worked out on paper, see the comments)."""
+    f = np.float32
+    cases = {}
+    # (1) offset quantisation: label 1202, max coordinate 1280 -> S = 1281, offset 1202 * 1281 = 1539762 (exact), fp32
+    # spacing there 0.125 px.  y2 = 170.05 becomes 170.0 on the offset box: IoU = 7000 / 10000 = fp32(0.7), not > 0.7 ->
+    # kept; on the original boxes IoU = 7005 / 10000 > 0.7 -> suppressed.
+    cases["quant"] = dict(boxes=np.array([[100, 100, 200, 200], [100, 100, 200, 170.05], [1270, 1270, 1280, 1280]], f),
+                          scores=np.array([0.9, 0.8, 0.7], f), labels=np.array([1202, 1202, 0], np.int64),
+                          vanilla=[0, 2], trick=[0, 1, 2])
+    # (2) cross-class meeting: max 99 -> S = 100; the class-1 box at (-50..-1) lands exactly on the class-0 box
+    # (50..99) after its offset of 100 -> IoU 1 in the agnostic pass; a per-class loop keeps both.
+    cases["cross"] = dict(boxes=np.array([[50, 50, 99, 99], [-50, -50, -1, -1]], f), scores=np.array([0.9, 0.8], f),
+                          labels=np.array([0, 1], np.int64), vanilla=[0, 1], trick=[0])
+    # (3) threshold type: inter 3, union 10 -> ovr = fp32(0.3) = 0.300000012.  torchvision compares with the double 0.3
+    # (suppressed), mmcv with float(0.3) = the same fp32 value (not >: kept).
+    cases["thr03"] = dict(boxes=np.array([[0, 0, 1, 6.5], [0, 3.5, 1, 10]], f), scores=np.array([0.9, 0.8], f),
+                          labels=np.array([0, 0], np.int64), thr=0.3, torchvision=[0], mmcv=[0, 1])
+    return cases
+
+
 def case_nms():
-    """Hand-made NMS unit cases for the build-defined semantics (parity unpinned)."""
-    print("== NMS unit cases (oracle-defined)")
+    """NMS unit cases: hand-derived vectors + oracle-authored regression records for the three forms (parity unpinned)."""
+    print("== NMS unit cases (oracle restatement of torchvision / mmcv; hand vectors)")
     f = np.float32
     fx = {}
+    for name, c in nms_hand_cases().items():
+        thr = c.get("thr", 0.7)
+        bx, sc, lb = c["boxes"], c["scores"], c["labels"]
+        tv = opp.torchvision_batched_nms(bx, sc, lb, thr, "cpu")                       # numel <= 4000: coordinate trick
+        mm = opp.mmcv_batched_nms(bx, sc, lb, dict(type="nms", iou_threshold=thr))     # n < 10000: one agnostic call
+        mm_split = opp.mmcv_batched_nms(bx, sc, lb, dict(type="nms", iou_threshold=thr, split_thr=1))
+        va = opp.batched_nms(bx, sc, lb, thr)
+        if "trick" in c:
+            assert tv.tolist() == c["trick"] and mm.tolist() == c["trick"] and va.tolist() == c["vanilla"], (name, tv, mm, va)
+        else:
+            assert tv.tolist() == c["torchvision"] and mm.tolist() == c["mmcv"], (name, tv, mm)
+        fx[f"hand.{name}.boxes"], fx[f"hand.{name}.scores"], fx[f"hand.{name}.labels"] = bx, sc, lb
+        fx[f"hand.{name}.thr"] = np.float64(thr)
+        fx[f"hand.{name}.tv"], fx[f"hand.{name}.mmcv"], fx[f"hand.{name}.mmcv_split"], fx[f"hand.{name}.vanilla"] = tv, mm, mm_split, va
+        print(f"  hand {name}: torchvision {tv.tolist()} mmcv {mm.tolist()} mmcv/per-class {mm_split.tolist()} vanilla {va.tolist()}")
     # IoU of [0,0,10,10] vs [0,0,10,7] = 0.7 exactly (not > 0.7 -> both kept);
     # vs [0,0,10,7.0001] slightly above -> suppressed.
     boxes = np.array([[0, 0, 10, 10], [0, 0, 10, 7], [0, 0, 10, 7.001], [0, 0, 10, 10], [20, 20, 30, 30],
@@ -414,7 +454,9 @@ def case_nms():
     labels = np.array([0, 0, 0, 1, 2, 2, 3, 3], dtype=np.int64)
     keep = opp.batched_nms(boxes, scores, labels, 0.7)
     fx["unit.boxes"], fx["unit.scores"], fx["unit.labels"], fx["unit.keep"] = boxes, scores, labels, keep
-    print("  unit keep:", keep.tolist())
+    fx["unit.keep_tv"] = opp.torchvision_batched_nms(boxes, scores, labels, 0.7)
+    fx["unit.keep_mmcv"] = opp.mmcv_batched_nms(boxes, scores, labels, dict(type="nms", iou_threshold=0.7))
+    print("  unit keep:", keep.tolist(), fx["unit.keep_tv"].tolist(), fx["unit.keep_mmcv"].tolist())
     g = np.random.default_rng(5)
     n = 3000
     ctr = g.random((n, 2), dtype=np.float32) * 200
@@ -425,8 +467,34 @@ def case_nms():
     keep = opp.batched_nms(boxes, scores, labels, 0.7)
     keep300 = opp.batched_nms(boxes, scores, labels, 0.7, max_keep=300)
     assert np.array_equal(keep[:300], keep300)
+    assert np.array_equal(keep, opp.torchvision_batched_nms(boxes, scores, labels, 0.7))      # 12000 coordinates: vanilla branch
     fx["rand.boxes"], fx["rand.scores"], fx["rand.labels"], fx["rand.keep"] = boxes, scores, labels, keep
+    fx["rand.keep_mmcv"] = opp.mmcv_batched_nms(boxes, scores, labels, dict(type="nms", iou_threshold=0.7))
+    fx["rand.keep_mmcv_split"] = opp.mmcv_batched_nms(boxes, scores, labels, dict(type="nms", iou_threshold=0.7, split_thr=100))
+    fx["rand.keep_tv_trick"] = opp.torchvision_batched_nms(boxes, scores, labels, 0.7, "cuda")    # 12000 <= 20000: trick
     fx["empty.keep"] = opp.batched_nms(np.zeros((0, 4), f), np.zeros((0,), f), np.zeros((0,), np.int64), 0.7)
+    # LVIS-sized labels on 1280-px coordinates, dense near-threshold pairs: the three forms must differ here
+    g = np.random.default_rng(1203)
+    n = 960
+    base = g.random((n // 2, 2), dtype=np.float32) * 1100 + 20
+    wh = g.random((n // 2, 2), dtype=np.float32) * 120 + 30
+    a = np.concatenate([base, base + wh], 1)
+    d = wh[:, 0] * f(0.3 / 1.7) + (g.random(n // 2, dtype=np.float32) - f(0.5)) * f(0.12)       # IoU ~ 0.7 +- a few 1e-4
+    b = a.copy(); b[:, 0] += d; b[:, 2] += d
+    boxes = np.concatenate([a, b], 0).astype(f)
+    boxes[0] = [1200, 1200, 1280, 1280]
+    labels = np.concatenate([g.integers(1100, 1203, n // 2)] * 2).astype(np.int64)
+    scores = np.sort(g.random(n, dtype=np.float32))[::-1].copy()
+    perm = np.concatenate([np.arange(n // 2) * 2, np.arange(n // 2) * 2 + 1])                   # a_i at 2i, b_i at 2i+1
+    bx2, lb2 = np.empty_like(boxes), np.empty_like(labels)
+    bx2[perm], lb2[perm] = boxes, labels
+    kv = opp.batched_nms(bx2, scores, lb2, 0.7)
+    kt = opp.torchvision_batched_nms(bx2, scores, lb2, 0.7)                                     # 3840 coordinates: trick
+    km = opp.mmcv_batched_nms(bx2, scores, lb2, dict(type="nms", iou_threshold=0.7))
+    assert np.array_equal(kt, km) and not np.array_equal(kv, kt), "the LVIS-label case must separate the offset forms from the label test"
+    fx["lvis.boxes"], fx["lvis.scores"], fx["lvis.labels"] = bx2, scores, lb2
+    fx["lvis.keep"], fx["lvis.keep_tv"], fx["lvis.keep_mmcv"] = kv, kt, km
+    print(f"  lvis: vanilla keeps {kv.shape[0]}, offset forms keep {kt.shape[0]} ({len(set(kv.tolist()) ^ set(kt.tolist()))} differ)")
     print(f"  rand: {n} boxes -> {keep.shape[0]} kept")
     np.savez_compressed(os.path.join(OUT, "nms.npz"), **fx)
 
@@ -715,6 +783,9 @@ if __name__ == "__main__":
         case_network(gp, "base", 2, 128)
         case_network(gp, "base", 1, 640)
         case_network(gp, "large", 1, 640, k_text=1203)
+        sys.exit(0)
+    if "--only-nms" in sys.argv:
+        case_nms()
         sys.exit(0)
     if "--only-configs" in sys.argv:
         case_configs()

@@ -77,6 +77,57 @@ def test_oracle_nms_golden_and_prefix_property():
     assert fx["unit.keep"].tolist() == [0, 1, 3, 4, 6, 7]
 
 
+def test_oracle_nms_library_forms():
+    """oracle.postprocess restates torchvision.ops.batched_nms and mmcv.ops.batched_nms branch for branch (both
+    absent here: parity unpinned).  Pinned to hand-derived vectors (the expectations are literals, worked out in
+    tests/golden/make_golden.py nms_hand_cases) and to the structural identities the published code implies."""
+    from oracle import postprocess as opp
+    f = np.float32
+    # offset quantisation at label 1202 (S = 1281, offset 1539762, fp32 spacing 0.125 px): y2 170.05 -> 170.0
+    bx = np.array([[100, 100, 200, 200], [100, 100, 200, 170.05], [1270, 1270, 1280, 1280]], f)
+    sc, lb = np.array([0.9, 0.8, 0.7], f), np.array([1202, 1202, 0])
+    assert opp.coordinate_offsets(bx, lb)[1].tolist() == [1539862.0, 1539862.0, 1539962.0, 1539932.0]
+    assert opp.batched_nms(bx, sc, lb, 0.7).tolist() == [0, 2]
+    assert opp.torchvision_batched_nms(bx, sc, lb, 0.7).tolist() == [0, 1, 2]
+    assert opp.mmcv_batched_nms(bx, sc, lb, dict(type="nms", iou_threshold=0.7)).tolist() == [0, 1, 2]
+    # a class-1 box below -1 lands on a class-0 box in the agnostic pass (S = 100); per-class loops keep both
+    bx = np.array([[50, 50, 99, 99], [-50, -50, -1, -1]], f)
+    sc, lb = np.array([0.9, 0.8], f), np.array([0, 1])
+    assert opp.torchvision_batched_nms(bx, sc, lb, 0.7).tolist() == [0]
+    assert opp.mmcv_batched_nms(bx, sc, lb, dict(type="nms", iou_threshold=0.7)).tolist() == [0]
+    assert opp.mmcv_batched_nms(bx, sc, lb, dict(type="nms", iou_threshold=0.7, split_thr=2)).tolist() == [0, 1]
+    assert opp.mmcv_batched_nms(bx, sc, lb, dict(type="nms", iou_threshold=0.7, class_agnostic=True)).tolist() == [0, 1]
+    # ovr = fp32(3/10) = 0.300000012: > the double 0.3 (torchvision), not > float(0.3) (mmcv)
+    bx = np.array([[0, 0, 1, 6.5], [0, 3.5, 1, 10]], f)
+    sc, lb = np.array([0.9, 0.8], f), np.array([0, 0])
+    assert opp.torchvision_batched_nms(bx, sc, lb, 0.3).tolist() == [0]
+    assert opp.mmcv_batched_nms(bx, sc, lb, dict(type="nms", iou_threshold=0.3)).tolist() == [0, 1]
+    from wedetect_amd import lib as L
+    assert L.nms_threshold(0.3, L.NMS_MMCV) == float(f(0.3)) and L.nms_threshold(0.3, L.NMS_TORCHVISION) < 0.3 < float(f(0.3))
+    assert L.nms_threshold(0.7, L.NMS_MMCV) == L.nms_threshold(0.7, L.NMS_TORCHVISION) == float(f(0.7))
+    # fixtures (regression records) + branch structure
+    fx = golden("nms.npz")
+    for c in ("quant", "cross", "thr03"):
+        a = [fx[f"hand.{c}.{k}"] for k in ("boxes", "scores", "labels")]
+        thr = float(fx[f"hand.{c}.thr"])
+        assert np.array_equal(opp.torchvision_batched_nms(*a, thr), fx[f"hand.{c}.tv"])
+        assert np.array_equal(opp.mmcv_batched_nms(*a, dict(type="nms", iou_threshold=thr)), fx[f"hand.{c}.mmcv"])
+    bx, sc, lb = fx["rand.boxes"], fx["rand.scores"], fx["rand.labels"]          # 3000 boxes: 12000 coordinates
+    assert np.array_equal(opp.torchvision_batched_nms(bx, sc, lb, 0.7, "cpu"), fx["rand.keep"])       # > 4000: per-class, no offsets
+    assert np.array_equal(opp.torchvision_batched_nms(bx, sc, lb, 0.7, "cuda"), fx["rand.keep_tv_trick"])
+    assert np.array_equal(opp.mmcv_batched_nms(bx, sc, lb, dict(type="nms", iou_threshold=0.7)), fx["rand.keep_mmcv"])
+    # all coordinates >= 0: no cross-class meeting, so mmcv's one agnostic call == its per-class loop == torchvision's trick
+    assert np.array_equal(fx["rand.keep_mmcv"], fx["rand.keep_mmcv_split"]) or bx.min() < 0
+    for m in (1, 17, 300):
+        assert np.array_equal(opp.mmcv_batched_nms(bx, sc, lb, dict(type="nms", iou_threshold=0.7), max_keep=m), fx["rand.keep_mmcv"][:m])
+        assert np.array_equal(opp.mmcv_batched_nms(bx, sc, lb, dict(type="nms", iou_threshold=0.7, split_thr=100), max_keep=m),
+                              fx["rand.keep_mmcv_split"][:m])
+    bx, sc, lb = fx["lvis.boxes"], fx["lvis.scores"], fx["lvis.labels"]
+    assert np.array_equal(opp.torchvision_batched_nms(bx, sc, lb, 0.7), fx["lvis.keep_tv"])
+    assert not np.array_equal(fx["lvis.keep"], fx["lvis.keep_tv"])     # labels 1100..1202 on 1280-px boxes: quantisation matters
+    assert opp.torchvision_batched_nms(np.zeros((0, 4), f), np.zeros(0, f), np.zeros(0, np.int64), 0.7).shape == (0,)
+
+
 def test_oracle_retrieval_golden():
     from oracle import postprocess as opp
     from wedetect_amd import weights as W

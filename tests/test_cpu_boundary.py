@@ -137,7 +137,10 @@ def test_detector_options_are_honoured_or_refused():
     with pytest.raises(NotImplementedError):
         YOLOWorldDetector("nano", test_cfg=dict(nms=dict(type="soft_nms", iou_threshold=0.5)))
     with pytest.raises(NotImplementedError):
-        YOLOWorldDetector("nano", test_cfg=dict(nms=dict(type="nms", iou_threshold=0.5, split_thr=100)))
+        YOLOWorldDetector("nano", test_cfg=dict(nms=dict(type="nms", iou_threshold=0.5, class_agnostic=True)))
+    # split_thr is mmcv.ops.batched_nms' own option and reaches wd_nms_gather as mode_param
+    d = YOLOWorldDetector("nano", test_cfg=dict(nms=dict(type="nms", iou_threshold=0.5, split_thr=100)))
+    assert d.test_cfg["nms"]["split_thr"] == 100
     with pytest.raises(NotImplementedError):
         YOLOWorldDetector("nano", test_cfg=dict(max_per_img=2000))
     with pytest.raises(NotImplementedError):
@@ -413,6 +416,33 @@ def _ragged_worker(rank, world, port, q):
     got = rg2.collect()
     out["meta"] = (got["scales"].tolist(), got["bias"].tolist(), got["image_ids"].tolist(), got["count"].tolist(),
                    got["scales"].dtype == torch.float32)
+    # ids beyond int32 survive, and a field left out of a submit reads as zeros (not the previous step's)
+    rg2.submit(emb, torch.tensor([2, 2], dtype=torch.int32), image_ids=torch.tensor([2 ** 40 + rank, -7 - rank]))
+    got = rg2.collect()
+    out["meta2"] = (got["image_ids"].tolist(), "scales" in got)
+    rg2.submit(emb, torch.tensor([1, 1], dtype=torch.int32), scales=sc, bias=bi)
+    rg2.submit(emb, torch.tensor([1, 1], dtype=torch.int32))                   # other slot
+    rg2.submit(emb, torch.tensor([1, 1], dtype=torch.int32))                   # the slot that carried scales / bias: cleared
+    out["meta3"] = int(rg2.slots[0]["meta"][:, :8].abs().sum()) + int(rg2.slots[1]["meta"][:, :8].abs().sum())
+    rg2.collect()
+    # bounded-memory record collection of a whole run (extract_embedding.py:1746-1761): 7 images over 3 ranks, batch 2
+    from wedetect_amd.parallel import StreamedRecordCollector
+    total, bs = 7, 2
+    mine = list(shard_range(total, world, rank))
+    n_steps = -(-len(shard_range(total, world, 0)) // bs)
+    col = StreamedRecordCollector(bs, 4, 8, torch.device("cpu"))
+    done = 0
+    for b0 in range(0, len(mine), bs):
+        ids = mine[b0:b0 + bs]
+        e = torch.stack([torch.arange(32, dtype=torch.float32).view(4, 8) + 100 * i for i in ids])
+        col.step(e, torch.tensor([i % 4 + 1 for i in ids], dtype=torch.int32), torch.full((len(ids), 4), 0.25) * torch.tensor(ids).view(-1, 1),
+                 -torch.ones(len(ids), 4) * torch.tensor(ids).view(-1, 1), torch.tensor([2 ** 33 + i for i in ids]))
+        done += 1
+    for _ in range(done, n_steps):
+        col.pad_step()
+    recs = col.finish()
+    out["records"] = [(r["image_id"], tuple(r["embedding"].shape), float(r["embedding"][0, 0]), r["scale"].tolist(), r["bias"].tolist())
+                      for r in recs]
     q.put((rank, out))
     dist.destroy_process_group()
 
@@ -447,6 +477,9 @@ def test_ragged_gather_world3_gloo():
         want_sc = [[(4 * i + j) * 0.125 - r for j in range(4)] for r in range(3) for i in range(2)]
         assert is_f32 and sc == want_sc and bi == [[-v - 0.5 for v in row] for row in want_sc]
         assert ids == [1000, 2000, 1001, 2001, 1002, 2002] and cnt == [4, 1] * 3
+        assert out["meta2"] == ([2 ** 40, -7, 2 ** 40 + 1, -8, 2 ** 40 + 2, -9], False) and out["meta3"] == 0
+        want = [(2 ** 33 + i, (i % 4 + 1, 8), 100.0 * i, [0.25 * i] * (i % 4 + 1), [-1.0 * i] * (i % 4 + 1)) for i in range(7)]
+        assert out["records"] == (want if rank == 0 else []), (rank, out["records"])
 
 
 def test_region_gatherer_single_process_does_not_alias_the_callers_buffers():
@@ -486,3 +519,39 @@ def test_presplit_kernel_selection_table():
     for (m, n, k), tag in want.items():
         got = L.gemm_config(m, n, k, split=True, presplit=True)
         assert got.endswith("/" + tag), ((m, n, k), got)
+
+
+# ------------------------------------------------------------------------------------------ bench launcher
+def test_bench_gpus_n_launches_n_ranks_itself(monkeypatch, capsys):
+    """`python bench.py --gpus 8` (no torchrun around it) must start 8 ranks or refuse — never run one
+    process and report it.  The launcher re-executes bench.py under torch.distributed.run with the same flags
+    (dist_test.sh:11-22 is the reference's form of that command line)."""
+    import importlib
+    import subprocess
+    import sys
+    bench = importlib.import_module("bench")
+    calls = []
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: calls.append((cmd, env)) or 0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    # no GPU here: refused (exit code 2), nothing launched, nothing on stdout
+    monkeypatch.delenv("WEDETECT_BENCH_SHARE_GPU", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 2 and not calls
+    out = capsys.readouterr()
+    assert out.out == "" and "refusing" in out.err
+    # dry-run mode (every rank on device 0): the ranks are launched with the caller's flags, rendezvous on 127.0.0.1
+    monkeypatch.setenv("WEDETECT_BENCH_SHARE_GPU", "1")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0 and len(calls) == 1
+    cmd, env = calls[0]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "7"]
+    assert cmd[-5].endswith("bench.py") and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # inside a launched job the world size must equal --gpus
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "WORLD_SIZE 2" in str(e.value.code)

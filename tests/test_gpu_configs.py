@@ -55,7 +55,7 @@ def _run_config(arch, b, k, fixture, precision):
     pad, sf, ori = fx["mm.img0.pad"], fx["mm.img0.sf"], fx["mm.img0.ori"]
     meta = torch.tensor([[float(pad[2]), float(pad[0]), 0.0, float(sf[0]), float(sf[1]), float(ori[1]), float(ori[0]), 1.0]] * b,
                         dtype=torch.float32).cuda()
-    res = {kk: v.clone() for kk, v in tower.postprocess(scores, 0.001, meta, with_embed=False).items()}
+    res = {kk: v.clone() for kk, v in tower.postprocess(scores, 0.001, meta, with_embed=False, nms="mmcv").items()}
     torch.cuda.synchronize()
     n0 = int(res["count"][0])
     compare_kept_lists(f"{tag} mmdet img0 vs reference golden", res["anchors"][0, :n0], res["labels"][0, :n0], res["scores"][0, :n0],
@@ -72,7 +72,7 @@ def _run_config(arch, b, k, fixture, precision):
         assert np.array_equal(to_np(res["bboxes"][i, :n]), o["bboxes"])
     # ---- Uni path on the same features: 256 prompts, thr 0, embeddings out
     scores_u = tower.similarity(tower.P["prompts"], normalize=False)
-    res_u = {kk: v.clone() for kk, v in tower.postprocess(scores_u, 0.0, tower.identity_meta()).items()}
+    res_u = {kk: v.clone() for kk, v in tower.postprocess(scores_u, 0.0, tower.identity_meta(), nms="torchvision").items()}
     torch.cuda.synchronize()
     n0 = int(res_u["count"][0])
     ref_boxes = opp.unletterbox(fx["img0.bboxes"], (0.0, 0.0), 1.0, (640, 640))
@@ -86,7 +86,7 @@ def _run_config(arch, b, k, fixture, precision):
     for i in (b // 2, b - 1):
         t1.features(x[i:i + 1].contiguous())
         s1 = t1.similarity(text, normalize=True)
-        r1 = t1.postprocess(s1, 0.001, meta[:1], with_embed=False)
+        r1 = t1.postprocess(s1, 0.001, meta[:1], with_embed=False, nms="mmcv")
         torch.cuda.synchronize()
         assert torch.equal(t1.embed[0], embed[i]) and torch.equal(s1[0], scores[i]), f"{tag}: image {i} alone != in the batch"
         for kk in ("bboxes", "scores", "labels", "anchors", "count"):

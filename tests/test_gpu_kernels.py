@@ -257,8 +257,9 @@ def test_topk_golden(L):
 
 
 # ------------------------------------------------------------------------------------------ NMS
-def run_nms(L, boxes_list, scores_list, labels_list, k, thr, max_out, meta_rows, embed=None):
+def run_nms(L, boxes_list, scores_list, labels_list, k, thr, max_out, meta_rows, embed=None, mode="vanilla", param=0):
     """Candidates are fed pre-sorted, one candidate per anchor (flat = anchor*k + label)."""
+    mode = {"vanilla": L.NMS_VANILLA, "torchvision": L.NMS_TORCHVISION, "mmcv": L.NMS_MMCV}[mode]
     b_ = len(boxes_list)
     nmax = max(1, max(b.shape[0] for b in boxes_list))
     boxes = np.zeros((b_, nmax, 4), np.float32)
@@ -281,9 +282,11 @@ def run_nms(L, boxes_list, scores_list, labels_list, k, thr, max_out, meta_rows,
     if embed is not None:
         ed = dev(embed)
         oe = torch.empty(b_, max_out, embed.shape[-1], device="cuda")
+    ws = torch.full((L.nms_workspace_bytes(b_) // 4,), 0x5a5a5a5a, dtype=torch.int32, device="cuda")   # the call must clear it
     L.nms_gather(dev(cidx, torch.int32), dev(csc), dev(cnt, torch.int32), nmax, dev(boxes), nmax, k,
-                 dev(np.asarray(meta_rows, np.float32)), float(np.float32(thr)), max_out, ed,
-                 0 if embed is None else embed.shape[-1], ob, os_, ol, oa, oc, oe, b_)
+                 dev(np.asarray(meta_rows, np.float32)), L.nms_threshold(thr, mode), max_out, ed,
+                 0 if embed is None else embed.shape[-1], ob, os_, ol, oa, oc, oe, b_, nms_mode=mode, mode_param=param,
+                 workspace=ws)
     torch.cuda.synchronize()
     return to_np(ob), to_np(os_), to_np(ol), to_np(oa), to_np(oc), None if oe is None else to_np(oe)
 
@@ -319,14 +322,17 @@ def test_nms_golden_and_random(L):
     emb = g.standard_normal((1, n, 32)).astype(np.float32)
     meta_pre = [6.0, 4.0, 0, 0.5, 0.8, 500.0, 380.0, 1.0]
     meta_post = [6.0, 4.0, 0, 0.5, 0.8, 500.0, 380.0, 0.0]
-    for meta in (meta_pre, meta_post):
-        ob, os_, ol, oa, oc, oe = run_nms(L, [bx], [sc], [lb], 3, 0.7, 300, [meta], embed=emb)
-        if meta[7]:
+    for meta, split_thr in ((meta_pre, 10000), (meta_pre, 1000), (meta_post, 0)):
+        if meta[7]:     # mmdet order: rescale, then mmcv.ops.batched_nms (one agnostic call / per-class loop), clamp
+            ob, os_, ol, oa, oc, oe = run_nms(L, [bx], [sc], [lb], 3, 0.7, 300, [meta], embed=emb, mode="mmcv", param=split_thr)
             r = opp.mmdet_predict_image_from_candidates(bx, sc, lb, (meta[1], 0, meta[0], 0), (meta[3], meta[4]),
-                                                        (meta[6], meta[5]), 0.7, 300)
+                                                        (meta[6], meta[5]), 0.7, 300,
+                                                        nms_cfg=dict(type="nms", iou_threshold=0.7, split_thr=split_thr))
             keep, rb = r["keep"], r["bboxes"]
-        else:
-            keep = opp.batched_nms(bx, sc, lb, 0.7, max_keep=300)
+        else:           # Uni order: torchvision.ops.batched_nms on network pixels (20000 coordinates: per-class branch)
+            ob, os_, ol, oa, oc, oe = run_nms(L, [bx], [sc], [lb], 3, 0.7, 300, [meta], embed=emb, mode="torchvision", param=4000)
+            keep = opp.torchvision_batched_nms(bx, sc, lb, 0.7, "cpu", max_keep=300)
+            assert np.array_equal(keep, opp.batched_nms(bx, sc, lb, 0.7, max_keep=300))
             rb = opp.clamp_boxes(opp.rescale_boxes(bx[keep], (meta[0], meta[1]), (meta[3], meta[4])),
                                  (meta[6], meta[5]))
         assert oc[0] == keep.shape[0]
@@ -334,6 +340,105 @@ def test_nms_golden_and_random(L):
         assert np.array_equal(ob[0, :oc[0]], rb), f"pre={meta[7]}: output boxes differ"
         assert np.array_equal(oe[0, :oc[0]], emb[0, keep])
         assert np.all(oe[0, oc[0]:] == 0)
+
+
+def _forms(opp, bx, sc, lb, thr, tv_param, split_thr, max_keep=None):
+    """Oracle keeps of the three device modes on one candidate list."""
+    tv_dev = {4000: "cpu", 20000: "cuda"}[tv_param]
+    return dict(vanilla=opp.batched_nms(bx, sc, lb, thr, max_keep=max_keep),
+                torchvision=opp.torchvision_batched_nms(bx, sc, lb, thr, tv_dev, max_keep=max_keep),
+                mmcv=opp.mmcv_batched_nms(bx, sc, lb, dict(type="nms", iou_threshold=thr, split_thr=split_thr), max_keep=max_keep))
+
+
+def _check_forms(L, opp, name, bx, sc, lb, k, thr=0.7, tv_param=4000, split_thr=10000, max_out=300):
+    want = _forms(opp, bx, sc, lb, thr, tv_param, split_thr, max_keep=max_out)
+    for mode, param in (("vanilla", 0), ("torchvision", tv_param), ("mmcv", split_thr)):
+        _, os_, ol, oa, oc, _ = run_nms(L, [bx], [sc], [lb], k, thr, max_out, [IDENT], mode=mode, param=param)
+        keep = want[mode]
+        assert oc[0] == keep.shape[0], f"{name}/{mode}: kept {oc[0]} vs oracle {keep.shape[0]}"
+        assert np.array_equal(oa[0, :oc[0]], keep), f"{name}/{mode}: kept indices differ"
+        assert np.array_equal(ol[0, :oc[0]], lb[keep]) and np.array_equal(os_[0, :oc[0]], sc[keep])
+    return want
+
+
+def test_nms_library_forms_hand_vectors_and_goldens(L):
+    """torchvision.ops.batched_nms and mmcv.ops.batched_nms as published (coordinate offsets in fp32, agnostic pass,
+    candidate-count branches, double vs float threshold) against the hand-derived vectors and the oracle's records."""
+    from oracle import postprocess as opp
+    fx = golden("nms.npz")
+    for name in ("quant", "cross", "thr03"):
+        bx, sc, lb, thr = (fx[f"hand.{name}.{k}"] for k in ("boxes", "scores", "labels", "thr"))
+        thr = float(thr)
+        k = int(lb.max()) + 1
+        for mode, param, key in (("vanilla", 0, "vanilla"), ("torchvision", 4000, "tv"), ("mmcv", 10000, "mmcv"), ("mmcv", 1, "mmcv_split")):
+            _, _, _, oa, oc, _ = run_nms(L, [bx], [sc], [lb], k, thr, 300, [IDENT], mode=mode, param=param)
+            assert oa[0, :oc[0]].tolist() == fx[f"hand.{name}.{key}"].tolist(), f"hand vector {name}, {mode}/{param}"
+    # the hand-derived expectations themselves (tests/golden/make_golden.py nms_hand_cases): quantisation keeps a box
+    # the label test suppresses; a class-1 box below -1 meets a class-0 box in the agnostic pass; double vs float 0.3
+    assert fx["hand.quant.tv"].tolist() == [0, 1, 2] and fx["hand.quant.vanilla"].tolist() == [0, 2]
+    assert fx["hand.cross.mmcv"].tolist() == [0] and fx["hand.cross.mmcv_split"].tolist() == [0, 1]
+    assert fx["hand.thr03.tv"].tolist() == [0] and fx["hand.thr03.mmcv"].tolist() == [0, 1]
+    want = _check_forms(L, opp, "rand", fx["rand.boxes"], fx["rand.scores"], fx["rand.labels"], 5, max_out=1024)
+    assert np.array_equal(want["mmcv"], fx["rand.keep_mmcv"][:1024]) and np.array_equal(want["vanilla"], fx["rand.keep"][:1024])
+    _check_forms(L, opp, "rand/split100+trick20000", fx["rand.boxes"], fx["rand.scores"], fx["rand.labels"], 5, tv_param=20000,
+                 split_thr=100, max_out=1024)
+    want = _check_forms(L, opp, "lvis", fx["lvis.boxes"], fx["lvis.scores"], fx["lvis.labels"], 1203, max_out=1024)
+    assert np.array_equal(want["torchvision"], fx["lvis.keep_tv"]) and np.array_equal(want["mmcv"], fx["lvis.keep_mmcv"])
+    assert not np.array_equal(want["vanilla"], want["mmcv"]), "label 1100-1202 on 1280-px boxes: the offset forms must differ from the label test"
+
+
+@pytest.mark.parametrize("case", ["lvis12000", "negative", "all_negative", "far_negative", "split_boundary"])
+def test_nms_library_forms_seeded(L, case):
+    """Seeded candidate lists that exercise every branch of the offset forms: >= split_thr candidates with LVIS-sized
+    labels, coordinates below -1 (cross-class reach 1..4 buckets), all-negative boxes (offset step <= 0: whole-list
+    walk), a reach beyond the bucket radius, and candidate counts at the branch boundaries."""
+    from oracle import postprocess as opp
+    g = np.random.default_rng({"lvis12000": 1, "negative": 2, "all_negative": 3, "far_negative": 4, "split_boundary": 5}[case])
+    f = np.float32
+
+    def boxes(n, lo, hi, wmin=8, wmax=90):
+        ctr = g.random((n, 2), dtype=np.float32) * f(hi - lo) + f(lo)
+        wh = g.random((n, 2), dtype=np.float32) * f(wmax - wmin) + f(wmin)
+        return np.concatenate([ctr - wh / 2, ctr + wh / 2], 1).astype(f)
+
+    def scores(n):
+        return np.sort(np.round(g.random(n, dtype=np.float32) * 4000) / 4000)[::-1].copy()     # with exact ties
+    if case == "lvis12000":
+        n, k = 12000, 1203
+        bx = boxes(n, 0, 1280, 20, 200)
+        bx[n // 2:] = bx[:n // 2] + (g.random((n // 2, 1), dtype=np.float32) * f(24) - f(12))   # heavy overlaps, some near 0.7
+        lb = np.concatenate([g.integers(0, 1203, n // 2)] * 2).astype(np.int64)
+        _check_forms(L, opp, case, bx, scores(n), lb, k)
+    elif case == "negative":
+        for lo, nlab in ((-40, 5), (-260, 3), (-390, 4)):           # reach 1, 2-3, 3-4 with max ~ 100
+            n = 1500
+            bx = boxes(n, lo, 100, 10, 70)
+            # plant cross-class coincidences: box j+1 = box j shifted by -(max+1) in x and y, next label
+            S = f(bx.max()) + f(1)
+            amax = int(np.argmax(bx.max(1)))
+            src = [int(j) for j in g.choice(n, 60, replace=False) if j != amax and (j + 7) % n != amax]
+            lb = g.integers(0, nlab, n).astype(np.int64)
+            for j in src:
+                t = (j + 7) % n
+                bx[t] = bx[j] - S
+                lb[t] = lb[j] + 1
+            assert f(bx.max()) + f(1) == S
+            sc = scores(n)
+            want = _check_forms(L, opp, f"{case}{lo}", bx, sc, lb, nlab + 1, tv_param=20000)
+            assert not np.array_equal(want["mmcv"], want["vanilla"]), "planted cross-class pairs must matter"
+    elif case == "all_negative":
+        n = 800
+        bx = boxes(n, -900, -300, 10, 120)
+        _check_forms(L, opp, case, bx, scores(n), g.integers(0, 9, n).astype(np.int64), 9)
+    elif case == "far_negative":
+        n = 900
+        bx = boxes(n, -2000, 60, 10, 120)
+        _check_forms(L, opp, case, bx, scores(n), g.integers(0, 40, n).astype(np.int64), 40)
+    else:
+        for n in (999, 1000, 1001):                      # torchvision: 4n <= 4000 -> trick, else vanilla
+            bx = boxes(n, -30, 400, 10, 150)
+            lb = g.integers(0, 80, n).astype(np.int64)
+            _check_forms(L, opp, f"{case}{n}", bx, scores(n), lb, 80, split_thr=1000)          # mmcv: n < 1000 agnostic
 
 
 # ------------------------------------------------------------------------------------------ retrieval

@@ -81,7 +81,7 @@ def test_tower_vs_oracle_all_stages(arch, b, hw):
     scores = tower.similarity(tower.P["prompts"], normalize=False)
     assert_close(f"{arch} scores", scores, flat["scores"], TOL, 0)
     # post-process exactness on the tower's own tensors
-    res = tower.postprocess(scores, 0.0, tower.identity_meta())
+    res = tower.postprocess(scores, 0.0, tower.identity_meta(), nms="torchvision")
     torch.cuda.synchronize()
     ref = oracle_post_on(tower, to_np(scores), to_np(boxes), to_np(embed))
     from oracle import postprocess as opp
@@ -114,7 +114,7 @@ def test_text_path_normalised_bank_vs_oracle():
     metas = [((8.0, 8.0, 0.0, 0.0), (0.5, 0.5), (224, 256)), ((0.0, 0.0, 12.0, 12.0), (0.8, 0.8), (160, 130))]
     meta = torch.tensor([[m[0][2], m[0][0], 0, m[1][0], m[1][1], m[2][1], m[2][0], 1.0] for m in metas],
                         dtype=torch.float32).cuda()
-    res = tower.postprocess(scores, 0.001, meta, with_embed=False)
+    res = tower.postprocess(scores, 0.001, meta, with_embed=False, nms="mmcv")
     torch.cuda.synchronize()
     ref = oracle_post_on(tower, to_np(scores), to_np(boxes), None, uni=False, thr=0.001, meta=metas)
     for i in range(b):
@@ -156,7 +156,7 @@ def test_base_against_reference_goldens(fixture, arch, b, hw):
         check_checksum(f"{fixture} embed{l}", e, fx, f"embed{l}", TOL, TOL)
     # Uni path end to end
     scores = tower.similarity(tower.P["prompts"], normalize=False)
-    res = tower.postprocess(scores, 0.0, tower.identity_meta())
+    res = tower.postprocess(scores, 0.0, tower.identity_meta(), nms="torchvision")
     torch.cuda.synchronize()
     for i in range(b):
         ref_boxes = opp.unletterbox(fx[f"img{i}.bboxes"], (0.0, 0.0), 1.0, (hw, hw))
@@ -171,7 +171,7 @@ def test_base_against_reference_goldens(fixture, arch, b, hw):
                           float(fx[f"mm.img{i}.sf"][0]), float(fx[f"mm.img{i}.sf"][1]),
                           float(fx[f"mm.img{i}.ori"][1]), float(fx[f"mm.img{i}.ori"][0]), 1.0] for i in range(b)],
                         dtype=torch.float32).cuda()
-    res = tower.postprocess(scores, 0.001, meta, with_embed=False)
+    res = tower.postprocess(scores, 0.001, meta, with_embed=False, nms="mmcv")
     torch.cuda.synchronize()
     for i in range(b):
         jj, gg = _compare_detections(f"{fixture} mmdet img{i}", res, i, fx, f"mm.img{i}", fx[f"mm.img{i}.bboxes"])

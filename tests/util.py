@@ -51,21 +51,24 @@ def check_checksum(name: str, got_nhwc, fx, prefix: str, atol: float, rtol: floa
 
 
 # ------------------------------------------------------------------------------------------ index parity
-PARITY_LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_r02.jsonl")
+PARITY_LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_r03.jsonl")
+RELAXATIONS = []          # (case, kind) of every comparison in this process that was not position-by-position identical
 
 
 def compare_kept_lists(name, got_anchor, got_label, got_score, ref_anchor, ref_label, ref_score, margins=None,
                        score_tol: float = 1e-3, got_boxes=None, ref_boxes=None):
     """Index parity of a kept-detection list against the reference's (north_star: "box indices/classes bit-exact").
 
-    Scores must agree within ``score_tol``.  The (anchor, class) lists must be IDENTICAL, position by position, except
-    where the reference itself says two implementations with fp32 summation noise cannot be told apart: rows whose
-    reference scores lie within ``eps`` of each other (eps = 4 x the score difference measured in this very comparison,
-    floor 1e-6) may appear in any order among themselves ("tie run").  That relaxation is only granted while the
-    reference's NMS decisions were not themselves within noise of flipping (``margins`` = [min |IoU - thr|, min
-    kept-vs-suppressed score gap, min kept gap, gap at the nms_pre cut] recorded by the golden generator; the IoU noise
-    is bounded by 8 x (box difference measured here) / (smallest box side)); if they were, the fallback is >= 97 % overlap.  Returns (rows of got, rows of ref) of the common detections and appends one JSON
-    line with what was observed to gpurun_out/parity_r02.jsonl."""
+    The assertion is EXACTNESS: the (anchor, class) lists must be identical, position by position, and the scores within
+    ``score_tol``.  One relaxation exists and is never silent: rows whose REFERENCE scores lie within ``eps`` of each other
+    (eps = 4 x the score difference measured in this very comparison, floor 1e-6 — fp32 summation noise between a CPU run
+    and the device) form a "tie run" whose members may appear in any order; it is only considered when the reference's own
+    ``kept_gap`` margin says such a run exists (kept_gap < eps), it is printed, appended to RELAXATIONS and to the parity
+    log, and ``assert_no_relaxations`` lets a test refuse it altogether.  Anything else fails, with the reference's four
+    decision margins ([min |IoU - thr| on the boxes NMS compared, min kept-vs-suppressed score gap, min kept gap, gap at
+    the nms_pre cut], recorded by the golden generator) in the message: margins below the measured noise mean the
+    reference's own decision was not reproducible by ANY second implementation — that is reported, not waved through.
+    Returns (rows of got, rows of ref) of the common detections and appends one JSON line to gpurun_out/parity_r03.jsonl."""
     import json
     ga, gl, gs = (np.asarray(to_np(x)) for x in (got_anchor, got_label, got_score))
     ra, rl, rs = (np.asarray(x) for x in (ref_anchor, ref_label, ref_score))
@@ -101,14 +104,20 @@ def compare_kept_lists(name, got_anchor, got_label, got_score, ref_anchor, ref_l
         box_noise = float(np.max(np.abs(gb - rb)))
         side = np.minimum(rb[:, 2] - rb[:, 0], rb[:, 3] - rb[:, 1])
         min_side = float(max(1.0, np.min(side)))
-    decided = True
+    iou_eps = 8.0 * box_noise / min_side + 1e-7
+    within_noise = []
+    kept_g = 0.0
     if margins is not None:
         iou_m, pair_g, kept_g, cut_g = (float(v) for v in margins)
-        iou_eps = 8.0 * box_noise / min_side + 1e-7
-        decided = iou_m > iou_eps and pair_g > eps
-    rec = dict(case=name, kept=int(n), exact=exact, tie_run_exact=run_exact, overlap=round(overlap, 4), score_noise=noise, eps=eps,
-               tie_runs=runs, longest_run=longest, box_noise=box_noise, margins=[float(v) for v in margins] if margins is not None else None,
-               nms_decided_beyond_noise=decided)
+        within_noise = [k for k, bad in (("iou_margin", iou_m <= iou_eps), ("pair_gap", pair_g <= eps), ("kept_gap", kept_g <= eps),
+                                         ("cut_gap", cut_g <= eps)) if bad]
+    relaxation = "none"
+    if not exact and run_exact and (margins is None or kept_g < eps):
+        relaxation = "tie_run"
+        RELAXATIONS.append((name, relaxation))
+    rec = dict(case=name, kept=int(n), exact=exact, relaxation=relaxation, overlap=round(overlap, 4), score_noise=noise, eps=eps,
+               tie_runs=runs, longest_run=longest, box_noise=box_noise, iou_eps=iou_eps,
+               margins=[float(v) for v in margins] if margins is not None else None, reference_margins_within_noise=within_noise)
     try:
         os.makedirs(os.path.dirname(PARITY_LOG), exist_ok=True)
         with open(PARITY_LOG, "a") as f:
@@ -116,9 +125,15 @@ def compare_kept_lists(name, got_anchor, got_label, got_score, ref_anchor, ref_l
     except OSError:
         pass
     print(f"[parity] {rec}")
-    if decided:
-        assert run_exact, (f"{name}: kept (anchor, class) list differs from the reference beyond near-ties "
-                           f"(eps {eps:.2e}, overlap {overlap:.4f}, margins {margins})")
-    else:
-        assert overlap >= 0.97, f"{name}: only {overlap:.3f} of the reference's detections reproduced"
+    if relaxation != "none":
+        print(f"[parity] RELAXATION #{len(RELAXATIONS)} ({relaxation}) granted to {name}: rows inside reference tie runs (score gap < {eps:.2e}) are permuted")
+    assert exact or relaxation == "tie_run", (
+        f"{name}: kept (anchor, class) list differs from the reference (overlap {overlap:.4f}, score noise {noise:.2e}, "
+        f"margins [iou, pair, kept, cut] {margins}; reference decisions within the measured noise: {within_noise or 'none'})")
     return jj, gg
+
+
+def assert_no_relaxations(prefix: str = "") -> None:
+    """For tests that must be order-exact with zero tie-run relaxations (the BASELINE configurations)."""
+    hit = [r for r in RELAXATIONS if r[0].startswith(prefix)]
+    assert not hit, f"index parity needed {len(hit)} tie-run relaxation(s): {hit}"

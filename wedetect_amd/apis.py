@@ -37,10 +37,18 @@ def get_test_pipeline_cfg(cfg):
 def load_checkpoint_file(path: str) -> dict:
     """``torch.load(path, map_location='cpu')`` -> the state dict (mmengine wrapper ``{'state_dict': ...}`` or a flat
     dict, as the Uni checkpoints are: generate_proposal.py:1233)."""
+    # the safe loader first (the reference calls torch.load with the library default, which is weights_only=True on
+    # current torch); mmengine checkpoints that pickle non-tensor metadata need the unsafe one, which executes
+    # arbitrary code from the file: that is an explicit opt-in ($WEDETECT_UNSAFE_LOAD=1), never a silent fallback
     try:
-        ckpt = torch.load(path, map_location="cpu", weights_only=False)
-    except TypeError:                                   # very old torch
+        ckpt = torch.load(path, map_location="cpu", weights_only=True)
+    except TypeError:                                   # very old torch: no weights_only keyword
         ckpt = torch.load(path, map_location="cpu")
+    except Exception as e:
+        if os.environ.get("WEDETECT_UNSAFE_LOAD") != "1":
+            raise RuntimeError(f"{path} cannot be read by the safe loader (torch.load(weights_only=True)): {e}\n"
+                               "If you trust the file, set WEDETECT_UNSAFE_LOAD=1 to unpickle it fully.") from e
+        ckpt = torch.load(path, map_location="cpu", weights_only=False)
     if not isinstance(ckpt, dict):
         raise RuntimeError(f"No state_dict found in checkpoint file {path}")
     return ckpt["state_dict"] if isinstance(ckpt.get("state_dict"), dict) else ckpt

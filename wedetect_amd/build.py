@@ -27,6 +27,18 @@ def _headers():
     return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(ROOT, "include", "wedetect_hip.h")]
 
 
+def source_hash() -> str:
+    """sha256 over the kernel sources and headers the library is built from (sorted names + contents): identifies the
+    code a profile was taken on independently of where / when it was compiled (bench.py: traffic_provenance)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    for f in files + [os.path.join(ROOT, "include", "wedetect_hip.h")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def _obj(src: str) -> str:
     return os.path.join(CSRC, src.replace(".hip", ".o"))
 

@@ -38,6 +38,19 @@ __device__ __forceinline__ bool wd_any_nonfinite4(float a, float b, float c, flo
   return z != z;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE setting of a kernel: remember it per device id, so a process
+// that drives a second GPU sets it there too (one bit per device; a lost race only repeats an idempotent call)
+struct WdAttrOnce { unsigned long long done = 0; };
+static inline int wd_set_max_lds(WdAttrOnce& once, const void* fn, int bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return WD_ERR_LAUNCH;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (once.done & bit) return WD_OK;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return WD_ERR_LAUNCH;
+  once.done |= bit;
+  return WD_OK;
+}
+
 static inline bool wd_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 __device__ __forceinline__ float wd_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }

@@ -432,22 +432,14 @@ int launch_cfg(const WdConvGemm& p, hipStream_t st) {
   const int vec_c = (p.ldc % 4 == 0) && wd_aligned16(p.c) && (p.out_mode == WD_OUT_ROWS || (p.n % 16 == 0));
   const int vec_res = p.res ? ((p.ldres % 4 == 0) && wd_aligned16(p.res)) : 0;
   const int vec_bias = p.bias ? wd_aligned16(p.bias) : 0;
-  static bool attr_plain = false, attr_conv = false;
+  static WdAttrOnce attr_plain, attr_conv;
   if (conv) {
     auto k = conv_gemm_kernel<TM, TN, WM, WN, true, BKT, VAR>;
-    if (!attr_conv) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              T::LDS_BYTES) != hipSuccess) return WD_ERR_LAUNCH;
-      attr_conv = true;
-    }
+    if (wd_set_max_lds(attr_conv, reinterpret_cast<const void*>(k), T::LDS_BYTES) != WD_OK) return WD_ERR_LAUNCH;
     WD_LAUNCH_GEMM(k, dim3((unsigned)nblk), dim3(T::NT), T::LDS_BYTES, st, p, nbn, vec_c, vec_res, vec_bias);
   } else {
     auto k = conv_gemm_kernel<TM, TN, WM, WN, false, BKT, VAR>;
-    if (!attr_plain) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              T::LDS_BYTES) != hipSuccess) return WD_ERR_LAUNCH;
-      attr_plain = true;
-    }
+    if (wd_set_max_lds(attr_plain, reinterpret_cast<const void*>(k), T::LDS_BYTES) != WD_OK) return WD_ERR_LAUNCH;
     WD_LAUNCH_GEMM(k, dim3((unsigned)nblk), dim3(T::NT), T::LDS_BYTES, st, p, nbn, vec_c, vec_res, vec_bias);
   }
   return wd_launch_status();
@@ -574,13 +566,8 @@ extern "C" int wd_retrieval_max(const float* e, const float* t, const float* sca
   if (n_img <= 0 || n_cls <= 0 || dim <= 0 || dim % 4) return WD_ERR_BAD_ARG;
   if (rows_per_img <= 0 || rows_per_img > T::BM) return WD_ERR_BAD_ARG;
   if (!wd_aligned16(e) || !wd_aligned16(t)) return WD_ERR_BAD_ARG;
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(retrieval_max_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES) != hipSuccess)
-      return WD_ERR_LAUNCH;
-    attr = true;
-  }
+  static WdAttrOnce attr;
+  if (wd_set_max_lds(attr, reinterpret_cast<const void*>(retrieval_max_kernel), T::LDS_BYTES) != WD_OK) return WD_ERR_LAUNCH;
   const int nbn = (n_cls + T::BN - 1) / T::BN;
   hipLaunchKernelGGL(retrieval_max_kernel, dim3(nbn, n_img), dim3(T::NT), T::LDS_BYTES,
                      static_cast<hipStream_t>(stream), e, t, scale, bias, count, out, rows_per_img, n_cls, dim);

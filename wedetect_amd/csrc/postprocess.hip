@@ -12,6 +12,8 @@
 // NMS: one wave per image; a 64-candidate chunk is first tested against the kept list
 // (LDS), then resolved sequentially inside the wave with ballots.  It stops at max_out
 // kept boxes, which equals slicing the full NMS result (greedy NMS is prefix-consistent).
+// Three forms (WD_NMS_*): label-test vanilla, torchvision.ops.batched_nms, mmcv.ops.batched_nms —
+// the latter two with the libraries' fp32 coordinate offsets and their candidate-count branches.
 #include "common.h"
 
 #pragma clang fp contract(off)
@@ -358,16 +360,76 @@ __device__ __forceinline__ f32x4 clamp_box(f32x4 bx, const float* mt) {
   return r;
 }
 
-constexpr int NMS_MAX_OUT = 1024, NMS_BUCKETS = 2048;
+constexpr int NMS_MAX_OUT = 1024, NMS_BUCKETS = 2048, NMS_MAX_RADIUS = 4;
+
+// The two upstream libraries express class awareness as a coordinate offset, not as a label test
+// (torchvision/ops/boxes.py _batched_nms_coordinate_trick, mmcv/ops/nms.py batched_nms):
+//     boxes_for_nms = boxes + label * (boxes.max() + 1)          (fp32: quantises the boxes)
+// followed by a class-AGNOSTIC greedy pass (torchvision at <= 4000 box coordinates on the CPU, mmcv below
+// split_thr = 10000 candidates), or by a per-class loop on the original boxes (torchvision above that) / on the
+// offset boxes (mmcv from split_thr).  Which form an image takes depends on its candidate count.
+struct NmsForm { bool offset, agnostic; };
+__device__ __forceinline__ NmsForm nms_form(int mode, int param, int count) {
+  NmsForm f{false, false};
+  if (mode == WD_NMS_MMCV) { f.offset = true; f.agnostic = count < param; }
+  else if (mode == WD_NMS_TORCHVISION && 4ll * count <= (long long)param) { f.offset = true; f.agnostic = true; }
+  return f;
+}
+
+// order-preserving float <-> uint map; 0 sorts below every float, so a zeroed word is the identity of atomicMax
+__device__ __forceinline__ unsigned ord_enc(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord_dec(unsigned e) {
+  return __uint_as_float((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e);
+}
+
+// boxes.max() (and -boxes.min(), for the cross-class reach below) over an image's candidates, on the boxes NMS sees
+// (after the mmdet-order rescale when meta says so).  bounds[b] = {enc(max), enc(-min)}, zeroed by the caller.
+__global__ void __launch_bounds__(256) nms_bounds_kernel(const int* __restrict__ cand_idx, const int* __restrict__ cand_count,
+                                                         int cand_stride, const float* __restrict__ boxes, int n_anchor,
+                                                         int k, const float* __restrict__ meta, int mode, int param,
+                                                         unsigned* __restrict__ bounds) {
+  const int b = blockIdx.y;
+  const int count = cand_count[b];
+  if (count <= 0 || !nms_form(mode, param, count).offset) return;
+  const int base = blockIdx.x * 1024;
+  if (base >= count) return;
+  const float* mt = meta + (size_t)b * 8;
+  const bool pre = mt[7] != 0.f;
+  const int* ci = cand_idx + (size_t)b * cand_stride;
+  const f32x4* bx = reinterpret_cast<const f32x4*>(boxes) + (size_t)b * n_anchor;
+  float mx = -INFINITY, mn = INFINITY;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = base + u * 256 + threadIdx.x;
+    if (i < count) {
+      f32x4 box = bx[ci[i] / k];
+      if (pre) box = rescale_box(box, mt);
+      mx = fmaxf(mx, fmaxf(fmaxf(box[0], box[1]), fmaxf(box[2], box[3])));
+      mn = fminf(mn, fminf(fminf(box[0], box[1]), fminf(box[2], box[3])));
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    mn = fminf(mn, __shfl_xor(mn, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0 && mx >= mn) {
+    atomicMax(bounds + 2 * b, ord_enc(mx));
+    atomicMax(bounds + 2 * b + 1, ord_enc(-mn));
+  }
+}
 
 __global__ void __launch_bounds__(64) nms_kernel(const int* __restrict__ cand_idx, const float* __restrict__ cand_score,
                                                  const int* __restrict__ cand_count, int cand_stride,
                                                  const float* __restrict__ boxes, int n_anchor, int k,
-                                                 const float* __restrict__ meta, float iou_thr, int max_out,
+                                                 const float* __restrict__ meta, float iou_thr, int max_out, int mode,
+                                                 int param, const unsigned* __restrict__ bounds,
                                                  float* __restrict__ out_boxes, float* __restrict__ out_scores,
                                                  int* __restrict__ out_labels, int* __restrict__ out_anchors,
                                                  int* __restrict__ out_count) {
-  __shared__ f32x4 kept_box[NMS_MAX_OUT];
+  __shared__ f32x4 kept_box[NMS_MAX_OUT];      // the boxes NMS compares: offset boxes when the form has offsets
   __shared__ int kept_label[NMS_MAX_OUT];
   // kept boxes are chained per class bucket (label & (NMS_BUCKETS - 1)): a candidate only walks the kept boxes of its
   // own bucket — with 80 classes and 300 kept boxes about four entries instead of all 300 (the scan of the whole
@@ -383,6 +445,28 @@ __global__ void __launch_bounds__(64) nms_kernel(const int* __restrict__ cand_id
   if (count < 0) {                         // non-finite scores upstream (wd_topk_candidates): nothing to trust in this image
     if (lane == 0) out_count[b] = -1;
     return;
+  }
+  const NmsForm form = nms_form(mode, param, count);
+  // offset step S = boxes.max() + 1 (fp32, as upstream).  The agnostic forms compare a candidate with kept boxes of
+  // EVERY class; two offset boxes of classes c < c' can only overlap when (c' - c) * S < (max - min) + rounding of
+  // the offsets (fl is monotone: fl(x1' + o_c') < fl(x2 + o_c) needs x1' + o_c' < x2 + o_c), so the walk visits the
+  // buckets of label - reach .. label + reach (reach 0 or 1 for boxes that touch the image) and falls back to the
+  // whole kept list when the reach is large, S <= 0 (all boxes left of -1) or the threshold is negative.
+  float S = 0.f;
+  int reach = 0;
+  bool whole_list = false;
+  if (form.offset && count > 0) {
+    const float maxc = ord_dec(bounds[2 * b]), minc = -ord_dec(bounds[2 * b + 1]);
+    S = maxc + 1.0f;
+    if (form.agnostic) {
+      const double sd = (double)S, span = (double)maxc - (double)minc;
+      if (!(sd > 0.0) || !(iou_thr >= 0.f)) whole_list = true;
+      else {
+        const double q = (span + 2.0 * (double)k * sd * 1.1920928955078125e-7) / sd;
+        if (!(q < (double)(NMS_MAX_RADIUS + 1))) whole_list = true;
+        else reach = (int)q;
+      }
+    }
   }
   const int* ci = cand_idx + (size_t)b * cand_stride;
   const float* cs = cand_score + (size_t)b * cand_stride;
@@ -416,23 +500,37 @@ __global__ void __launch_bounds__(64) nms_kernel(const int* __restrict__ cand_id
     f32x4 box = n_box;
     if (base + 64 < count) fetch(base + 64);
     if (valid && pre) box = rescale_box(box, mt);
+    f32x4 cmp = box;                       // what NMS compares
+    if (form.offset) {
+      const float off = (float)label * S;  // idxs.to(boxes) * (max_coordinate + 1), then boxes + offsets[:, None]
+      cmp[0] = box[0] + off; cmp[1] = box[1] + off; cmp[2] = box[2] + off; cmp[3] = box[3] + off;
+    }
     bool alive = valid;
-    // candidates vs. the kept boxes of their class bucket (any order: a candidate dies if ANY kept box of its class
-    // overlaps it by more than the threshold)
+    // candidates vs. the kept boxes that can suppress them (any order: a candidate dies if ANY of them overlaps it by
+    // more than the threshold)
     if (alive) {
-      for (int e = bucket_head[label & (NMS_BUCKETS - 1)]; e >= 0; e = kept_next[e])
-        if (kept_label[e] == label && iou_gt(kept_box[e], box, iou_thr)) { alive = false; break; }
+      if (!form.agnostic) {
+        for (int e = bucket_head[label & (NMS_BUCKETS - 1)]; e >= 0; e = kept_next[e])
+          if (kept_label[e] == label && iou_gt(kept_box[e], cmp, iou_thr)) { alive = false; break; }
+      } else if (whole_list) {
+        for (int e = 0; e < nk; ++e)
+          if (iou_gt(kept_box[e], cmp, iou_thr)) { alive = false; break; }
+      } else {
+        for (int c2 = max(label - reach, 0); alive && c2 <= min(label + reach, k - 1); ++c2)
+          for (int e = bucket_head[c2 & (NMS_BUCKETS - 1)]; e >= 0; e = kept_next[e])
+            if (kept_label[e] == c2 && iou_gt(kept_box[e], cmp, iou_thr)) { alive = false; break; }
+      }
     }
     // sequential resolution inside the chunk, visiting only the candidates that are still alive
     unsigned long long mask = __ballot(alive);
     while (mask != 0ull && nk < max_out) {
       const int p = __ffsll((long long)mask) - 1;          // lowest alive lane = next kept box
       f32x4 bp;
-      bp[0] = __shfl(box[0], p, 64); bp[1] = __shfl(box[1], p, 64);
-      bp[2] = __shfl(box[2], p, 64); bp[3] = __shfl(box[3], p, 64);
+      bp[0] = __shfl(cmp[0], p, 64); bp[1] = __shfl(cmp[1], p, 64);
+      bp[2] = __shfl(cmp[2], p, 64); bp[3] = __shfl(cmp[3], p, 64);
       const int lp = __shfl(label, p, 64);
       if (lane == p) {
-        kept_box[nk] = box;
+        kept_box[nk] = cmp;
         kept_label[nk] = label;
         kept_next[nk] = bucket_head[label & (NMS_BUCKETS - 1)];
         bucket_head[label & (NMS_BUCKETS - 1)] = (short)nk;
@@ -445,7 +543,7 @@ __global__ void __launch_bounds__(64) nms_kernel(const int* __restrict__ cand_id
         oa[nk] = anchor;
       }
       ++nk;
-      if (lane > p && alive && label == lp && iou_gt(bp, box, iou_thr)) alive = false;
+      if (lane > p && alive && (form.agnostic || label == lp) && iou_gt(bp, cmp, iou_thr)) alive = false;
       mask = __ballot(alive && lane > p);
     }
     __syncthreads();   // single-wave workgroup: orders the LDS writes above before the next chunk's reads
@@ -554,22 +652,37 @@ extern "C" int wd_topk_candidates(const float* scores, int32_t batch, int64_t n,
   return wd_launch_status();
 }
 
+extern "C" int64_t wd_nms_workspace_bytes(int32_t batch) {
+  return batch <= 0 ? 0 : (int64_t)align256((size_t)batch * 2 * sizeof(unsigned));
+}
+
 extern "C" int wd_nms_gather(const int32_t* cand_idx, const float* cand_score, const int32_t* cand_count,
                              int32_t cand_stride, const float* boxes, int32_t n_anchor, int32_t k, const float* meta,
-                             float iou_thr, int32_t max_out, const float* embed, int32_t embed_dim, float* out_boxes,
-                             float* out_scores, int32_t* out_labels, int32_t* out_anchors, int32_t* out_count,
-                             float* out_embed, int32_t batch, void* stream) {
+                             float iou_thr, int32_t max_out, int32_t nms_mode, int32_t mode_param, const float* embed,
+                             int32_t embed_dim, float* out_boxes, float* out_scores, int32_t* out_labels,
+                             int32_t* out_anchors, int32_t* out_count, float* out_embed, int32_t batch, void* workspace,
+                             int64_t workspace_bytes, void* stream) {
   if (!cand_idx || !cand_score || !cand_count || !boxes || !meta || !out_boxes || !out_scores || !out_labels ||
       !out_anchors || !out_count)
     return WD_ERR_BAD_ARG;
-  if (batch <= 0 || batch > 65535 || n_anchor <= 0 || k <= 0 || max_out <= 0 || max_out > NMS_MAX_OUT)
+  if (batch <= 0 || batch > 65535 || n_anchor <= 0 || k <= 0 || max_out <= 0 || max_out > NMS_MAX_OUT || cand_stride <= 0)
     return WD_ERR_BAD_ARG;
+  if (nms_mode != WD_NMS_VANILLA && nms_mode != WD_NMS_TORCHVISION && nms_mode != WD_NMS_MMCV) return WD_ERR_BAD_ARG;
   if (!wd_aligned16(boxes) || !wd_aligned16(out_boxes)) return WD_ERR_BAD_ARG;
   if (embed && (!out_embed || embed_dim <= 0 || (embed_dim & 3) || !wd_aligned16(embed) || !wd_aligned16(out_embed)))
     return WD_ERR_BAD_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  unsigned* bounds = static_cast<unsigned*>(workspace);
+  if (nms_mode != WD_NMS_VANILLA) {
+    if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 3u)) return WD_ERR_BAD_ARG;
+    if (workspace_bytes < wd_nms_workspace_bytes(batch)) return WD_ERR_WORKSPACE;
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((2 * batch + 255) / 256), dim3(256), 0, st, bounds, 0u, (long long)2 * batch);
+    hipLaunchKernelGGL(nms_bounds_kernel, dim3((cand_stride + 1023) / 1024, batch), dim3(256), 0, st, cand_idx, cand_count,
+                       cand_stride, boxes, n_anchor, k, meta, nms_mode, mode_param, bounds);
+  }
   hipLaunchKernelGGL(nms_kernel, dim3(batch), dim3(64), 0, st, cand_idx, cand_score, cand_count, cand_stride, boxes,
-                     n_anchor, k, meta, iou_thr, max_out, out_boxes, out_scores, out_labels, out_anchors, out_count);
+                     n_anchor, k, meta, iou_thr, max_out, nms_mode, mode_param, bounds, out_boxes, out_scores, out_labels,
+                     out_anchors, out_count);
   if (embed)
     hipLaunchKernelGGL(gather_embed_kernel, dim3(max_out, batch), dim3(64), 0, st, embed, n_anchor, embed_dim,
                        out_anchors, out_count, max_out, out_embed);

@@ -660,25 +660,17 @@ int launch_split(const WdConvGemm& p, const void* wsp, float unscale, hipStream_
     if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero4)) != hipSuccess || !zp) return WD_ERR_LAUNCH;
     zero = static_cast<const float*>(zp);
   }
-  static bool attr_plain = false, attr_conv = false;
+  static WdAttrOnce attr_plain, attr_conv;
   if constexpr (WHICH != 1) if (conv) {
     auto k = split_gemm_kernel<TM, TN, WM, WN, BKT, true, VAR>;
-    if (!attr_conv) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              T::LDS_BYTES) != hipSuccess) return WD_ERR_LAUNCH;
-      attr_conv = true;
-    }
+    if (wd_set_max_lds(attr_conv, reinterpret_cast<const void*>(k), T::LDS_BYTES) != WD_OK) return WD_ERR_LAUNCH;
     WD_LAUNCH_GEMM(k, dim3((unsigned)nblk), dim3(T::NT), T::LDS_BYTES, st, p, w8, zero, k16, unscale, nbn,
                        vec_c, vec_res, vec_bias, ksplits, ws);
     return wd_launch_status();
   }
   if constexpr (WHICH != 2) if (!conv) {
     auto k = split_gemm_kernel<TM, TN, WM, WN, BKT, false, VAR>;
-    if (!attr_plain) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              T::LDS_BYTES) != hipSuccess) return WD_ERR_LAUNCH;
-      attr_plain = true;
-    }
+    if (wd_set_max_lds(attr_plain, reinterpret_cast<const void*>(k), T::LDS_BYTES) != WD_OK) return WD_ERR_LAUNCH;
     WD_LAUNCH_GEMM(k, dim3((unsigned)nblk), dim3(T::NT), T::LDS_BYTES, st, p, w8, zero, k16, unscale, nbn,
                        vec_c, vec_res, vec_bias, ksplits, ws);
   }

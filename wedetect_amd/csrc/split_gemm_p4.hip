@@ -281,12 +281,8 @@ int launch_p4(const WdConvGemm& p, const void* wsp, float unscale, hipStream_t s
   int ngrp = 2;                                                    // column tiles walked in pairs
   if (ngrp > nbn || nbn % ngrp) ngrp = nbn;
   auto k = split_gemm_p4_kernel<VAR>;
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, P4_LDS) != hipSuccess)
-      return WD_ERR_LAUNCH;
-    attr = true;
-  }
+  static WdAttrOnce attr;
+  if (wd_set_max_lds(attr, reinterpret_cast<const void*>(k), P4_LDS) != WD_OK) return WD_ERR_LAUNCH;
   WD_LAUNCH_GEMM(k, dim3((unsigned)nblk), dim3(256), P4_LDS, st, p, static_cast<const unsigned char*>(wsp), k16, unscale, nbn,
                  vec_c, vec_res, vec_bias, ngrp, nbm);
   return wd_launch_status();

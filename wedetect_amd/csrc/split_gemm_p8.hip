@@ -467,12 +467,8 @@ int launch_p8(const WdConvGemm& p, const void* wsp, float unscale, hipStream_t s
     grid = wgs;
   }
   auto k = split_gemm_p8_kernel<VAR, ABL, PERSIST>;
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS) !=
-        hipSuccess) return WD_ERR_LAUNCH;
-    attr = true;
-  }
+  static WdAttrOnce attr;
+  if (wd_set_max_lds(attr, reinterpret_cast<const void*>(k), P8_LDS) != WD_OK) return WD_ERR_LAUNCH;
   WD_LAUNCH_GEMM(k, dim3((unsigned)grid), dim3(512), P8_LDS, st, p, static_cast<const unsigned char*>(wsp), k16, unscale, nbn,
                  vec_c, vec_res, vec_bias, ngrp, nbm, ps);
   return wd_launch_status();

@@ -213,12 +213,8 @@ int launch_glds(const WdConvGemm& p, const void* wsp, float unscale, hipStream_t
 #endif
   if (ngrp > nbn || nbn % ngrp) ngrp = nbn;
   auto k = split_gemm_glds_kernel<BK, VAR>;
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
-        hipSuccess) return WD_ERR_LAUNCH;
-    attr = true;
-  }
+  static WdAttrOnce attr;
+  if (wd_set_max_lds(attr, reinterpret_cast<const void*>(k), LDS) != WD_OK) return WD_ERR_LAUNCH;
   WD_LAUNCH_GEMM(k, dim3((unsigned)nblk), dim3(256), LDS, st, p, static_cast<const unsigned char*>(wsp), zero, k16,
                      unscale, nbn, vec_c, vec_res, vec_bias, ngrp, nbm, ksplits, ws);
   return wd_launch_status();
@@ -511,12 +507,8 @@ int launch_pingpong(const WdConvGemm& p, const void* wsp, float unscale, hipStre
     zero = static_cast<const float*>(zp);
   }
   auto k = split_gemm_pingpong_kernel<VAR, NBUF, TN>;
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
-        hipSuccess) return WD_ERR_LAUNCH;
-    attr = true;
-  }
+  static WdAttrOnce attr;
+  if (wd_set_max_lds(attr, reinterpret_cast<const void*>(k), LDS) != WD_OK) return WD_ERR_LAUNCH;
   WD_LAUNCH_GEMM(k, dim3((unsigned)nblk), dim3(512), LDS, st, p, static_cast<const unsigned char*>(wsp), zero, k16,
                      unscale, nbn, vec_c, vec_res, vec_bias, ra);
   return wd_launch_status();

@@ -171,13 +171,25 @@ class _TowerHolder:
         range guard's switch to fp32 therefore captures anew."""
         if tower.B > self.graph_max_batch:
             return tower.detect(images_u8, text, meta, **kw)
-        key = (id(tower), tower.precision, tower.neck_pin, int(text.shape[0]), tuple(sorted(kw.items())))
+        k = int(text.shape[0])
+        if k > tower.max_classes or k > tower.text_norm.shape[0]:
+            # a larger bank re-allocates the tower's similarity / top-k buffers: do it BEFORE any capture or replay, and
+            # drop every graph of this tower that still points at the old ones (ADVICE r2: a K=80 graph replayed after a
+            # K=100 call would write into freed memory)
+            tower._alloc_post(max(k, tower.max_classes))
+            if k > tower.text_norm.shape[0]:
+                tower.text_norm = torch.empty(k, tower.text_norm.shape[1], dtype=torch.float32, device=tower.dev)
+                tower.generation += 1
+        self._graphs = {kk: g for kk, g in self._graphs.items() if g.tower is not tower or g.generation == tower.generation}
+        key = (id(tower), tower.generation, tower.precision, tower.neck_pin, k, tuple(sorted((a, str(b)) for a, b in kw.items())))
         g = self._graphs.get(key)
         if g is None:
             from .engine import GraphedDetect
             if len(self._graphs) >= 8:
                 self._graphs.pop(next(iter(self._graphs)))
-            g = self._graphs[key] = GraphedDetect(tower, int(text.shape[0]), **kw)
+            g = self._graphs[key] = GraphedDetect(tower, k, **kw)
+            if g.generation != tower.generation:             # cannot happen after the pre-growth above; never replay a stale graph
+                raise RuntimeError("tower buffers were re-allocated during graph capture")
         return g(images_u8, text, meta)
 
 
@@ -262,6 +274,8 @@ class SimpleYOLOWorldDetector(_DeviceModule):
         self.img_size = tuple(img_size) if img_size is not None else _IMG_SIZE[backbone_size]
         self._h = _TowerHolder(backbone_size, num_prompts, max(num_prompts, 1), num_proposals, precision)
         self._lb = None
+        from .lib import TV_TRICK_MAX_NUMEL
+        self.tv_trick_max_numel = TV_TRICK_MAX_NUMEL[os.environ.get("WEDETECT_TV_NMS_DEVICE", "cpu")]
 
     @torch.no_grad()
     def forward(self, image_paths: Sequence[Union[str, object]], rescale=True) -> List[Dict[str, torch.Tensor]]:
@@ -303,7 +317,11 @@ class SimpleYOLOWorldDetector(_DeviceModule):
             metas.append([dw, dh, 0.0, sc, sc, float(w), float(h), 0.0])
         tower = self._h.tower(len(imgs), self.img_size[0], self.img_size[1])
         meta = torch.tensor(metas, dtype=torch.float32, device=self._h.device)
-        run = lambda: self._h.detect(tower, x, tower.P["prompts"], meta, normalize_text=False, score_thr=0.0, with_embed=True)
+        # torchvision.ops.batched_nms(bbox, scores, labels, 0.7)[:num_proposals] (generate_proposal.py:1210), with the
+        # branch threshold of the device the reference's tensors would live on ($WEDETECT_TV_NMS_DEVICE: "cpu" = the CPU
+        # reference path the parity contract names, "cuda" = what the script's hard-coded .cuda() run takes)
+        run = lambda: self._h.detect(tower, x, tower.P["prompts"], meta, normalize_text=False, score_thr=0.0, with_embed=True,
+                                     nms="torchvision", nms_param=self.tv_trick_max_numel)
         res = run()
         counts = tower.checked_counts(res, run)             # one D2H sync per batch (+ the fp16x3 range guard)
         if tower.overflowed:
@@ -537,8 +555,8 @@ class YOLOWorldDetector(_DeviceModule):
         nms = dict(cfg["nms"])
         if nms.get("type", "nms") != "nms":
             raise NotImplementedError(f"test_cfg.nms.type={nms.get('type')!r}: only the plain greedy 'nms' is implemented")
-        if set(nms) - {"type", "iou_threshold"}:
-            raise NotImplementedError(f"test_cfg.nms options {sorted(set(nms) - {'type', 'iou_threshold'})} are not implemented")
+        if set(nms) - {"type", "iou_threshold", "split_thr"}:      # class_agnostic / max_num / score_threshold: not built
+            raise NotImplementedError(f"test_cfg.nms options {sorted(set(nms) - {'type', 'iou_threshold', 'split_thr'})} are not implemented")
         self.test_cfg = cfg
         self.model_size = model_size
         self.img_scale = tuple(img_scale) if img_scale is not None else _IMG_SIZE[model_size]
@@ -680,7 +698,9 @@ class YOLOWorldDetector(_DeviceModule):
             meta = torch.tensor(metas, dtype=torch.float32, device=dev)
             bank = banks[idxs[0]].to(dev)
             run = lambda: self._h.detect(tower, x, bank, meta, normalize_text=True, score_thr=self.test_cfg["score_thr"],
-                                         iou_thr=self.test_cfg["nms"]["iou_threshold"], with_embed=False)
+                                         iou_thr=self.test_cfg["nms"]["iou_threshold"], with_embed=False,
+                                         # mmdet _bbox_post_process -> mmcv.ops.batched_nms(bboxes, scores, labels, cfg.nms)
+                                         nms="mmcv", nms_param=int(self.test_cfg["nms"].get("split_thr", 10000)))
             res = run()
             counts = tower.checked_counts(res, run)
             if tower.overflowed:

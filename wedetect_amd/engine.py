@@ -132,7 +132,11 @@ class ImageTower:
         # ---- similarity / post-process buffers (sized for max_classes; grown on demand)
         self.nms_pre, self.max_out = nms_pre, max_out
         self.cap = L.topk_capacity(nms_pre)
+        # bumped whenever a buffer that captured hipGraphs hold raw pointers to is re-allocated (scores, top-k workspace,
+        # normalised text bank): graphs captured under an older generation must be dropped, not replayed
+        self.generation = 0
         self._alloc_post(max_classes)
+        self.nms_ws = torch.zeros(max(1, L.nms_workspace_bytes(B) // 4), dtype=torch.int32, device=self.dev)
         self.cand_idx = torch.empty(B, self.cap, dtype=torch.int32, device=self.dev)
         self.cand_score = f(B, self.cap)
         self.cand_count = torch.empty(B, dtype=torch.int32, device=self.dev)
@@ -150,6 +154,7 @@ class ImageTower:
 
     def _alloc_post(self, k: int) -> None:
         self.max_classes = k
+        self.generation += 1
         self.scores = torch.empty(self.B, self.ntot, k, dtype=torch.float32, device=self.dev)
         nbytes = L.topk_workspace_bytes(self.B, self.ntot * k, self.nms_pre)
         self.topk_ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.dev)
@@ -346,6 +351,7 @@ class ImageTower:
             self._alloc_post(k)
         if k > self.text_norm.shape[0]:
             self.text_norm = torch.empty(k, EMBED_DIM, dtype=torch.float32, device=self.dev)
+            self.generation += 1
         t = text.contiguous()
         if normalize:
             L.l2norm_rows(t, self.text_norm[:k])
@@ -357,17 +363,26 @@ class ImageTower:
         return out
 
     # ------------------------------------------------------------------ post-process
+    NMS_MODES = {"vanilla": L.NMS_VANILLA, "torchvision": L.NMS_TORCHVISION, "mmcv": L.NMS_MMCV}
+
     def postprocess(self, scores: torch.Tensor, score_thr: float, meta: torch.Tensor, iou_thr: float = 0.7,
-                    with_embed: bool = True) -> Dict[str, torch.Tensor]:
+                    with_embed: bool = True, nms: str = "vanilla", nms_param: Optional[int] = None) -> Dict[str, torch.Tensor]:
         """scores [B, N, K] -> candidates (score desc, index asc, <= nms_pre) -> class-aware NMS
-        -> <= max_out rows per image.  ``meta`` [B, 8] fp32 device tensor, see wd_nms_gather."""
+        -> <= max_out rows per image.  ``meta`` [B, 8] fp32 device tensor, see wd_nms_gather.
+        ``nms``: which library's batched NMS is reproduced — "torchvision" (generate_proposal.py:1210; ``nms_param`` =
+        the box-coordinate count above which it runs per class, 4000 for CPU tensors), "mmcv" (mmdet's
+        _bbox_post_process, yolo_world_head.py:740-744; ``nms_param`` = split_thr, 10000) or "vanilla" (label test)."""
         B, n, k = scores.shape
+        mode = self.NMS_MODES[nms]
+        if nms_param is None:
+            nms_param = {L.NMS_VANILLA: 0, L.NMS_TORCHVISION: L.TV_TRICK_MAX_NUMEL["cpu"], L.NMS_MMCV: L.MMCV_SPLIT_THR}[mode]
         L.topk_candidates(scores, B, n * k, float(np.float32(score_thr)), self.nms_pre, self.cand_idx,
                           self.cand_score, self.cand_count, self.topk_ws)
         L.nms_gather(self.cand_idx, self.cand_score, self.cand_count, self.cap, self.boxes, n, k, meta,
-                     float(np.float32(iou_thr)), self.max_out, self.embed if with_embed else None, EMBED_DIM,
+                     L.nms_threshold(iou_thr, mode), self.max_out, self.embed if with_embed else None, EMBED_DIM,
                      self.out_boxes, self.out_scores, self.out_labels, self.out_anchors, self.out_count,
-                     self.out_embed if with_embed else None, B)
+                     self.out_embed if with_embed else None, B, nms_mode=mode, mode_param=int(nms_param),
+                     workspace=self.nms_ws)
         res = dict(bboxes=self.out_boxes, scores=self.out_scores, labels=self.out_labels, anchors=self.out_anchors,
                    count=self.out_count)
         if with_embed:
@@ -390,10 +405,14 @@ class ImageTower:
         return self.head()
 
     def detect(self, images_u8, text, meta, *, normalize_text: bool, score_thr: float, iou_thr: float = 0.7,
-               with_embed: bool = False):
+               with_embed: bool = False, nms: Optional[str] = None, nms_param: Optional[int] = None):
+        """The whole step.  ``nms`` None picks the library the reference's path of this text handling uses: normalised
+        text = BNContrastiveHead of the mmdet path -> "mmcv"; prompts as stored = the Uni scripts -> "torchvision"."""
+        if nms is None:
+            nms = "mmcv" if normalize_text else "torchvision"
         self.features(images_u8)
         scores = self.similarity(text, normalize=normalize_text)
-        return self.postprocess(scores, score_thr, meta, iou_thr, with_embed)
+        return self.postprocess(scores, score_thr, meta, iou_thr, with_embed, nms, nms_param)
 
     def checked_counts(self, res: Dict[str, torch.Tensor], rerun) -> List[int]:
         """Kept-row counts of a step on the host (the one D2H sync a caller needs anyway) with the fp16x3 range guard:
@@ -443,14 +462,16 @@ class GraphedDetect:
     """
 
     def __init__(self, tower: ImageTower, num_classes: int, *, normalize_text: bool, score_thr: float,
-                 iou_thr: float = 0.7, with_embed: bool = True, warmup: int = 2):
+                 iou_thr: float = 0.7, with_embed: bool = True, warmup: int = 2, nms: Optional[str] = None,
+                 nms_param: Optional[int] = None):
         self.tower = tower
         dev = tower.dev
         self.images = torch.zeros(tower.B, tower.H, tower.W, 3, dtype=torch.uint8, device=dev)
         self.text = torch.zeros(num_classes, EMBED_DIM, dtype=torch.float32, device=dev)
         self.text[:, 0] = 1.0
         self.meta = tower.identity_meta()
-        kw = dict(normalize_text=normalize_text, score_thr=score_thr, iou_thr=iou_thr, with_embed=with_embed)
+        kw = dict(normalize_text=normalize_text, score_thr=score_thr, iou_thr=iou_thr, with_embed=with_embed, nms=nms,
+                  nms_param=nms_param)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # one-time kernel attribute setup + buffer growth
@@ -461,8 +482,13 @@ class GraphedDetect:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = tower.detect(self.images, self.text, self.meta, **kw)
+        # the graph holds raw pointers to tower.scores / topk_ws / text_norm: it is valid for this generation only
+        self.generation = tower.generation
 
     def __call__(self, images_u8: torch.Tensor, text: torch.Tensor, meta: torch.Tensor):
+        if self.generation != self.tower.generation:
+            raise L.WedetectHipError("stale hipGraph: the tower re-allocated its similarity / top-k buffers (a larger class "
+                                     "bank arrived) after this graph was captured; capture a new one")
         self.images.copy_(images_u8, non_blocking=True)
         self.text.copy_(text, non_blocking=True)
         self.meta.copy_(meta, non_blocking=True)

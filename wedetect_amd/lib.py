@@ -19,12 +19,15 @@ LIB_PATH = os.path.join(_HERE, "libwedetect_hip.so")
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU = 0, 1, 2, 3
 OUT_ROWS, OUT_DECONV2X2 = 0, 1
 SPLIT_A, SPLIT_C = 1, 2
-ABI_VERSION = 8
+ABI_VERSION = 9
+NMS_VANILLA, NMS_TORCHVISION, NMS_MMCV = 0, 1, 2
+TV_TRICK_MAX_NUMEL = {"cpu": 4000, "cuda": 20000}   # torchvision/ops/boxes.py batched_nms: vanilla above this many box coordinates
+MMCV_SPLIT_THR = 10000                                 # mmcv/ops/nms.py batched_nms: per-class loop from this many candidates
 
 EXPORTS = (
     "wd_abi_version", "wd_strerror", "wd_sizeof_conv_gemm", "wd_conv_gemm", "wd_conv_gemm_tuned", "wd_conv_gemm_config", "wd_stem_patchify", "wd_dwconv7",
     "wd_layernorm_rows", "wd_l2norm_rows", "wd_dfl_decode", "wd_topk_workspace_bytes", "wd_topk_capacity",
-    "wd_topk_candidates", "wd_nms_gather", "wd_retrieval_max",
+    "wd_topk_candidates", "wd_nms_workspace_bytes", "wd_nms_gather", "wd_retrieval_max",
     "wd_split_weights_bytes", "wd_split_weights", "wd_conv_gemm_split", "wd_conv_gemm_split_ws", "wd_conv_gemm_split_config", "wd_layernorm_rows_split", "wd_layernorm_rows_split_s2d", "wd_letterbox_u8", "wd_retrieval_max_split", "wd_text_embed", "wd_attention_small", "wd_recall_scratch_floats", "wd_recall_match",
     "wd_max_sigmoid_attn", "wd_adaptive_maxpool_nhwc", "wd_cross_attention_small", "wd_time_next_gemm",
     "wd_cv_resize_paste_u8", "wd_chw_to_hwc_u8", "wd_p8_workspace_bytes", "wd_dwconv7_ln",
@@ -85,7 +88,9 @@ def _load():
     lib.wd_topk_capacity.restype = i32
     lib.wd_topk_capacity.argtypes = [i32]
     lib.wd_topk_candidates.argtypes = [vp, i32, i64, f32, i32, vp, vp, vp, vp, i64, vp]
-    lib.wd_nms_gather.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp, f32, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp]
+    lib.wd_nms_workspace_bytes.restype = i64
+    lib.wd_nms_workspace_bytes.argtypes = [i32]
+    lib.wd_nms_gather.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp, f32, i32, i32, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, i64, vp]
     lib.wd_retrieval_max.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.wd_split_weights_bytes.restype = i64
     lib.wd_split_weights_bytes.argtypes = [i32, i32]
@@ -287,11 +292,29 @@ def topk_candidates(scores, batch, n, thr, nms_pre, out_idx, out_score, out_coun
           "wd_topk_candidates")
 
 
+def nms_workspace_bytes(batch: int) -> int:
+    return LIB.wd_nms_workspace_bytes(batch)
+
+
+def nms_threshold(iou_thr: float, nms_mode: int) -> float:
+    """The fp32 value whose ``ovr > value`` decides like the library's own comparison: mmcv's nms_cpu takes a C++
+    ``float`` (nearest); torchvision's nms_kernel_impl compares the fp32 IoU with a C++ ``double``, i.e. like the
+    largest fp32 <= the Python value (include/wedetect_hip.h, wd_nms_gather)."""
+    import numpy as np
+    t = np.float32(iou_thr)
+    if nms_mode == NMS_TORCHVISION and float(t) > float(iou_thr):
+        t = np.nextafter(t, np.float32(-np.inf), dtype=np.float32)
+    return float(t)
+
+
 def nms_gather(cand_idx, cand_score, cand_count, cand_stride, boxes, n_anchor, k, meta, iou_thr, max_out,
-               embed, embed_dim, out_boxes, out_scores, out_labels, out_anchors, out_count, out_embed, batch) -> None:
+               embed, embed_dim, out_boxes, out_scores, out_labels, out_anchors, out_count, out_embed, batch,
+               nms_mode: int = NMS_VANILLA, mode_param: int = 0, workspace=None) -> None:
+    ws_bytes = 0 if workspace is None else workspace.numel() * workspace.element_size()
     check(LIB.wd_nms_gather(_p(cand_idx), _p(cand_score), _p(cand_count), cand_stride, _p(boxes), n_anchor, k,
-                            _p(meta), iou_thr, max_out, _p(embed), embed_dim, _p(out_boxes), _p(out_scores),
-                            _p(out_labels), _p(out_anchors), _p(out_count), _p(out_embed), batch, stream_ptr()),
+                            _p(meta), iou_thr, max_out, nms_mode, mode_param, _p(embed), embed_dim, _p(out_boxes),
+                            _p(out_scores), _p(out_labels), _p(out_anchors), _p(out_count), _p(out_embed), batch,
+                            _p(workspace), ws_bytes, stream_ptr()),
           "wd_nms_gather")
 
 

@@ -85,9 +85,11 @@ class RegionGatherer:
     process group.  Every rank must submit the same B_local per step (pad the final short batch with count = 0
     rows, or use ``gather_ragged`` for it).
 
-    Per step TWO collectives: the embeddings block, and one int32 block [B_local, 2 R + 2] that carries everything
+    Per step TWO collectives: the embeddings block, and one int32 block [B_local, 2 R + 3] that carries everything
     else the reference gathers (extract_embedding.py:1753-1756): per-region ``scales`` and ``bias`` (fp32 bit
-    patterns), the kept count and the image id — instead of four pickled object gathers."""
+    patterns), the kept count and the 64-bit image id as two int32 words — instead of four pickled object gathers.
+    The block is cleared on every ``submit``: a field the caller leaves out reads as zeros, never as the previous
+    step's values."""
 
     def __init__(self, group=None):
         self.group = group
@@ -99,16 +101,16 @@ class RegionGatherer:
         s = self.slots[self.turn]
         b, r = emb.shape[0], emb.shape[1]
         if s is None or s["emb"].shape != emb.shape or s["emb"].dtype != emb.dtype or s["emb"].device != emb.device:
-            s = dict(emb=torch.empty_like(emb), meta=torch.zeros(b, 2 * r + 2, dtype=torch.int32, device=emb.device),
+            s = dict(emb=torch.empty_like(emb), meta=torch.zeros(b, 2 * r + 3, dtype=torch.int32, device=emb.device),
                      out_e=torch.empty((world * b,) + tuple(emb.shape[1:]), dtype=emb.dtype, device=emb.device),
-                     out_m=torch.empty(world * b, 2 * r + 2, dtype=torch.int32, device=emb.device))
+                     out_m=torch.empty(world * b, 2 * r + 3, dtype=torch.int32, device=emb.device))
             self.slots[self.turn] = s
         return s
 
     def submit(self, embeddings: torch.Tensor, count: torch.Tensor, scales: Optional[torch.Tensor] = None,
                bias: Optional[torch.Tensor] = None, image_ids: Optional[torch.Tensor] = None) -> Optional[Dict[str, torch.Tensor]]:
         """Starts the exchange of this step; returns the PREVIOUS step's gathered result (or None).  ``embeddings``
-        [B, R, D], ``count`` [B]; optional ``scales`` / ``bias`` [B, R] fp32 and ``image_ids`` [B] (< 2^31)."""
+        [B, R, D], ``count`` [B]; optional ``scales`` / ``bias`` [B, R] fp32 and ``image_ids`` [B] (any int64)."""
         prev = self.collect()
         single = not dist.is_available() or not dist.is_initialized()
         world = 1 if single else dist.get_world_size(self.group)
@@ -116,13 +118,14 @@ class RegionGatherer:
         r = embeddings.shape[1]
         s["emb"].copy_(embeddings, non_blocking=True)
         m = s["meta"]
+        m.zero_()
         if scales is not None:
             m[:, :r].copy_(scales.contiguous().view(torch.int32), non_blocking=True)
         if bias is not None:
             m[:, r:2 * r].copy_(bias.contiguous().view(torch.int32), non_blocking=True)
         m[:, 2 * r].copy_(count.to(torch.int32), non_blocking=True)
         if image_ids is not None:
-            m[:, 2 * r + 1].copy_(image_ids.to(torch.int32), non_blocking=True)
+            m[:, 2 * r + 1:2 * r + 3].copy_(image_ids.to(torch.int64).contiguous().view(-1, 1).view(torch.int32), non_blocking=True)
         extra = (scales is not None, bias is not None, image_ids is not None)
         if single:                                    # same contract without a process group: the caller's buffers
             self.pending = (None, dict(out_e=s["emb"], out_m=s["meta"]), extra)   # are free again as soon as submit returns
@@ -152,8 +155,72 @@ class RegionGatherer:
         if extra[1]:
             out["bias"] = m[:, r:2 * r].view(torch.float32)
         if extra[2]:
-            out["image_ids"] = m[:, 2 * r + 1]
+            out["image_ids"] = m[:, 2 * r + 1:2 * r + 3].contiguous().view(torch.int64).view(-1)
         return out
+
+
+class StreamedRecordCollector:
+    """Result collection for a whole evaluation run (extract_embedding.py:1746-1761) with BOUNDED device memory: every
+    step's kept regions go through a :class:`RegionGatherer` (two staging slots of world x B_local x R x D floats,
+    whatever the size of the image set); ``dst`` trims each gathered image to its kept rows and moves those to the
+    host, the other ranks drop the block.  The reference moves only kept rows through its object gathers too; the
+    round-2 form (all results dense on the device, one final all-gather onto EVERY rank) needed N_total x 0.92 MB per
+    GPU.  Every rank must call ``step`` the same number of times with the same B_local (``pad_step`` for ranks whose
+    shard ran out; short batches are padded with count-0 rows)."""
+
+    def __init__(self, batch: int, regions: int, dim: int, device, dst: int = 0, group=None):
+        self.g = RegionGatherer(group)
+        self.batch, self.regions, self.dim, self.dev = batch, regions, dim, device
+        single = not dist.is_available() or not dist.is_initialized()
+        self.world = 1 if single else dist.get_world_size(group)
+        self.rank = 0 if single else dist.get_rank(group)
+        self.dst = dst
+        self.per_rank = [[] for _ in range(self.world)]        # dst only: records in each rank's own image order
+
+    def _pad(self, t, shape, dtype):
+        out = torch.zeros(shape, dtype=dtype, device=self.dev)
+        if t is not None and t.shape[0]:
+            out[: t.shape[0]] = t
+        return out
+
+    def step(self, embeddings, count, scales, bias, image_ids) -> None:
+        b, r, d = self.batch, self.regions, self.dim
+        n = 0 if embeddings is None else int(embeddings.shape[0])
+        if n > b:
+            raise ValueError(f"step holds {n} images, collector was built for {b}")
+        if n < b:                                              # short final batch / exhausted shard: count-0 rows
+            embeddings = self._pad(embeddings, (b, r, d), torch.float32)
+            count = self._pad(count, (b,), torch.int32)
+            scales, bias = self._pad(scales, (b, r), torch.float32), self._pad(bias, (b, r), torch.float32)
+            image_ids = self._pad(image_ids, (b,), torch.int64)
+            valid = torch.zeros(b, dtype=torch.int32, device=self.dev)
+            valid[:n] = 1
+        else:
+            valid = torch.ones(b, dtype=torch.int32, device=self.dev)
+        # the validity flag rides in the count word's sign-free high bit space: count <= R < 2^16
+        self._drain(self.g.submit(embeddings, count.to(torch.int32) + (valid << 16), scales=scales, bias=bias, image_ids=image_ids))
+
+    def pad_step(self) -> None:
+        self.step(None, None, None, None, None)
+
+    def _drain(self, got) -> None:
+        if got is None or self.rank != self.dst:
+            return
+        cnt = got["count"].cpu()
+        valid = (cnt >> 16).bool().tolist()
+        cnt = (cnt & 0xFFFF).tolist()
+        ids = got["image_ids"].cpu().tolist()
+        b = self.batch
+        for i, (v, c, iid) in enumerate(zip(valid, cnt, ids)):
+            if not v:
+                continue
+            self.per_rank[i // b].append({"image_id": int(iid), "embedding": got["embeddings"][i, :c].cpu(),
+                                          "scale": got["scales"][i, :c].cpu(), "bias": got["bias"][i, :c].cpu()})
+
+    def finish(self):
+        """Records in global (rank-major = ``shard_range``) image order on ``dst``; [] elsewhere."""
+        self._drain(self.g.collect())
+        return [rec for lst in self.per_rank for rec in lst]
 
 
 def gather_results(fields: Dict[str, torch.Tensor], group=None) -> Dict[str, torch.Tensor]:
