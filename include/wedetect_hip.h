@@ -99,6 +99,10 @@ typedef struct WdConvGemm {
   float seg_scale[3], seg_bias[3];
   uint32_t* range_flag;        /* fp16x3 kernels only, may be NULL: *range_flag is set to 1 (sticky) when an accumulator
                                 * of this launch is inf / NaN, i.e. an operand left the fp16 range; never cleared here */
+  float* c2;                   /* fp16x3 + WD_SPLIT_C only, may be NULL: an fp32 copy of the output in plain rows (row
+                                * stride ldc2) next to the fp16 hi/lo output in c — for consumers that read fp32 (the
+                                * BottleRep residual, yolo_world_pafpn.py:602-605); plain-row outputs only */
+  int32_t ldc2;
 } WdConvGemm;
 
 int wd_conv_gemm(const WdConvGemm* p, void* stream);
@@ -127,10 +131,15 @@ int wd_conv_gemm_split(const WdConvGemm* p, const void* w_split, float w_unscale
 /* flags: operands that are stored as fp16 (hi, lo) groups instead of fp32 — per row, per 8
  * consecutive elements: [8 x fp16 hi | 8 x fp16 lo] in the 32 bytes the 8 floats would occupy
  * (so buffers, row strides and lda / ldc keep their fp32 meaning).
- *   WD_SPLIT_A: p->a was written by wd_layernorm_rows_split or by a WD_SPLIT_C layer (k % 8 == 0)
- *   WD_SPLIT_C: write p->c in that format for a following WD_SPLIT_A layer (plain rows, no
- *               residual, n % 8 == 0; needs WD_SPLIT_A)
- * Results are bit-identical to the flags = 0 path (the same halves, produced earlier). */
+ *   WD_SPLIT_A: p->a was written by wd_layernorm_rows_split or by a WD_SPLIT_C layer (cin % 8 == 0).  Any geometry:
+ *               1x1 layers run the direct-to-LDS GEMM kernels, k x k / strided convolutions the implicit-GEMM
+ *               LDS-DMA kernel of split_gemm_conv.hip (cin % 16 == 0; im2col by per-lane DMA addresses, a zero page
+ *               for the halo).
+ *   WD_SPLIT_C: write p->c in that format for a following WD_SPLIT_A layer (n % 8 == 0, ldc % 8 == 0).  With
+ *               WD_SPLIT_A: any output addressing (rows, channel slices, c_batch_stride, the 2x2 deconv scatter), an
+ *               fp32 residual and an fp32 copy in p->c2 are allowed.  Without WD_SPLIT_A (fp32 activations split by
+ *               the loader): plain rows, no residual.
+ * Results are bit-identical to the flags = 0 path (the same halves, produced earlier; same K order). */
 #define WD_SPLIT_A 1
 #define WD_SPLIT_C 2
 /* wd_conv_gemm_split with a caller-owned workspace (16-byte aligned): when a launch has few tiles and a long

@@ -82,7 +82,7 @@ def _iou_f32(bi: np.ndarray, bj: np.ndarray) -> np.ndarray:
 
 
 def batched_nms(boxes: np.ndarray, scores: np.ndarray, labels: np.ndarray, thr: float,
-                max_keep: Optional[int] = None, stats: Optional[dict] = None) -> np.ndarray:
+                max_keep: Optional[int] = None, stats: Optional[dict] = None, compare: str = "f32") -> np.ndarray:
     """Label-test form of class-aware greedy NMS == torchvision's _batched_nms_vanilla on sorted input (one global
     loop instead of one per class; tests/test_cpu.py checks the two equal).  It is what WD_NMS_VANILLA computes; the
     reference's call sites go through torchvision_batched_nms / mmcv_batched_nms below.  Inputs must already be in the
@@ -110,6 +110,8 @@ def batched_nms(boxes: np.ndarray, scores: np.ndarray, labels: np.ndarray, thr: 
         rest = np.nonzero((labels[i + 1:] == labels[i]) & ~suppressed[i + 1:])[0] + i + 1
         if rest.size:
             sup = iou_suppresses(boxes[i], boxes[rest], thr)
+            if compare == "double":          # torchvision: fp32 IoU promoted and compared with the C++ double threshold
+                sup = _iou_f32(boxes[i], boxes[rest]).astype(np.float64) > float(thr)
             suppressed[rest[sup]] = True
             if stats is not None:
                 ovr = _iou_f32(boxes[i], boxes[rest]).astype(np.float64)
@@ -208,6 +210,10 @@ def torchvision_batched_nms(boxes: np.ndarray, scores: np.ndarray, idxs: np.ndar
     scores = np.ascontiguousarray(scores, dtype=f32)
     if boxes.size > TV_TRICK_MAX_NUMEL[device_type]:
         # _batched_nms_vanilla: nms() per class on the boxes as given
+        if max_keep is not None and _sorted_desc(scores):
+            # same keeps as the per-class loops + final stable sort below, found by ONE greedy pass with a label test
+            # that can stop at max_keep (tests/test_cpu.py checks the two equal): what the CPU baseline times
+            return batched_nms(boxes, scores, idxs, iou_threshold, max_keep, stats, compare="double")
         keep_mask = np.zeros(scores.shape[0], dtype=bool)
         for class_id in np.unique(idxs):
             curr_indices = np.nonzero(idxs == class_id)[0]
@@ -239,6 +245,9 @@ def mmcv_batched_nms(boxes: np.ndarray, scores: np.ndarray, idxs: np.ndarray, nm
     boxes_for_nms = boxes if class_agnostic else coordinate_offsets(boxes, idxs)
     if boxes_for_nms.shape[0] < split_thr:
         return nms_greedy(boxes_for_nms, scores, thr, "f32", stats, max_keep)
+    if max_keep is not None and _sorted_desc(scores):
+        # per-class loops on the offset boxes + stable sort + [:max_keep] == one label-test pass over them with early exit
+        return batched_nms(boxes_for_nms, scores, idxs, thr, max_keep, stats)
     total_mask = np.zeros(scores.shape[0], dtype=bool)
     for id_ in np.unique(idxs):
         mask = np.nonzero(idxs == id_)[0]
@@ -247,6 +256,10 @@ def mmcv_batched_nms(boxes: np.ndarray, scores: np.ndarray, idxs: np.ndarray, nm
     keep = np.nonzero(total_mask)[0]
     keep = keep[np.argsort(-scores[keep], kind="stable")]
     return keep if max_keep is None else keep[:max_keep]
+
+
+def _sorted_desc(scores: np.ndarray) -> bool:
+    return bool(np.all(scores[:-1] >= scores[1:]))
 
 
 def _finish_stats(stats: dict, scores: np.ndarray, keep: np.ndarray) -> dict:

@@ -126,6 +126,20 @@ def test_oracle_nms_library_forms():
     assert np.array_equal(opp.torchvision_batched_nms(bx, sc, lb, 0.7), fx["lvis.keep_tv"])
     assert not np.array_equal(fx["lvis.keep"], fx["lvis.keep_tv"])     # labels 1100..1202 on 1280-px boxes: quantisation matters
     assert opp.torchvision_batched_nms(np.zeros((0, 4), f), np.zeros(0, f), np.zeros(0, np.int64), 0.7).shape == (0,)
+    # the per-class branches literally (a loop per class, stable sort of the survivors, [:max]) == the one-pass label-test form
+    # with early exit that max_keep selects (what the detectors' oracle calls and the CPU baseline times)
+    g = np.random.default_rng(7)
+    for n, k in ((10500, 1203), (10200, 5)):
+        ctr = g.random((n, 2), dtype=np.float32) * 600
+        wh = g.random((n, 2), dtype=np.float32) * 90 + 6
+        bx = np.concatenate([ctr - wh / 2, ctr + wh / 2], 1).astype(f)
+        bx[n // 2:] = bx[:n // 2] + (g.random((n // 2, 1), dtype=np.float32) * 20 - 10)
+        sc = np.sort(np.round(g.random(n, dtype=np.float32) * 3000) / 3000)[::-1].copy()          # exact ties included
+        lb = np.concatenate([g.integers(0, k, n // 2)] * 2)
+        full = opp.mmcv_batched_nms(bx, sc, lb, dict(type="nms", iou_threshold=0.7))
+        assert np.array_equal(full[:300], opp.mmcv_batched_nms(bx, sc, lb, dict(type="nms", iou_threshold=0.7), max_keep=300))
+        full = opp.torchvision_batched_nms(bx, sc, lb, 0.7)
+        assert np.array_equal(full[:300], opp.torchvision_batched_nms(bx, sc, lb, 0.7, max_keep=300))
 
 
 def test_oracle_retrieval_golden():
@@ -528,7 +542,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     from wedetect_amd import lib as L
     assert set(L.EXPORTS) == declared
     assert L.LIB.wd_abi_version() == L.ABI_VERSION
-    assert ctypes.sizeof(L.ConvGemm) == L.LIB.wd_sizeof_conv_gemm() == 176
+    assert ctypes.sizeof(L.ConvGemm) == L.LIB.wd_sizeof_conv_gemm() == 192
     assert L.topk_capacity(30000) == 32768 and L.topk_workspace_bytes(2, 8400 * 80, 30000) > 2 * 32768 * 8
     assert L.gemm_config(1000, 80, 768).startswith("64x80") and L.gemm_config(100000, 2048, 512).startswith("128x128") and L.gemm_config(1000, 2048, 512).startswith("64x128")
 

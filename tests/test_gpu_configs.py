@@ -5,15 +5,17 @@
   configs[4]  WeDetect-Large retrieval against a 1 000 000-class text bank (per-GPU form; the 8-shard identity)
 (configs[0] is tests/test_gpu_entry.py; configs[3]'s exchange is covered by the gloo tests and the one-rank RCCL run there.)
 
-Each full batch is checked three ways: image 0 IS the image of the reference-generated B = 1 golden (tests/golden/
-net_*_b1_640.npz) and must reproduce its checksums and kept lists; the post-process of EVERY image must equal the
-oracle's post-process run on the device's own score / box tensors bit for bit (candidate order, NMS keeps, boxes); and
-two other images must come out bit-identical when run alone (batch independence)."""
+Each full batch is checked four ways: image 0 IS the image of the reference-generated B = 1 golden (tests/golden/
+net_*_b1_640.npz) and must reproduce its checksums and kept lists ORDER-EXACT (zero tie-run relaxations, asserted); one
+image from the middle of the batch goes through the CPU oracle's whole network on the box (the oracle is bit-identical
+to the reference on the golden cases) and must agree on embeddings / scores / boxes and, exactly, on both kept lists;
+the post-process of EVERY image must equal the oracle's post-process run on the device's own score / box tensors bit
+for bit (candidate order, NMS keeps, boxes); and two other images must come out bit-identical when run alone."""
 import numpy as np
 import pytest
 import torch
 
-from tests.util import assert_close, check_checksum, compare_kept_lists, golden, to_np
+from tests.util import assert_close, assert_no_relaxations, check_checksum, compare_kept_lists, golden, to_np
 
 pytestmark = pytest.mark.gpu
 
@@ -81,6 +83,35 @@ def _run_config(arch, b, k, fixture, precision):
                                 got_boxes=res_u["bboxes"][0, :n0], ref_boxes=ref_boxes)
     assert_close(f"{tag} uni img0 embeddings[:, :16]", to_np(res_u["embeddings"][0])[jj][:, :16], fx["img0.embed16"][gg], 1e-3, 1e-3)
     assert_close(f"{tag} uni img0 boxes", to_np(res_u["bboxes"][0])[jj], ref_boxes[gg], 2e-2, 1e-5)
+    # ---- a mid-batch image against the CPU oracle's own network run (batch-position bugs of the GEMM tilings)
+    from oracle import ref_cpu as orc
+    from wedetect_amd.arch import get_arch
+    im = b // 2 + 1
+    sd_t = orc.to_torch(sd)
+    with torch.no_grad():
+        _, p_cpu = orc.forward_features(sd_t, get_arch(arch), imgs[im:im + 1])
+        flat_mm = orc.head_flat(sd_t, p_cpu, text.cpu()[None], normalize_text=True)
+        flat_u = orc.head_flat(sd_t, p_cpu, sd_t["embeddings"], normalize_text=False)
+    assert_close(f"{tag} img{im} embeddings vs CPU oracle", embed[im], flat_mm["embed"][0], 1e-3)
+    assert_close(f"{tag} img{im} scores vs CPU oracle", scores[im], flat_mm["scores"][0], 1e-3)
+    assert_close(f"{tag} img{im} boxes vs CPU oracle", boxes[im], flat_mm["boxes"][0], 1e-2)
+    o = opp.mmdet_predict_image(flat_mm["boxes"][0].numpy(), flat_mm["scores"][0].numpy(), tuple(float(v) for v in pad),
+                                tuple(float(v) for v in sf), tuple(int(v) for v in ori))
+    n = int(res["count"][im])
+    mg = o["margins"]
+    compare_kept_lists(f"{tag} mmdet img{im} vs CPU oracle network", res["anchors"][im, :n], res["labels"][im, :n], res["scores"][im, :n],
+                       o["anchors"], o["labels"], o["scores"], [mg["iou_margin"], mg["pair_gap"], mg["kept_gap"], mg["cut_gap"]],
+                       got_boxes=res["bboxes"][im, :n], ref_boxes=o["bboxes"])
+    ls = np.asarray(tower.lvl_logit_scale, np.float32)
+    cb = np.asarray(tower.lvl_bias, np.float32)
+    o = opp.uni_predict_image(flat_u["boxes"][0].numpy(), flat_u["embed"][0].numpy(), flat_u["scores"][0].numpy(),
+                              flat_u["level_of"].numpy(), ls, cb)
+    n = int(res_u["count"][im])
+    mg = o["margins"]
+    compare_kept_lists(f"{tag} uni img{im} vs CPU oracle network", res_u["anchors"][im, :n], res_u["labels"][im, :n], res_u["scores"][im, :n],
+                       o["anchors"], o["labels"], o["scores"], [mg["iou_margin"], mg["pair_gap"], mg["kept_gap"], mg["cut_gap"]],
+                       got_boxes=res_u["bboxes"][im, :n], ref_boxes=o["bboxes"])
+    assert_no_relaxations(tag)          # the BASELINE configurations reproduce the reference's lists with no tie-run allowance
     # ---- batch independence: two images alone, bit for bit
     t1 = ImageTower(arch, packed, 1, 640, 640, max_classes=max(k, 256), precision=precision)
     for i in (b // 2, b - 1):

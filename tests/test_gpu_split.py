@@ -410,3 +410,127 @@ def test_p8_persistent_kernel_bit_identical_and_repeatable(m, n, k, mode):
     with pytest.raises(L.WedetectHipError):                       # fewer tiles than CUs: ranges shorter than a tile would chain
         L.conv_gemm(xs[:2048], None, bias, small, w_split=ws, split_cfg=65, split_flags=flags, workspace=park,
                     **dict(kw, win=2048, **({"res": kw["res"][:2048]} if "res" in kw else {})))
+
+
+# ------------------------------------------------------------------------------------------ pre-split implicit-GEMM (split_gemm_conv.hip)
+def _to_split(x2d: torch.Tensor) -> torch.Tensor:
+    """fp32 rows -> the fp16 hi/lo group format a WD_SPLIT_C producer writes, in a buffer of the same byte size
+    (wd_split_weights with scale 1: the same two roundings as the GEMM loader's split)."""
+    from wedetect_amd import lib as L
+    rows, k = x2d.shape
+    assert k % 16 == 0
+    out = torch.empty(rows, k, dtype=torch.float32, device="cuda")
+    L.check(L.LIB.wd_split_weights(x2d.contiguous().data_ptr(), rows, k, 1.0, out.data_ptr(), L.stream_ptr()), "split")
+    return out
+
+
+def _from_split(buf: torch.Tensor) -> torch.Tensor:
+    """hi + lo of a split-format buffer as float64 (for checking a WD_SPLIT_C output against its fp32 twin)."""
+    rows, k = buf.shape
+    h = buf.contiguous().view(torch.float16).view(rows, k // 8, 2, 8)
+    return (h[:, :, 0].double() + h[:, :, 1].double()).reshape(rows, k)
+
+
+CONV_PP_CASES = [
+    # name,            b, h,  w,  cin, n,   k, s, act,  res,   form
+    ("3x3 c128 40x40", 3, 40, 40, 128, 128, 3, 1, "silu", True, "dual"),
+    ("3x3 c128 s2",    2, 40, 40, 128, 128, 3, 2, "relu", False, "split_slice"),
+    ("3x3 c64 n64",    2, 26, 30, 64,  64,  3, 1, "silu", True, "f32"),
+    ("3x3 c256 20x20", 2, 20, 20, 256, 256, 3, 1, "silu", False, "split"),
+    ("3x3 ragged",     1, 13, 17, 32,  96,  3, 1, "silu", True, "split"),
+    ("1x1 wide n",     2, 9,  31, 256, 768, 1, 1, "none", False, "batch_stride"),
+    ("1x1 dual",       2, 12, 20, 384, 128, 1, 1, "silu", False, "dual"),
+    ("2x2 s2",         2, 16, 12, 64,  128, 2, 2, "none", False, "f32"),
+]
+
+
+@pytest.mark.parametrize("case", CONV_PP_CASES, ids=[c[0] for c in CONV_PP_CASES])
+@pytest.mark.parametrize("cfg", [-1, 73, 74])
+def test_conv_pp_bit_identical_to_loader_split(case, cfg):
+    """The LDS-DMA implicit-GEMM kernel on pre-split activations (every output form: fp32, fp16 hi/lo, both at once,
+    channel slices, batch-strided rows; fp32 residual) against the register-staged loader-split kernel on the fp32 twin
+    of the same tensor: same halves, same K order, same epilogue arithmetic -> the same bits."""
+    from wedetect_amd import lib as L
+    name, b_, h, w_, ci, co, kk, stride, act, with_res, form = case
+    pad = 1 if kk == 3 else 0
+    ho, wo = (h + 2 * pad - kk) // stride + 1, (w_ + 2 * pad - kk) // stride + 1
+    m = b_ * ho * wo
+    x = _rand((b_ * h * w_, ci), 41)
+    wrow = _rand((co, kk * kk * ci), 42, (ci * kk * kk) ** -0.5)
+    bias = _rand((co,), 43)
+    res = _rand((m, co), 44) if with_res else None
+    ws = L.split_weights(wrow)
+    actc = dict(none=L.ACT_NONE, relu=L.ACT_RELU, silu=L.ACT_SILU)[act]
+    geo = dict(batch=b_, hin=h, win=w_, cin=ci, lda=ci, kh=kk, kw=kk, stride=stride, pad=pad, n=co, act=actc, res=res,
+               ldres=co if with_res else 0, res_alpha=0.625, w_split=ws)
+    xs = _to_split(x)
+    if form == "batch_stride":
+        rows = ho * wo + 7
+        ref = torch.zeros(b_, rows, co, device="cuda")
+        got = torch.zeros(b_, rows, co, device="cuda")
+        L.conv_gemm(x, None, bias, ref[0, 3:], ldc=co, c_batch_stride=rows, **geo)
+        L.conv_gemm(xs, None, bias, got[0, 3:], ldc=co, c_batch_stride=rows, split_flags=L.SPLIT_A, split_cfg=cfg if cfg > 0 else -1, **geo)
+        assert torch.equal(got, ref), f"{name} cfg{cfg}: batch-strided fp32 output differs"
+        return
+    ldc = co + 64 if form == "split_slice" else co
+    ref = torch.zeros(m, ldc, device="cuda")
+    L.conv_gemm(x, None, bias, ref[:, ldc - co:], ldc=ldc, **geo)
+    if form == "f32":
+        got = torch.zeros(m, ldc, device="cuda")
+        L.conv_gemm(xs, None, bias, got, ldc=ldc, split_flags=L.SPLIT_A, split_cfg=cfg if cfg > 0 else 70, **geo)
+        assert torch.equal(got, ref), f"{name} cfg{cfg}: fp32 output differs from the loader-split kernel"
+        return
+    got = torch.zeros(m, ldc, device="cuda")
+    c2 = torch.full((m, co), float("nan"), device="cuda") if form == "dual" else None
+    L.conv_gemm(xs, None, bias, got[:, ldc - co:], ldc=ldc, split_flags=L.SPLIT_A | L.SPLIT_C, split_cfg=cfg if cfg > 0 else -1,
+                c2=c2, ldc2=co if c2 is not None else 0, **geo)
+    want = _to_split(ref[:, ldc - co:].contiguous())                  # split of the loader-split kernel's fp32 output
+    assert torch.equal(got[:, ldc - co:].contiguous().view(torch.int32), want.view(torch.int32)), f"{name} cfg{cfg}: hi/lo output differs"
+    assert float(got[:, : ldc - co].abs().max()) == 0.0 if ldc > co else True
+    if c2 is not None:
+        assert torch.equal(c2, ref), f"{name} cfg{cfg}: fp32 copy differs"
+
+
+def test_conv_pp_split_k_deconv_and_c_only_split():
+    """(a) two-way split-K (the 20 x 20 maps): equal to the loader-split kernel's split-K result; (b) the 2x2 transposed
+    conv scatter written as fp16 hi/lo groups; (c) WD_SPLIT_C without WD_SPLIT_A (fp32 activations in, split out)."""
+    from wedetect_amd import lib as L
+    b_, h, w_, ci, co = 2, 20, 20, 256, 256
+    x = _rand((b_ * h * w_, ci), 51)
+    wrow = _rand((co, 9 * ci), 52, (9 * ci) ** -0.5)
+    bias = _rand((co,), 53)
+    res = _rand((b_ * h * w_, co), 54)
+    ws = L.split_weights(wrow)
+    work = torch.empty(2 * b_ * h * w_ * co + 64, device="cuda")
+    geo = dict(batch=b_, hin=h, win=w_, cin=ci, lda=ci, kh=3, kw=3, stride=1, pad=1, n=co, ldc=co, act=L.ACT_SILU, res=res,
+               ldres=co, res_alpha=0.3, w_split=ws, workspace=work, k_splits=2)
+    ref = torch.empty(b_ * h * w_, co, device="cuda")
+    L.conv_gemm(x, None, bias, ref, **geo)
+    got = torch.empty_like(ref)
+    c2 = torch.empty_like(ref)
+    L.conv_gemm(_to_split(x), None, bias, got, split_flags=L.SPLIT_A | L.SPLIT_C, c2=c2, ldc2=co, **geo)
+    assert torch.equal(c2, ref) and torch.equal(got.view(torch.int32), _to_split(ref).view(torch.int32))
+    # (b) deconv scatter, hi/lo output into the first third of a concat buffer
+    b_, h, w_, ci, co = 2, 5, 7, 64, 32
+    a = _rand((b_ * h * w_, ci), 55)
+    wd, bias = _rand((4 * co, ci), 56, 0.1), _rand((4 * co,), 57)
+    wsd = L.split_weights(wd)
+    kw = dict(batch=b_, hin=h, win=w_, cin=ci, lda=ci, n=4 * co, ldc=3 * co, out_mode=L.OUT_DECONV2X2, w_split=wsd)
+    ref = torch.zeros(b_ * 4 * h * w_, 3 * co, device="cuda")
+    L.conv_gemm(a, None, bias, ref, **kw)
+    got = torch.zeros_like(ref)
+    L.conv_gemm(_to_split(a), None, bias, got, split_flags=L.SPLIT_A | L.SPLIT_C, **kw)
+    assert torch.equal(got[:, :co].contiguous().view(torch.int32), _to_split(ref[:, :co].contiguous()).view(torch.int32))
+    assert float(got[:, co:].abs().max()) == 0.0
+    # (c) loader-split kernel writing hi/lo (C-only split): 1x1, ReLU, channel slice
+    m, ci, co = 5000, 512, 128
+    a, w, bias = _rand((m, ci), 58), _rand((co, ci), 59, ci ** -0.5), _rand((co,), 60)
+    wsw = L.split_weights(w)
+    ref = torch.zeros(m, 3 * co, device="cuda")
+    kw = dict(batch=1, hin=1, win=m, cin=ci, lda=ci, n=co, ldc=3 * co, act=L.ACT_RELU, w_split=wsw)
+    L.conv_gemm(a, None, bias, ref[:, co:], **kw)
+    got = torch.zeros_like(ref)
+    L.conv_gemm(a, None, bias, got[:, co:], split_flags=L.SPLIT_C, **kw)
+    assert torch.equal(got[:, co:2 * co].contiguous().view(torch.int32), _to_split(ref[:, co:2 * co].contiguous()).view(torch.int32))
+    assert float(got[:, :co].abs().max()) == 0.0 and float(got[:, 2 * co:].abs().max()) == 0.0
+    assert float((_from_split(got[:, co:2 * co].contiguous()) - ref[:, co:2 * co].double()).abs().max()) < 1e-6

@@ -102,6 +102,10 @@ static int pick_split_cfg(const WdConvGemm& p) {
 }
 
 long long wd_p8_workspace_floats();                                   // split_gemm_p8.hip
+// split_gemm_conv.hip: implicit-GEMM LDS-DMA kernel for pre-split activations (any geometry, every output form)
+bool wd_conv_pp_ok(const WdConvGemm& p, int flags);
+int wd_launch_conv_pp(const WdConvGemm& p, const void* w, float unscale, int flags, hipStream_t st, int ksplits, float* ws,
+                      long long ws_floats, int variant);
 
 extern "C" int64_t wd_p8_workspace_bytes(void) { return 4 * wd_p8_workspace_floats(); }
 
@@ -175,11 +179,46 @@ static int conv_gemm_split_impl(const WdConvGemm* pp, const void* w_split, float
   if (rc != WD_OK) return rc;
   if (flags & ~(WD_SPLIT_A | WD_SPLIT_C)) return WD_ERR_BAD_ARG;
   if (ws && !wd_aligned16(ws)) return WD_ERR_BAD_ARG;
+  if (p.c2 && !(flags & WD_SPLIT_C)) return WD_ERR_BAD_ARG;
   const bool production = cfg < 0;
   if (cfg < 0) cfg = pick_split_cfg(p);
   const bool plain = p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0;
   const bool special = p.out_mode != WD_OUT_ROWS || p.c_batch_stride > 0 || p.seg_rows > 0 || p.sigmoid ||
                        p.out_scale != 1.0f || p.out_bias != 0.0f;
+  if (flags & WD_SPLIT_A) {
+    // Pre-split activations.  Plain row-output 1x1 layers keep the GEMM kernels tuned for the ConvNeXt MLPs (below);
+    // everything else — k x k / strided convolutions, scatter / batch-stride outputs, residual or dual-format outputs of a
+    // WD_SPLIT_C layer — runs the implicit-GEMM LDS-DMA kernel (split_gemm_conv.hip).  cfg 70 / 73 / 74 force it (A/B runs).
+    const bool covered = plain && !special && !p.c2 && !((flags & WD_SPLIT_C) && p.res);
+    const bool forced = cfg == 70 || cfg == 73 || cfg == 74;
+    if (forced || (production && !covered)) {
+      if (!wd_conv_pp_ok(p, flags)) return forced || !covered ? WD_ERR_UNSUPPORTED : WD_ERR_BAD_ARG;
+      const long long wsf = ws ? ws_bytes / 4 : 0;
+      int splits = force_splits > 0 ? force_splits : 1;
+      if (force_splits == 0 && wsf > 0 && !forced) {                 // latency mode: under-filled launches split K
+        const long long tiles = (long long)((p.m + 255) / 256) * ((p.n + 127) / 128);
+        const int nk = p.k / 16;
+        if (tiles < 128 && nk >= 32) {
+          int s2 = (int)(256 / tiles);
+          if (s2 > nk / 16) s2 = nk / 16;
+          if (s2 > 8) s2 = 8;
+          while (s2 > 1 && (long long)s2 * p.m * p.n > wsf) --s2;
+          if (s2 > 1) splits = s2;
+        }
+      }
+      return wd_launch_conv_pp(p, w_split, w_unscale, flags, st, splits, ws, wsf, cfg == 73 ? 3 : cfg == 74 ? 4 : 0);
+    }
+  }
+  if (flags == WD_SPLIT_C) {
+    // fp32 activations split by the loader, output written as fp16 hi/lo groups (the neck layers that read the ConvNeXt
+    // residual streams and feed pre-split consumers): plain 1x1 layers, plain rows, no residual
+    if (!plain || special || p.res || p.c2 || p.n % 8 || p.ldc % 8 || (p.bias && !wd_aligned16(p.bias)) || !wd_aligned16(p.c))
+      return WD_ERR_UNSUPPORTED;
+    constexpr int VC = SVAR_XCD | SVAR_PIN | SVAR_LDSEPI | SVAR_CSPLIT;
+    const long long tiles = (long long)((p.m + 127) / 128) * ((p.n + 127) / 128);
+    return tiles < 1024 ? launch_split<2, 2, 2, 2, 32, VC, 1>(p, w_split, w_unscale, st)
+                        : launch_split<2, 2, 2, 2, 16, VC, 1>(p, w_split, w_unscale, st);
+  }
   if (flags != 0) {
     // pre-split operands: 128-wide tiles only (every layer on that path has n % 128 == 0 in the
     // shipped towers; other widths still work, with padding).  Plain layers go global -> LDS

@@ -1,0 +1,502 @@
+// split_gemm_conv.hip — fp16x3 implicit-GEMM convolution for PRE-SPLIT activations: the neck / head
+// convolution family of the image tower (yolo_world_pafpn.py:40-68, 566-647, 692-715; yolo_world_head.py:194-232).
+//
+// Round 1-2 ran these layers on the register-staged loader-split kernel (split_gemm_impl.h): fp32 activations are
+// re-split by every column tile and every filter tap that re-reads them (2.5 VALU per element), staged through
+// VGPRs and ds_write (20-35 % of the LDS cycles were bank conflicts), one barrier and one exposed load latency per
+// 12-24 MFMAs: 0.08-0.26 of the fp16x3 roof, 9.2 ms of the 41.6 ms step.  Here the producers write their outputs
+// as fp16 hi/lo groups (the WD_SPLIT_C epilogue below, also for residual / dual-format / scatter outputs), and the
+// K loop is pure data movement like the ConvNeXt MLP kernels':
+//   * every operand byte goes global -> LDS with global_load_lds_dwordx4 (1 KB per instruction, no VGPR staging,
+//     no ds_write, no VALU); im2col is done by the DMA's PER-LANE source address: lane (row, 16-byte slot) of an
+//     activation instruction points at input pixel (ho*stride - pad + kh, wo*stride - pad + kw), channel chunk of
+//     the K stage, or at a zero page when that tap falls outside the image (halo) or the row is past m;
+//   * unpadded 64-byte LDS rows, XOR-swizzled on the global side (slot ^ (row/4 & 3)): conflict-free ds_read_b128;
+//   * 256 x 128 (or 256 x 64) tile, 8 waves in two groups half an iteration apart (the ping-pong schedule of
+//     split_gemm_pre.hip): each SIMD always has one wave issuing MFMAs while its partner issues the DMAs (an
+//     LDS-DMA instruction costs 60-185 issue cycles) and reads fragments; an LDS ring of NBUF stages of k = 16 with
+//     the DMA NBUF-1 stages ahead and counted s_waitcnt vmcnt (never 0 in steady state).  These launches are small
+//     (200-1600 tiles): the ring depth, not occupancy, is what hides the L2 / fabric latency.
+// Same MFMA chain per accumulator and the same K order as the loader-split kernels: BIT-IDENTICAL results
+// (tests/test_gpu_split.py).
+#include "split_gemm_impl.h"
+
+namespace {
+
+constexpr int CV_BM = 256, CV_WROWS = 128, CV_ROWB = 64, CV_STAGE = (CV_BM + CV_WROWS) * CV_ROWB, CV_NI = 3;
+
+__device__ __forceinline__ void cv_dma16(unsigned lds_addr, const unsigned char* src) {
+  asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(src) : "memory", "m0");
+}
+
+// wave-uniform: let the newest `groups` DMA groups (CV_NI instructions each) stay outstanding
+__device__ __forceinline__ void cv_wait_groups(int groups) {
+  if (groups <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if (groups == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if (groups == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if (groups == 3) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+}
+
+// ---------------------------------------------------------------------------------------
+// Epilogue of one (row, 8 consecutive channels) piece — the unit of the fp16 hi/lo output format.  Same
+// arithmetic, same order per element as epi_quad (split_gemm_impl.h).  Outputs, any combination the host asks for:
+//   CSPLIT : p.c receives [hi x8 | lo x8] groups (rows / batch-stride rows / the 2x2 deconv scatter)
+//   !CSPLIT: p.c receives fp32
+//   p.c2   : an fp32 copy in plain rows (ldc2) next to a CSPLIT output — for consumers that read fp32
+//            (the BottleRep "+ alpha x" residual, yolo_world_pafpn.py:602-605)
+// Host-side contract: n % 8 == 0, bias / res / c / c2 16-byte aligned, ldres % 4 == 0, ldc2 % 4 == 0,
+// ldc % 8 == 0 (CSPLIT) or % 4 == 0.
+// ---------------------------------------------------------------------------------------
+template <int ACT, bool SPECIAL, bool CSPLIT>
+__device__ __forceinline__ void epi_oct(const WdConvGemm& p, float unscale, int m, int n, const f32x4 v0, const f32x4 v1) {
+  if (p.range_flag) {
+    if (wd_any_nonfinite4(v0[0] + v0[1], v0[2] + v0[3], v1[0] + v1[1], v1[2] + v1[3])) *p.range_flag = 1u;
+  }
+  f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) {
+    b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
+    b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+  }
+  const EpiRow er = epi_row<SPECIAL>(p, m);
+  f32x4 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float x0 = sact<ACT>(fmaf(v0[r], unscale, b0[r]));
+    float x1 = sact<ACT>(fmaf(v1[r], unscale, b1[r]));
+    if (SPECIAL) {
+      x0 = x0 * er.oscale + er.obias;
+      x1 = x1 * er.oscale + er.obias;
+      if (p.sigmoid) { x0 = wd_sigmoid_fast(x0); x1 = wd_sigmoid_fast(x1); }
+    }
+    o0[r] = x0;
+    o1[r] = x1;
+  }
+  if (p.res != nullptr) {
+    const float* rp = p.res + (size_t)m * p.ldres + n;
+    const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      o0[r] += p.res_alpha * r0[r];
+      o1[r] += p.res_alpha * r1[r];
+    }
+  }
+  if (p.c2 != nullptr) {
+    float* qp = p.c2 + (size_t)m * p.ldc2 + n;
+    *reinterpret_cast<f32x4*>(qp) = o0;
+    *reinterpret_cast<f32x4*>(qp + 4) = o1;
+  }
+  float* rowp;
+  int col = n;
+  if (SPECIAL && p.out_mode == WD_OUT_DECONV2X2) {
+    const int ncq = p.n >> 2;
+    const int tap = n / ncq;
+    col = n - tap * ncq;
+    rowp = p.c + (er.crow + (size_t)(tap >> 1) * er.hw2 + (tap & 1)) * p.ldc;
+  } else {
+    rowp = p.c + er.crow * p.ldc;
+  }
+  if (CSPLIT) {
+    u32x2 h0, l0, h1, l1;
+    split4(o0, h0, l0);
+    split4(o1, h1, l1);
+    unsigned char* cp = reinterpret_cast<unsigned char*>(rowp) + (size_t)(col >> 3) * 32;
+    *reinterpret_cast<u32x4*>(cp) = u32x4{h0[0], h0[1], h1[0], h1[1]};
+    *reinterpret_cast<u32x4*>(cp + 16) = u32x4{l0[0], l0[1], l1[0], l1[1]};
+  } else {
+    *reinterpret_cast<f32x4*>(rowp + col) = o0;
+    *reinterpret_cast<f32x4*>(rowp + col + 4) = o1;
+  }
+}
+
+// a wave's TM x TN accumulator tiles through its private LDS patch: a lane ends with 8 consecutive channels of a
+// row, 4 lanes cover a 128-byte row segment
+template <int IJ, int TM, int TN, int ACT, bool SPECIAL, bool CSPLIT>
+struct EpiOctWalk {
+  static __device__ __forceinline__ void run(const WdConvGemm& p, float unscale, int mw, int nw, int lane,
+                                             const f32x16 (&acc)[TM][TN], float* patch) {
+    constexpr int I = IJ / TN, J = IJ % TN;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<f32x4*>(patch + (lane & 31) * EPI_LDT + 8 * g + 4 * (lane >> 5)) =
+          f32x4{acc[I][J][4 * g], acc[I][J][4 * g + 1], acc[I][J][4 * g + 2], acc[I][J][4 * g + 3]};
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int row = ps * 16 + (lane >> 2);
+      const int m = mw + I * 32 + row;
+      const int n = nw + J * 32 + 8 * (lane & 3);
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(patch + row * EPI_LDT + 8 * (lane & 3));
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(patch + row * EPI_LDT + 8 * (lane & 3) + 4);
+      if (m < p.m && n < p.n) epi_oct<ACT, SPECIAL, CSPLIT>(p, unscale, m, n, v0, v1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    EpiOctWalk<IJ + 1, TM, TN, ACT, SPECIAL, CSPLIT>::run(p, unscale, mw, nw, lane, acc, patch);
+  }
+};
+template <int TM, int TN, int ACT, bool SPECIAL, bool CSPLIT>
+struct EpiOctWalk<TM * TN, TM, TN, ACT, SPECIAL, CSPLIT> {
+  static __device__ __forceinline__ void run(const WdConvGemm&, float, int, int, int, const f32x16 (&)[TM][TN], float*) {}
+};
+
+template <int TM, int TN, bool CSPLIT>
+__device__ __forceinline__ void epi_oct_all(const WdConvGemm& p, float unscale, int mw, int nw, int lane,
+                                            const f32x16 (&acc)[TM][TN], float* patch) {
+  const bool special = p.out_mode != WD_OUT_ROWS || p.c_batch_stride > 0 || p.seg_rows > 0 || p.sigmoid ||
+                       p.out_scale != 1.0f || p.out_bias != 0.0f;
+#define WD_OCT(A, S) EpiOctWalk<0, TM, TN, A, S, CSPLIT>::run(p, unscale, mw, nw, lane, acc, patch)
+  if (special) {
+    switch (p.act) {
+      case WD_ACT_RELU: WD_OCT(WD_ACT_RELU, true); break;
+      case WD_ACT_SILU: WD_OCT(WD_ACT_SILU, true); break;
+      case WD_ACT_GELU: WD_OCT(WD_ACT_GELU, true); break;
+      default: WD_OCT(WD_ACT_NONE, true); break;
+    }
+  } else {
+    switch (p.act) {
+      case WD_ACT_RELU: WD_OCT(WD_ACT_RELU, false); break;
+      case WD_ACT_SILU: WD_OCT(WD_ACT_SILU, false); break;
+      case WD_ACT_GELU: WD_OCT(WD_ACT_GELU, false); break;
+      default: WD_OCT(WD_ACT_NONE, false); break;
+    }
+  }
+#undef WD_OCT
+}
+
+// ---------------------------------------------------------------------------------------
+// TN = 2: 256 x 128 output tile (wave = 64 x 64); TN = 1: 256 x 64 (wave = 64 x 32).  The LDS stage always has 128
+// weight rows (rows past n come from the zero page and are never read when TN = 1).
+// ksplits > 1: workgroup (tile, ks) walks K stages [ks * per, ...) and writes raw partial sums to ws[ks][m][n];
+// splitk_oct_reduce_kernel adds them in split order and applies the epilogue.
+// ---------------------------------------------------------------------------------------
+template <int NBUF, int TN, bool CSPLIT>
+__global__ void __launch_bounds__(512, NBUF <= 3 ? 4 : 2)
+split_conv_pp_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, const float* __restrict__ zero, int k16,
+                     float unscale, int nbn, int ksplits, float* __restrict__ ws) {
+  constexpr int TM = 2, BM = CV_BM, BN = 64 * TN, ROWB = CV_ROWB, STAGE = CV_STAGE, NI = CV_NI, DIST = NBUF - 1;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int group = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+  int tile = blockIdx.x;
+  {
+    const int nwg = gridDim.x, xcd = tile & 7, idx = tile >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int ntiles = gridDim.x / ksplits;
+  const int ks = tile / ntiles;
+  tile -= ks * ntiles;
+  const int bn = tile % nbn, bm = tile / nbn;
+  const int m0 = bm * BM, n0 = bn * BN;
+  const int nk_all = p.k >> 4;
+  const int per_split = (nk_all + ksplits - 1) / ksplits;
+  const int s_begin = ks * per_split;
+  const int nk = (s_begin + per_split < nk_all ? s_begin + per_split : nk_all) - s_begin;
+
+  // DMA sources: instruction j of this wave fills combined rows [(wave*3 + j)*16, +16) of a stage (rows 0..255 =
+  // activation rows of the tile, 256..383 = weight rows); lane = (row in the group of 16, 16-byte slot).
+  // Activation rows keep the address of their (kh, kw) = (0, 0) input pixel and one validity bit per filter tap;
+  // weight rows their row pointer.  Per stage the tap / channel offset is wave-uniform (cin % 16 == 0: a stage never
+  // straddles a tap).
+  const unsigned char* base[NI];
+  unsigned mask[NI];
+  const int taps = p.kh * p.kw;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int row = (wave * NI + j) * 16 + (lane >> 2);
+    const int logical = (lane & 3) ^ ((row >> 2) & 3);
+    const int memchunk = ((logical & 1) << 1) | ((logical >> 1) & 1);
+    if (row < BM) {
+      const int m = m0 + row;
+      const bool ok = m < p.m;
+      const int mm = ok ? m : 0;
+      const int wo = mm % p.wout;
+      const int q = mm / p.wout;
+      const int ho = q % p.hout;
+      const int b = q / p.hout;
+      const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+      const long long pix = ((long long)b * p.hin + hi0) * p.win + wi0;
+      base[j] = reinterpret_cast<const unsigned char*>(p.a) + pix * p.lda * 4 + memchunk * 16;
+      unsigned mk = 0;
+      for (int tp = 0; tp < taps; ++tp) {
+        const int kh = tp / p.kw, kw = tp - kh * p.kw;
+        const bool in = (unsigned)(hi0 + kh) < (unsigned)p.hin && (unsigned)(wi0 + kw) < (unsigned)p.win;
+        mk |= (ok && in) ? (1u << tp) : 0u;
+      }
+      mask[j] = mk;
+    } else {
+      const int n = n0 + row - BM;
+      const bool ok = n < p.n;
+      base[j] = wsp + (size_t)(ok ? n : 0) * k16 * 4 + memchunk * 16;
+      mask[j] = ok ? 0xFFFFFFFFu : 0u;
+    }
+  }
+  // stage cursor of the DMA stream (wave-uniform): filter tap, channel offset inside the tap, weight byte offset
+  int i_tap, i_ci, i_kh, i_kw, i_w;
+  {
+    const int kofs = s_begin * 16;
+    i_tap = kofs / p.cin;
+    i_ci = kofs - i_tap * p.cin;
+    i_kh = i_tap / p.kw;
+    i_kw = i_tap - i_kh * p.kw;
+    i_w = s_begin * ROWB;
+  }
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_raw;
+  const unsigned char* zp = reinterpret_cast<const unsigned char*>(zero);
+  auto issue = [&](int buf) {
+    const unsigned lbase = lds0 + buf * STAGE + wave * NI * 1024;
+    const int a_off = ((i_kh * p.win + i_kw) * p.lda + i_ci) * 4;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const bool is_a = (wave * NI + j) * 16 < BM;                     // wave-uniform
+      const int off = is_a ? a_off : i_w;
+      const unsigned bit = is_a ? (mask[j] >> i_tap) & 1u : mask[j] & 1u;
+      cv_dma16(__builtin_amdgcn_readfirstlane(lbase + j * 1024), bit ? base[j] + off : zp);
+    }
+    i_w += ROWB;
+    i_ci += 16;
+    if (i_ci == p.cin) {
+      i_ci = 0;
+      ++i_tap;
+      if (++i_kw == p.kw) { i_kw = 0; ++i_kh; }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  int aoff_h[TM], aoff_l[TM], boff_h[TN], boff_l[TN];
+  const int hsel = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int row = group * 128 + wm * 64 + i * 32 + (lane & 31), f = (row >> 2) & 3;
+    aoff_h[i] = row * ROWB + ((hsel ^ f) << 4);
+    aoff_l[i] = row * ROWB + (((2 + hsel) ^ f) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int row = wn * 32 * TN + j * 32 + (lane & 31), f = (row >> 2) & 3;
+    boff_h[j] = BM * ROWB + row * ROWB + ((hsel ^ f) << 4);
+    boff_l[j] = BM * ROWB + row * ROWB + (((2 + hsel) ^ f) << 4);
+  }
+  h8 xh[TM], xl[TM], wh[TN], wl[TN];
+  auto read = [&](int buf) {
+    const unsigned char* sp = smem_raw + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      xh[i] = *reinterpret_cast<const h8*>(sp + aoff_h[i]);
+      xl[i] = *reinterpret_cast<const h8*>(sp + aoff_l[i]);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      wh[j] = *reinterpret_cast<const h8*>(sp + boff_h[j]);
+      wl[j] = *reinterpret_cast<const h8*>(sp + boff_l[j]);
+    }
+  };
+  auto mfma = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[j], xh[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], xl[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], xh[i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // prologue: stages 0 .. DIST-1 in flight, all landed before anyone reads
+#pragma unroll
+  for (int d = 0; d < DIST; ++d)
+    if (d < nk) issue(d);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int bcur = 0, bnext = 1, bfill = DIST % NBUF;
+  auto advance = [&]() {
+    bcur = bcur == NBUF - 1 ? 0 : bcur + 1;
+    bnext = bnext == NBUF - 1 ? 0 : bnext + 1;
+    bfill = bfill == NBUF - 1 ? 0 : bfill + 1;
+  };
+#define WD_SLOT_BARRIER()                 \
+  __builtin_amdgcn_sched_barrier(0);      \
+  __syncthreads();                        \
+  __builtin_amdgcn_sched_barrier(0)
+  // Schedule (as split_gemm_pingpong_kernel): group 0 computes stage s in slot 2s and moves data in slot 2s+1,
+  // group 1 the other way round.  Before the barrier that ends a wave's data slot its share of the NEXT stage to be
+  // read must have landed; younger DMA groups stay in flight.
+  if (group == 0) {
+    read(0);
+    for (int s = 0; s < nk; ++s) {
+      mfma();                                  // slot 2s
+      __builtin_amdgcn_sched_barrier(0);
+      {                                        // issued so far: up to stage s+DIST-1; stage s+1 must be complete
+        const int last = s + DIST - 1 < nk - 1 ? s + DIST - 1 : nk - 1;
+        cv_wait_groups(last - (s + 1));
+      }
+      WD_SLOT_BARRIER();
+      if (s + DIST < nk) issue(bfill);         // slot 2s+1
+      if (s + 1 < nk) read(bnext);
+      WD_SLOT_BARRIER();
+      advance();
+    }
+  } else {
+    for (int s = 0; s < nk; ++s) {
+      if (s + DIST < nk) issue(bfill);         // slot 2s
+      read(bcur);
+      __builtin_amdgcn_sched_barrier(0);
+      {                                        // issued so far: up to stage s+DIST; stage s+1 must be complete
+        const int last = s + DIST < nk - 1 ? s + DIST : nk - 1;
+        cv_wait_groups(last - (s + 1));
+      }
+      WD_SLOT_BARRIER();
+      mfma();                                  // slot 2s+1
+      WD_SLOT_BARRIER();
+      advance();
+    }
+  }
+#undef WD_SLOT_BARRIER
+  __syncthreads();
+
+  const int mw = m0 + group * 128 + wm * 64, nw = n0 + wn * 32 * TN;
+  float* patch = reinterpret_cast<float*>(smem_raw) + wave * 32 * EPI_LDT;
+  static_assert(2 * STAGE >= 8 * 32 * EPI_LDT * 4, "operand LDS must hold one patch per wave");
+  if (ksplits > 1) {
+    WdConvGemm pr = p;                                 // raw partial sums, plain rows [m][n] of this split
+    pr.bias = nullptr; pr.res = nullptr; pr.c2 = nullptr; pr.range_flag = nullptr;
+    pr.c = ws + (size_t)ks * p.m * p.n; pr.ldc = p.n;
+    pr.out_mode = WD_OUT_ROWS; pr.c_batch_stride = 0; pr.seg_rows = 0; pr.sigmoid = 0; pr.out_scale = 1.0f; pr.out_bias = 0.0f;
+    pr.act = WD_ACT_NONE;
+    EpiOctWalk<0, TM, TN, WD_ACT_NONE, false, false>::run(pr, 1.0f, mw, nw, lane, acc, patch);
+    return;
+  }
+  epi_oct_all<TM, TN, CSPLIT>(p, unscale, mw, nw, lane, acc, patch);
+}
+
+// split-K second pass: one thread per (row, 8 channels); partial sums added in split order (deterministic, and the
+// same order as splitk_reduce_kernel: results equal the loader-split kernels' split-K results bit for bit)
+template <int ACT, bool SPECIAL, bool CSPLIT>
+__global__ void __launch_bounds__(256) splitk_oct_reduce_kernel(const WdConvGemm p, const float* __restrict__ ws, int splits,
+                                                                float unscale) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int no = p.n >> 3;
+  if (idx >= (long long)p.m * no) return;
+  const int m = (int)(idx / no), n = (int)(idx - (long long)m * no) * 8;
+  const size_t plane = (size_t)p.m * p.n;
+  const float* src = ws + (size_t)m * p.n + n;
+  f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+  for (int s = 1; s < splits; ++s) {
+    v0 += *reinterpret_cast<const f32x4*>(src + s * plane);
+    v1 += *reinterpret_cast<const f32x4*>(src + s * plane + 4);
+  }
+  epi_oct<ACT, SPECIAL, CSPLIT>(p, unscale, m, n, v0, v1);
+}
+
+template <bool CSPLIT>
+int launch_oct_reduce(const WdConvGemm& p, const float* ws, int splits, float unscale, hipStream_t st) {
+  const long long total = (long long)p.m * (p.n >> 3);
+  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  const bool special = p.out_mode != WD_OUT_ROWS || p.c_batch_stride > 0 || p.seg_rows > 0 || p.sigmoid ||
+                       p.out_scale != 1.0f || p.out_bias != 0.0f;
+#define WD_RED(A, S) hipLaunchKernelGGL((splitk_oct_reduce_kernel<A, S, CSPLIT>), grid, block, 0, st, p, ws, splits, unscale)
+  if (special) {
+    switch (p.act) {
+      case WD_ACT_RELU: WD_RED(WD_ACT_RELU, true); break;
+      case WD_ACT_SILU: WD_RED(WD_ACT_SILU, true); break;
+      case WD_ACT_GELU: WD_RED(WD_ACT_GELU, true); break;
+      default: WD_RED(WD_ACT_NONE, true); break;
+    }
+  } else {
+    switch (p.act) {
+      case WD_ACT_RELU: WD_RED(WD_ACT_RELU, false); break;
+      case WD_ACT_SILU: WD_RED(WD_ACT_SILU, false); break;
+      case WD_ACT_GELU: WD_RED(WD_ACT_GELU, false); break;
+      default: WD_RED(WD_ACT_NONE, false); break;
+    }
+  }
+#undef WD_RED
+  return wd_launch_status();
+}
+
+template <int NBUF, int TN, bool CSPLIT>
+int launch_conv_pp(const WdConvGemm& p, const void* wsp, float unscale, hipStream_t st, int ksplits, float* ws) {
+  constexpr int BN = 64 * TN, LDS = NBUF * CV_STAGE;
+  const int nbm = (p.m + CV_BM - 1) / CV_BM, nbn = (p.n + BN - 1) / BN;
+  const long long nblk = (long long)nbm * nbn * ksplits;
+  if (nblk <= 0 || nblk > 0x7fffffffLL) return WD_ERR_BAD_ARG;
+  const int k16 = (p.k + 15) / 16 * 16;
+  static const float* zero = nullptr;
+  if (!zero) {
+    void* zp = nullptr;
+    if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero4)) != hipSuccess || !zp) return WD_ERR_LAUNCH;
+    zero = static_cast<const float*>(zp);
+  }
+  auto k = split_conv_pp_kernel<NBUF, TN, CSPLIT>;
+  static WdAttrOnce attr;
+  if (wd_set_max_lds(attr, reinterpret_cast<const void*>(k), LDS) != WD_OK) return WD_ERR_LAUNCH;
+  WD_LAUNCH_GEMM(k, dim3((unsigned)nblk), dim3(512), LDS, st, p, static_cast<const unsigned char*>(wsp), zero, k16, unscale,
+                 nbn, ksplits, ws);
+  return wd_launch_status();
+}
+
+}  // namespace
+
+// What this family covers: pre-split activations (WD_SPLIT_A), cin % 16 == 0, at most 16 filter taps, n % 8 == 0,
+// vector-friendly pointers / strides; any geometry (1x1, 3x3 stride 1 / 2, ...), any output form of the epilogue above.
+bool wd_conv_pp_ok(const WdConvGemm& p, int flags) {
+  if (!(flags & WD_SPLIT_A)) return false;
+  if (p.cin % 16 || p.k % 16 || p.lda % 8 || p.kh * p.kw > 16 || p.n % 8) return false;
+  if (!wd_aligned16(p.a) || !wd_aligned16(p.c)) return false;
+  if (p.bias && !wd_aligned16(p.bias)) return false;
+  if (p.res && (!wd_aligned16(p.res) || p.ldres % 4)) return false;
+  if (p.c2 && (!(flags & WD_SPLIT_C) || !wd_aligned16(p.c2) || p.ldc2 % 4 || p.ldc2 < p.n || p.out_mode != WD_OUT_ROWS ||
+               p.c_batch_stride > 0))
+    return false;
+  if ((flags & WD_SPLIT_C) ? (p.ldc % 8 != 0) : (p.ldc % 4 != 0)) return false;
+  if (p.out_mode == WD_OUT_DECONV2X2 && (p.n % 32)) return false;
+  return true;
+}
+
+// variant: 0 = production choice; 3 / 4 = ring depth forced (A/B runs)
+int wd_launch_conv_pp(const WdConvGemm& p, const void* w, float unscale, int flags, hipStream_t st, int ksplits, float* ws,
+                      long long ws_floats, int variant) {
+  if (!wd_conv_pp_ok(p, flags)) return WD_ERR_UNSUPPORTED;
+  const bool csplit = (flags & WD_SPLIT_C) != 0;
+  const bool narrow = (p.n % 128) != 0 && ((p.n + 63) / 64) * 64 < ((p.n + 127) / 128) * 128;
+  const long long tiles = (long long)((p.m + CV_BM - 1) / CV_BM) * (narrow ? (p.n + 63) / 64 : (p.n + 127) / 128);
+  if (ksplits < 1) ksplits = 1;
+  if (ksplits > 1 && (!ws || (long long)ksplits * p.m * p.n > ws_floats)) return WD_ERR_WORKSPACE;
+  if (ksplits > (p.k >> 4)) ksplits = p.k >> 4;
+  // ring depth: launches that give a CU at most one workgroup hide the load latency with a deeper ring (4 stages,
+  // 96 KB); fuller launches run two workgroups per CU on 3 stages (72 KB each)
+  int nbuf = (tiles * ksplits <= 320) ? 4 : 3;
+  if (variant == 3 || variant == 4) nbuf = variant;
+  int rc;
+#define WD_CPP(NB, TNN, CS) launch_conv_pp<NB, TNN, CS>(p, w, unscale, st, ksplits, ws)
+  if (nbuf == 4) {
+    if (narrow) rc = csplit ? WD_CPP(4, 1, true) : WD_CPP(4, 1, false);
+    else rc = csplit ? WD_CPP(4, 2, true) : WD_CPP(4, 2, false);
+  } else {
+    if (narrow) rc = csplit ? WD_CPP(3, 1, true) : WD_CPP(3, 1, false);
+    else rc = csplit ? WD_CPP(3, 2, true) : WD_CPP(3, 2, false);
+  }
+#undef WD_CPP
+  if (rc != WD_OK || ksplits <= 1) return rc;
+  return csplit ? launch_oct_reduce<true>(p, ws, ksplits, unscale, st) : launch_oct_reduce<false>(p, ws, ksplits, unscale, st);
+}
