@@ -63,6 +63,7 @@ KERNEL_SYMBOL = {
     "fp16x3 128x256x16/4w/p4/plain": ["split_gemm_p4_kernel<2048>", "split_gemm_p4_kernel<0>"],
     "fp16x3 256x256x32/8w/p8s/plain": ["split_gemm_p8_kernel<2048, 0, true>", "split_gemm_p8_kernel<0, 0, true>"],
     "fp16x3 256x256x32/8w/p8/plain": ["split_gemm_p8_kernel<2048, 0, false>", "split_gemm_p8_kernel<0, 0, false>"],
+    "fp16x3 256x128x16/8w/dma/conv": ["split_conv_pp_kernel<3, 2, true, 0>", "split_conv_pp_kernel<4, 2, true, 0>"],
 }
 
 
@@ -160,8 +161,13 @@ class GemmTimer:
             plain = kh == 1 and kw_ == 1 and stride == 1 and pad == 0
             ws_t = kw.get("workspace")
             park = ws_t is not None and bool(kw.get("split_flags", 0)) and ws_t.numel() * 4 == lib.p8_workspace_bytes()
+            flags = kw.get("split_flags", 0)
+            special = (kw.get("out_mode", 0) != 0 or kw.get("c_batch_stride", 0) > 0 or kw.get("seg") is not None or kw.get("sigmoid")
+                       or kw.get("out_scale", 1.0) != 1.0 or kw.get("out_bias", 0.0) != 0.0)
+            covered = plain and not special and kw.get("c2") is None and not ((flags & lib.SPLIT_C) and kw.get("res") is not None)
+            dma = kw.get("w_split") is not None and bool(flags & lib.SPLIT_A) and not covered
             tag = lib.gemm_config(m, n, k, split=kw.get("w_split") is not None, conv=not plain,
-                                  presplit=bool(kw.get("split_flags", 0)), park=park) + ("/plain" if plain else "/conv")
+                                  presplit=bool(flags & lib.SPLIT_A), park=park, dma=dma) + ("/plain" if plain else "/conv")
             s, e = self.pool.pop() if self.pool else self._pair()
             lib.time_next_gemm(s, e)
             orig(a, w, bias, c, **kw)

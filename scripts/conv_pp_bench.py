@@ -44,35 +44,40 @@ def timeit(fn, n=20, warm=5):
     return ts[len(ts) // 2]
 
 
-g = torch.Generator(device="cuda").manual_seed(1)
-work = torch.empty(2 * 32 * 400 * 256 + 64, device="cuda")
-print(f"{'shape':44s} {'old us':>8s} {'TF':>6s} | {'pp auto':>8s} {'TF':>6s} {'nbuf3':>8s} {'nbuf4':>8s}  identical")
-for (b, h, w, ci, n, k, s, res, out) in SHAPES:
-    pad = 1 if k == 3 else 0
-    ho, wo = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
-    m = b * ho * wo
-    x = torch.randn(b * h * w, ci, device="cuda", generator=g)
-    wt = torch.randn(n, k * k * ci, device="cuda", generator=g) * (k * k * ci) ** -0.5
-    bias = torch.randn(n, device="cuda", generator=g)
-    r = torch.randn(m, n, device="cuda", generator=g) if res else None
-    ws = L.split_weights(wt)
-    xs = to_split(x)
-    ksp = 2 if (k == 3 and s == 1 and h * w <= 400 and 9 * ci >= 2304) else 0
-    geo = dict(batch=b, hin=h, win=w, cin=ci, lda=ci, kh=k, kw=k, stride=s, pad=pad, n=n, ldc=n, act=L.ACT_SILU, res=r,
-               ldres=n if res else 0, res_alpha=0.5, w_split=ws)
-    if ksp:
-        geo.update(workspace=work, k_splits=ksp)
-    c0, c1 = torch.empty(m, n, device="cuda"), torch.empty(m, n, device="cuda")
-    fl = L.SPLIT_A | (L.SPLIT_C if out == "split" else 0)
-    t_old = timeit(lambda: L.conv_gemm(x, None, bias, c0, **geo))
-    row = []
-    for cfg in (-1, 73, 74):
-        try:
-            row.append(timeit(lambda: L.conv_gemm(xs, None, bias, c1, split_flags=fl, split_cfg=cfg, **geo)))
-        except Exception as e:
-            row.append(float("nan"))
-    L.conv_gemm(xs, None, bias, c1, split_flags=fl, split_cfg=-1, **geo)
-    same = torch.equal(c1.view(torch.int32), (to_split(c0) if out == "split" else c0).view(torch.int32))
-    fl_ = 2.0 * m * n * k * k * ci
-    print(f"{b}x{h}x{w} c{ci}->{n} {k}x{k} s{s} res={int(res)} ks={ksp} {out:5s}".ljust(44) +
-          f" {t_old:8.1f} {fl_ / t_old / 1e6:6.1f} | {row[0]:8.1f} {fl_ / row[0] / 1e6:6.1f} {row[1]:8.1f} {row[2]:8.1f}  {same}")
+def main():
+    g = torch.Generator(device="cuda").manual_seed(1)
+    work = torch.empty(2 * 32 * 400 * 256 + 64, device="cuda")
+    print(f"{'shape':44s} {'old us':>8s} {'TF':>6s} | {'dma auto':>8s} {'TF':>6s} {'ring 3':>8s} {'ring 4':>8s}  identical")
+    for (b, h, w, ci, n, k, s, res, out) in SHAPES:
+        pad = 1 if k == 3 else 0
+        ho, wo = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
+        m = b * ho * wo
+        x = torch.randn(b * h * w, ci, device="cuda", generator=g)
+        wt = torch.randn(n, k * k * ci, device="cuda", generator=g) * (k * k * ci) ** -0.5
+        bias = torch.randn(n, device="cuda", generator=g)
+        r = torch.randn(m, n, device="cuda", generator=g) if res else None
+        ws = L.split_weights(wt)
+        xs = to_split(x)
+        ksp = 2 if (k == 3 and s == 1 and h * w <= 400 and 9 * ci >= 2304) else 0
+        geo = dict(batch=b, hin=h, win=w, cin=ci, lda=ci, kh=k, kw=k, stride=s, pad=pad, n=n, ldc=n, act=L.ACT_SILU, res=r,
+                   ldres=n if res else 0, res_alpha=0.5, w_split=ws)
+        if ksp:
+            geo.update(workspace=work, k_splits=ksp)
+        c0, c1 = torch.empty(m, n, device="cuda"), torch.empty(m, n, device="cuda")
+        fl = L.SPLIT_A | (L.SPLIT_C if out == "split" else 0)
+        t_old = timeit(lambda: L.conv_gemm(x, None, bias, c0, **geo))
+        row = []
+        for cfg in (-1, 73, 74):
+            try:
+                row.append(timeit(lambda: L.conv_gemm(xs, None, bias, c1, split_flags=fl, split_cfg=cfg, **geo)))
+            except Exception as e:
+                row.append(float("nan"))
+        L.conv_gemm(xs, None, bias, c1, split_flags=fl, split_cfg=-1, **geo)
+        same = torch.equal(c1.view(torch.int32), (to_split(c0) if out == "split" else c0).view(torch.int32))
+        fl_ = 2.0 * m * n * k * k * ci
+        print(f"{b}x{h}x{w} c{ci}->{n} {k}x{k} s{s} res={int(res)} ks={ksp} {out:5s}".ljust(44) +
+              f" {t_old:8.1f} {fl_ / t_old / 1e6:6.1f} | {row[0]:8.1f} {fl_ / row[0] / 1e6:6.1f} {row[1]:8.1f} {row[2]:8.1f}  {same}")
+
+
+if __name__ == "__main__":
+    main()

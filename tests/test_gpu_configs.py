@@ -46,7 +46,7 @@ def _run_config(arch, b, k, fixture, precision):
         rows = tower.hw[i][0] * tower.hw[i][1]
         check_checksum(f"{tag} c{i+1}", tower.x[i][:rows], fx, f"c{i+1}", 1e-3, 1e-3)
     tower.neck()
-    for i, t in enumerate((tower.p3, tower.p4, tower.p5)):
+    for i, t in enumerate(tower.pyramid()):
         check_checksum(f"{tag} p{i+3}", t[: tower.nl[i]], fx, f"p{i+3}", 1e-3, 1e-3)
     embed, boxes = tower.head()
     for l in range(3):

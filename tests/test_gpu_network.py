@@ -71,7 +71,7 @@ def test_tower_vs_oracle_all_stages(arch, b, hw):
     for i in range(4):
         assert_close(f"{arch} c{i+1}", nhwc(tower.x[i], b, tower.hw[i], a.dims[i]), c_ref[i].permute(0, 2, 3, 1), TOL, TOL)
     tower.neck()
-    for i, (t, r) in enumerate(zip((tower.p3, tower.p4, tower.p5), p_ref)):
+    for i, (t, r) in enumerate(zip(tower.pyramid(), p_ref)):
         assert_close(f"{arch} p{i+3}", nhwc(t, b, tower.lv[i], r.shape[1]), r.permute(0, 2, 3, 1), TOL, TOL)
     embed, boxes = tower.head()
     assert_close(f"{arch} embeddings", embed, flat["embed"], TOL, TOL)
@@ -148,7 +148,7 @@ def test_base_against_reference_goldens(fixture, arch, b, hw):
     for i in range(4):
         check_checksum(f"{fixture} c{i+1}", tower.x[i], fx, f"c{i+1}", TOL, TOL)
     tower.neck()
-    for i, t in enumerate((tower.p3, tower.p4, tower.p5)):
+    for i, t in enumerate(tower.pyramid()):
         check_checksum(f"{fixture} p{i+3}", t, fx, f"p{i+3}", TOL, TOL)
     embed, boxes = tower.head()
     for l in range(3):
@@ -186,7 +186,7 @@ def test_large_and_tiny_goldens():
         for i in range(4):
             check_checksum(f"{fixture} c{i+1}", tower.x[i], fx, f"c{i+1}", TOL, TOL)
         tower.neck()
-        for i, t in enumerate((tower.p3, tower.p4, tower.p5)):
+        for i, t in enumerate(tower.pyramid()):
             check_checksum(f"{fixture} p{i+3}", t, fx, f"p{i+3}", TOL, TOL)
         if arch == "large":
             embed, _ = tower.head()
@@ -284,3 +284,34 @@ def test_hipgraph_replay_equals_eager_and_is_faster_at_batch1():
     tg = timeit(lambda: g(x1, text, meta))
     print(f"[tiny b1 640] eager {te*1e3:.2f} ms/step, hipGraph {tg*1e3:.2f} ms/step")
     assert tg < te * 1.05
+
+
+@pytest.mark.parametrize("arch,b,hw", [("base", 2, 128), ("tiny", 3, 96), ("large", 1, 64), ("base", 1, 640)])
+def test_presplit_neck_head_is_bit_identical_to_the_loader_split_path(arch, b, hw, monkeypatch):
+    """Round 3: neck / head activations travel as fp16 hi/lo groups through the LDS-DMA implicit-GEMM kernel
+    (split_gemm_conv.hip).  Same halves, same K order, same epilogue arithmetic as the register-staged loader-split
+    kernels of rounds 1-2 ($WEDETECT_NECK_PRESPLIT=0): region embeddings, DFL boxes and scores must come out
+    BIT-IDENTICAL, and P3..P5 (stored split) must be the fp32 values to the 2^-22 the format carries."""
+    from wedetect_amd import weights as W
+    from wedetect_amd.engine import ImageTower
+    from wedetect_amd.pack import pack
+    sd = W.make_state_dict(arch, num_prompts=64)
+    packed = pack(sd, arch)
+    x = torch.from_numpy(W.make_images(b, hw, hw)).cuda()
+    monkeypatch.setenv("WEDETECT_NECK_PRESPLIT", "0")
+    t_old = ImageTower(arch, packed, b, hw, hw, precision="fp16x3")
+    monkeypatch.setenv("WEDETECT_NECK_PRESPLIT", "1")
+    t_new = ImageTower(arch, packed, b, hw, hw, precision="fp16x3")
+    assert not t_old._neck_split() and t_new._neck_split()
+    e0, b0 = t_old.features(x)
+    s0 = t_old.similarity(t_old.P["prompts"], normalize=False).clone()
+    e1, b1 = t_new.features(x)
+    s1 = t_new.similarity(t_new.P["prompts"], normalize=False)
+    torch.cuda.synchronize()
+    assert torch.equal(e0, e1), f"{arch}: embeddings differ (max |d| {float((e0 - e1).abs().max()):.3e})"
+    assert torch.equal(b0, b1) and torch.equal(s0, s1)
+    for i, (p_old, p_new) in enumerate(zip(t_old.pyramid(), t_new.pyramid())):
+        d = (p_old.double() - p_new.double()).abs()
+        bound = 2.0 ** -21 * p_old.double().abs() + 1e-7          # hi + lo carries the fp32 value to 2^-22 relative (3e-8 absolute below the fp16 normal range)
+        assert bool((d <= bound).all()), f"{arch} P{i+3}: split storage off by {float(d.max()):.3e}"
+    assert int(t_new.range_flags.sum()) == 0

@@ -246,10 +246,13 @@ def test_presplit_flags_are_validated():
     base = dict(batch=1, hin=1, win=m, cin=k, lda=k, n=n, ldc=n, w_split=ws)
     with pytest.raises(L.WedetectHipError):                       # unknown flag bit
         L.conv_gemm(a, None, None, c, split_flags=4, **base)
-    with pytest.raises(L.WedetectHipError):                       # C split without a split A
-        L.conv_gemm(a, None, None, c, split_flags=L.SPLIT_C, **base)
-    with pytest.raises(L.WedetectHipError):                       # C split cannot carry a residual
-        L.conv_gemm(a, None, None, c, split_flags=L.SPLIT_A | L.SPLIT_C, res=c, ldres=n, **base)
+    with pytest.raises(L.WedetectHipError):                       # C split of a loader-split layer (fp32 A): no residual
+        L.conv_gemm(a, None, None, c, split_flags=L.SPLIT_C, res=c, ldres=n, **base)
+    with pytest.raises(L.WedetectHipError):                       # an fp32 copy (c2) only exists next to a split output
+        L.conv_gemm(a, None, None, c, split_flags=L.SPLIT_A, c2=torch.empty_like(c), ldc2=n, **base)
+    with pytest.raises(L.WedetectHipError):                       # split output rows are groups of 8 channels: ldc % 8
+        L.conv_gemm(a, None, None, torch.empty(m, n + 4, device="cuda"), split_flags=L.SPLIT_A | L.SPLIT_C, res=c, ldres=n,
+                    **dict(base, ldc=n + 4))
     a12, w12 = _rand((m, 12), 83), _rand((n, 12), 84)
     with pytest.raises(L.WedetectHipError):                       # groups of 8 need k % 8 == 0
         L.conv_gemm(a12, None, None, c, batch=1, hin=1, win=m, cin=12, lda=12, n=n, ldc=n, w_split=L.split_weights(w12),

@@ -34,9 +34,10 @@ MODEL_TYPES = {
 TRAINING_ONLY_TYPES = ("CrossEntropyLoss", "mmyoloIoULoss", "DistributionFocalLoss", "BatchTaskAlignedAssigner")
 PIPELINE_TYPES = {
     "LoadImageFromFile": "host: read the image (PIL / cv2), uint8 HWC",
-    "WeDetectKeepRatioResize": "host (cv2 resize in the reference); preprocess.DeviceLetterbox is the device form of the "
-                               "PIL letterbox of generate_proposal.py:17-82 — same geometry, int(round()) vs int() sizes",
-    "WeDetectLetterResize": "host (pad to the target with 114); DeviceLetterbox pads on the device",
+    "WeDetectKeepRatioResize": "pipeline.WeDetectKeepRatioResize: the reference's geometry (transforms.py:94-123), pixels resampled on "
+                               "the DEVICE by wd_cv_resize_paste_u8 (OpenCV's INTER_AREA / INTER_LINEAR arithmetic, fused with the pad)",
+    "WeDetectLetterResize": "pipeline.WeDetectLetterResize: pad_param / scale_factor bookkeeping of transforms.py:180-272; the 114 pad is "
+                            "written by the same device kernel",
     "LoadAnnotations": "no-op at inference",
     "LoadText": "class names -> YOLOWorldDetector.reparameterize(texts)",
     "PackDetInputs": "detector.DetDataSample metainfo (ori_shape, scale_factor, pad_param)",

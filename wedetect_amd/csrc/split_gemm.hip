@@ -133,8 +133,13 @@ static int pick_presplit_cfg(int m, int n, int k, bool park) {
   return m >= 131072 ? 63 : 60;
 }
 
-// is_conv: 0 = plain, 1 = conv, 2 = plain with pre-split operands, 3 = the same with a park workspace on offer
+// is_conv: 0 = plain, 1 = conv, 2 = plain with pre-split operands, 3 = the same with a park workspace on offer,
+// 4 = pre-split activations through the implicit-GEMM LDS-DMA kernel (k x k / strided convs, scatter / batch-stride / dual outputs)
 extern "C" const char* wd_conv_gemm_split_config(int32_t m, int32_t n, int32_t k, int32_t is_conv) {
+  if (is_conv == 4) {
+    const bool narrow = (n % 128) != 0 && ((n + 63) / 64) * 64 < ((n + 127) / 128) * 128;
+    return narrow ? "fp16x3 256x64x16/8w/dma" : "fp16x3 256x128x16/8w/dma";
+  }
   if ((is_conv == 2 || is_conv == 3) && k % 16 == 0) {
     switch (pick_presplit_cfg(m, n, k, is_conv == 3)) {
       case 65: return "fp16x3 256x256x32/8w/p8s";
@@ -190,7 +195,7 @@ static int conv_gemm_split_impl(const WdConvGemm* pp, const void* w_split, float
     // everything else — k x k / strided convolutions, scatter / batch-stride outputs, residual or dual-format outputs of a
     // WD_SPLIT_C layer — runs the implicit-GEMM LDS-DMA kernel (split_gemm_conv.hip).  cfg 70 / 73 / 74 force it (A/B runs).
     const bool covered = plain && !special && !p.c2 && !((flags & WD_SPLIT_C) && p.res);
-    const bool forced = cfg == 70 || cfg == 73 || cfg == 74;
+    const bool forced = cfg == 70 || cfg == 73 || cfg == 74 || (cfg >= 700 && cfg < 716);
     if (forced || (production && !covered)) {
       if (!wd_conv_pp_ok(p, flags)) return forced || !covered ? WD_ERR_UNSUPPORTED : WD_ERR_BAD_ARG;
       const long long wsf = ws ? ws_bytes / 4 : 0;
@@ -206,7 +211,8 @@ static int conv_gemm_split_impl(const WdConvGemm* pp, const void* w_split, float
           if (s2 > 1) splits = s2;
         }
       }
-      return wd_launch_conv_pp(p, w_split, w_unscale, flags, st, splits, ws, wsf, cfg == 73 ? 3 : cfg == 74 ? 4 : 0);
+      return wd_launch_conv_pp(p, w_split, w_unscale, flags, st, splits, ws, wsf,
+                               cfg == 73 ? 3 : cfg == 74 ? 4 : cfg >= 700 ? cfg - 600 : 0);
     }
   }
   if (flags == WD_SPLIT_C) {

@@ -12,11 +12,12 @@
 //     activation instruction points at input pixel (ho*stride - pad + kh, wo*stride - pad + kw), channel chunk of
 //     the K stage, or at a zero page when that tap falls outside the image (halo) or the row is past m;
 //   * unpadded 64-byte LDS rows, XOR-swizzled on the global side (slot ^ (row/4 & 3)): conflict-free ds_read_b128;
-//   * 256 x 128 (or 256 x 64) tile, 8 waves in two groups half an iteration apart (the ping-pong schedule of
-//     split_gemm_pre.hip): each SIMD always has one wave issuing MFMAs while its partner issues the DMAs (an
-//     LDS-DMA instruction costs 60-185 issue cycles) and reads fragments; an LDS ring of NBUF stages of k = 16 with
-//     the DMA NBUF-1 stages ahead and counted s_waitcnt vmcnt (never 0 in steady state).  These launches are small
-//     (200-1600 tiles): the ring depth, not occupancy, is what hides the L2 / fabric latency.
+//   * 256 x 128 (or 256 x 64) tile, 8 waves of 64 x 64 (64 x 32), an LDS ring of NBUF stages of k = 16 with the DMA
+//     NBUF-1 stages ahead and counted s_waitcnt vmcnt (never 0 in steady state), one barrier per stage.  These
+//     launches are small (100-1600 tiles): the ring depth, not occupancy, is what hides the L2 / fabric latency.
+// What bounds it (profiles/r03_convpp_ablations_*.txt, timing-only builds): the 32 x 40 x 40, 128 -> 128 layer moves
+// 345 MB global -> LDS per launch (im2col re-reads the input nine times, the weight panel once per 256 rows) in ~50 us,
+// i.e. the ~6.5 TB/s every LDS-fed kernel of this library ends at; its MFMAs alone take 27 us.
 // Same MFMA chain per accumulator and the same K order as the loader-split kernels: BIT-IDENTICAL results
 // (tests/test_gpu_split.py).
 #include "split_gemm_impl.h"
@@ -35,7 +36,8 @@ __device__ __forceinline__ void cv_wait_groups(int groups) {
   else if (groups == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
   else if (groups == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else if (groups == 3) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (groups == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
 }
 
 // ---------------------------------------------------------------------------------------
@@ -173,7 +175,8 @@ __device__ __forceinline__ void epi_oct_all(const WdConvGemm& p, float unscale, 
 // ksplits > 1: workgroup (tile, ks) walks K stages [ks * per, ...) and writes raw partial sums to ws[ks][m][n];
 // splitk_oct_reduce_kernel adds them in split order and applies the epilogue.
 // ---------------------------------------------------------------------------------------
-template <int NBUF, int TN, bool CSPLIT>
+// ABL (timing-only, WD_DEBUG_ABLATIONS builds, WRONG results): 1 = no DMA after the prologue, 2 = no fragment reads, 4 = no MFMAs
+template <int NBUF, int TN, bool CSPLIT, int ABL = 0>
 __global__ void __launch_bounds__(512, NBUF <= 3 ? 4 : 2)
 split_conv_pp_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, const float* __restrict__ zero, int k16,
                      float unscale, int nbn, int ksplits, float* __restrict__ ws) {
@@ -204,7 +207,6 @@ split_conv_pp_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, 
   // straddles a tap).
   const unsigned char* base[NI];
   unsigned mask[NI];
-  const int taps = p.kh * p.kw;
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     const int row = (wave * NI + j) * 16 + (lane >> 2);
@@ -221,13 +223,13 @@ split_conv_pp_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, 
       const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
       const long long pix = ((long long)b * p.hin + hi0) * p.win + wi0;
       base[j] = reinterpret_cast<const unsigned char*>(p.a) + pix * p.lda * 4 + memchunk * 16;
-      unsigned mk = 0;
-      for (int tp = 0; tp < taps; ++tp) {
-        const int kh = tp / p.kw, kw = tp - kh * p.kw;
-        const bool in = (unsigned)(hi0 + kh) < (unsigned)p.hin && (unsigned)(wi0 + kw) < (unsigned)p.win;
-        mk |= (ok && in) ? (1u << tp) : 0u;
+      unsigned mk = 0, bit = 1u;                     // no integer division per tap: this runs per lane and per tile
+      for (int kh = 0; kh < p.kh; ++kh) {
+        const bool hok = (unsigned)(hi0 + kh) < (unsigned)p.hin;
+        for (int kw = 0; kw < p.kw; ++kw, bit <<= 1)
+          mk |= (hok && (unsigned)(wi0 + kw) < (unsigned)p.win) ? bit : 0u;
       }
-      mask[j] = mk;
+      mask[j] = ok ? mk : 0u;
     } else {
       const int n = n0 + row - BM;
       const bool ok = n < p.n;
@@ -247,7 +249,9 @@ split_conv_pp_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, 
   }
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_raw;
   const unsigned char* zp = reinterpret_cast<const unsigned char*>(zero);
+  bool prologue = true;
   auto issue = [&](int buf) {
+    if ((ABL & 1) && !prologue) return;
     const unsigned lbase = lds0 + buf * STAGE + wave * NI * 1024;
     const int a_off = ((i_kh * p.win + i_kw) * p.lda + i_ci) * 4;
 #pragma unroll
@@ -290,6 +294,7 @@ split_conv_pp_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, 
   }
   h8 xh[TM], xl[TM], wh[TN], wl[TN];
   auto read = [&](int buf) {
+    if ((ABL & 2) && !prologue) return;
     const unsigned char* sp = smem_raw + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -303,7 +308,7 @@ split_conv_pp_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, 
     }
   };
   auto mfma = [&]() {
-    __builtin_amdgcn_s_setprio(1);
+    if (ABL & 4) return;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -319,7 +324,6 @@ split_conv_pp_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, 
 #pragma unroll
       for (int j = 0; j < TN; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], xh[i], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
   };
 
   // prologue: stages 0 .. DIST-1 in flight, all landed before anyone reads
@@ -328,52 +332,44 @@ split_conv_pp_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, 
     if (d < nk) issue(d);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  int bcur = 0, bnext = 1, bfill = DIST % NBUF;
-  auto advance = [&]() {
+  if (ABL & 2) read(0);
+  prologue = false;
+  // Steady state, all eight waves in phase, ONE barrier per K stage:
+  //   read the fragments of stage s | issue the DMA of stage s + NBUF - 1 into the buffer every wave finished reading
+  //   before the last barrier | 12 MFMAs | wait (counted) until the own share of stage s + 1 has landed | barrier
+  // A ping-pong schedule (two wave groups half a stage apart, two barriers per stage) and fragment reads software-
+  // pipelined inside the wave were built on this kernel, are bit-identical, and measured 5-12 % slower on every neck / head
+  // shape (profiles/r03_convpp_modes.txt): the launches are bound by the global -> LDS byte rate, not by issue slots.
+  int bcur = 0, bfill = DIST % NBUF;
+  for (int s = 0; s < nk; ++s) {
+    read(bcur);
+    if (s + DIST < nk) issue(bfill);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma();
+    __builtin_amdgcn_sched_barrier(0);
+    {                                          // issued so far: up to stage s+DIST; stage s+1 must be complete
+      const int last = s + DIST < nk - 1 ? s + DIST : nk - 1;
+      cv_wait_groups(last - (s + 1));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
     bcur = bcur == NBUF - 1 ? 0 : bcur + 1;
-    bnext = bnext == NBUF - 1 ? 0 : bnext + 1;
     bfill = bfill == NBUF - 1 ? 0 : bfill + 1;
-  };
-#define WD_SLOT_BARRIER()                 \
-  __builtin_amdgcn_sched_barrier(0);      \
-  __syncthreads();                        \
-  __builtin_amdgcn_sched_barrier(0)
-  // Schedule (as split_gemm_pingpong_kernel): group 0 computes stage s in slot 2s and moves data in slot 2s+1,
-  // group 1 the other way round.  Before the barrier that ends a wave's data slot its share of the NEXT stage to be
-  // read must have landed; younger DMA groups stay in flight.
-  if (group == 0) {
-    read(0);
-    for (int s = 0; s < nk; ++s) {
-      mfma();                                  // slot 2s
-      __builtin_amdgcn_sched_barrier(0);
-      {                                        // issued so far: up to stage s+DIST-1; stage s+1 must be complete
-        const int last = s + DIST - 1 < nk - 1 ? s + DIST - 1 : nk - 1;
-        cv_wait_groups(last - (s + 1));
-      }
-      WD_SLOT_BARRIER();
-      if (s + DIST < nk) issue(bfill);         // slot 2s+1
-      if (s + 1 < nk) read(bnext);
-      WD_SLOT_BARRIER();
-      advance();
-    }
-  } else {
-    for (int s = 0; s < nk; ++s) {
-      if (s + DIST < nk) issue(bfill);         // slot 2s
-      read(bcur);
-      __builtin_amdgcn_sched_barrier(0);
-      {                                        // issued so far: up to stage s+DIST; stage s+1 must be complete
-        const int last = s + DIST < nk - 1 ? s + DIST : nk - 1;
-        cv_wait_groups(last - (s + 1));
-      }
-      WD_SLOT_BARRIER();
-      mfma();                                  // slot 2s+1
-      WD_SLOT_BARRIER();
-      advance();
-    }
   }
-#undef WD_SLOT_BARRIER
   __syncthreads();
 
+  if (ABL & 8) {                                       // timing only: keep the accumulators live, one store per lane
+    float sacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+    if (m0 + (t & 255) < p.m) p.c[(size_t)(m0 + (t & 255)) * p.ldc + n0 + (t >> 8)] = sacc;
+    return;
+  }
   const int mw = m0 + group * 128 + wm * 64, nw = n0 + wn * 32 * TN;
   float* patch = reinterpret_cast<float*>(smem_raw) + wave * 32 * EPI_LDT;
   static_assert(2 * STAGE >= 8 * 32 * EPI_LDT * 4, "operand LDS must hold one patch per wave");
@@ -434,7 +430,7 @@ int launch_oct_reduce(const WdConvGemm& p, const float* ws, int splits, float un
   return wd_launch_status();
 }
 
-template <int NBUF, int TN, bool CSPLIT>
+template <int NBUF, int TN, bool CSPLIT, int ABL = 0>
 int launch_conv_pp(const WdConvGemm& p, const void* wsp, float unscale, hipStream_t st, int ksplits, float* ws) {
   constexpr int BN = 64 * TN, LDS = NBUF * CV_STAGE;
   const int nbm = (p.m + CV_BM - 1) / CV_BM, nbn = (p.n + BN - 1) / BN;
@@ -447,7 +443,7 @@ int launch_conv_pp(const WdConvGemm& p, const void* wsp, float unscale, hipStrea
     if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero4)) != hipSuccess || !zp) return WD_ERR_LAUNCH;
     zero = static_cast<const float*>(zp);
   }
-  auto k = split_conv_pp_kernel<NBUF, TN, CSPLIT>;
+  auto k = split_conv_pp_kernel<NBUF, TN, CSPLIT, ABL>;
   static WdAttrOnce attr;
   if (wd_set_max_lds(attr, reinterpret_cast<const void*>(k), LDS) != WD_OK) return WD_ERR_LAUNCH;
   WD_LAUNCH_GEMM(k, dim3((unsigned)nblk), dim3(512), LDS, st, p, static_cast<const unsigned char*>(wsp), zero, k16, unscale,
@@ -484,10 +480,25 @@ int wd_launch_conv_pp(const WdConvGemm& p, const void* w, float unscale, int fla
   if (ksplits > 1 && (!ws || (long long)ksplits * p.m * p.n > ws_floats)) return WD_ERR_WORKSPACE;
   if (ksplits > (p.k >> 4)) ksplits = p.k >> 4;
   // ring depth: launches that give a CU at most one workgroup hide the load latency with a deeper ring (4 stages,
-  // 96 KB); fuller launches run two workgroups per CU on 3 stages (72 KB each)
-  int nbuf = (tiles * ksplits <= 320) ? 4 : 3;
+  // 96 KB); fuller launches run two workgroups per CU on 3 stages (72 KB each) — profiles/r03_convpp_modes.txt
+  int nbuf = (tiles * ksplits <= 256) ? 4 : 3;
   if (variant == 3 || variant == 4) nbuf = variant;
   int rc;
+#ifdef WD_DEBUG_ABLATIONS
+  if (variant >= 100 && variant < 116 && !narrow && csplit) {     // timing-only builds (scripts/conv_pp_abl.py)
+    switch (variant - 100) {
+      case 1: return launch_conv_pp<4, 2, true, 1>(p, w, unscale, st, 1, ws);
+      case 2: return launch_conv_pp<4, 2, true, 2>(p, w, unscale, st, 1, ws);
+      case 3: return launch_conv_pp<4, 2, true, 3>(p, w, unscale, st, 1, ws);
+      case 4: return launch_conv_pp<4, 2, true, 4>(p, w, unscale, st, 1, ws);
+      case 7: return launch_conv_pp<4, 2, true, 7>(p, w, unscale, st, 1, ws);
+      case 8: return launch_conv_pp<4, 2, true, 8>(p, w, unscale, st, 1, ws);
+      case 11: return launch_conv_pp<4, 2, true, 11>(p, w, unscale, st, 1, ws);
+      case 15: return launch_conv_pp<4, 2, true, 15>(p, w, unscale, st, 1, ws);
+      default: break;
+    }
+  }
+#endif
 #define WD_CPP(NB, TNN, CS) launch_conv_pp<NB, TNN, CS>(p, w, unscale, st, ksplits, ws)
   if (nbuf == 4) {
     if (narrow) rc = csplit ? WD_CPP(4, 1, true) : WD_CPP(4, 1, false);

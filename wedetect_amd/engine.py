@@ -119,7 +119,15 @@ class ImageTower:
         for name, m, cout in (("Rep_p4", M4, nc["p5r"]), ("Rep_p3", M3, nc["p4r"]),
                               ("Rep_n3", M4, nc["n3"]), ("Rep_n4", M5, nc["n4"])):
             c_ = cout // 2
-            self._bep[name] = dict(cat=f(m, 2 * c_), u0=f(m, c_), u1=f(m, c_), t=f(m, c_), c_=c_)
+            # u0s / u1s: the fp16 hi/lo twins of u0 / u1 (pre-split neck: the 3x3 convs read the split form, the BottleRep
+            # residual "+ alpha x" the fp32 form — the producing layer writes both)
+            self._bep[name] = dict(cat=f(m, 2 * c_), u0=f(m, c_), u1=f(m, c_), t=f(m, c_), u0s=f(m, c_), u1s=f(m, c_), c_=c_)
+        # Pre-split neck / head (round 3, $WEDETECT_NECK_PRESPLIT=0 restores the round-2 path for A/B runs): every neck / head
+        # activation is written by its producer as fp16 hi/lo groups (WD_SPLIT_C epilogues) and every conv reads it through
+        # the LDS-DMA implicit-GEMM kernel (split_gemm_conv.hip) — no per-tap re-splitting, no register staging, no LDS bank
+        # conflicts.  Same halves, same K order: embeddings / boxes are bit-identical to the loader-split path.
+        self.presplit_neck = (precision == "fp16x3" and os.environ.get("WEDETECT_NECK_PRESPLIT", "1") != "0"
+                              and all(v % 32 == 0 for v in nc.values()) and CLS_MID % 16 == 0 and REG_MID % 16 == 0)
         # ---- head buffers
         self.lv = level_sizes(height, width)
         self.nl = [h * w for h, w in self.lv]
@@ -191,6 +199,24 @@ class ImageTower:
                     w_split=ws, workspace=work,
                     range_flag=(self.range_flag2 if guarded else self.range_flag) if ws is not None else None, **kw)
 
+    def _neck_split(self) -> bool:
+        """Is the neck / head running on pre-split activations in this step?  Not when the tower fell back to fp32 kernels,
+        nor when the five neck input layers are pinned to fp32 (their outputs would have to be re-split)."""
+        return self.presplit_neck and self.precision == "fp16x3" and not self.neck_pin
+
+    @staticmethod
+    def unsplit(t: torch.Tensor) -> torch.Tensor:
+        """fp32 view of a tensor stored as fp16 hi/lo groups ([hi x8 | lo x8] per 8 channels): hi + lo, i.e. the producer's
+        fp32 value to 2^-22 relative.  Diagnostics / tests only — the hot path never converts back."""
+        rows, c = t.shape
+        h = t.contiguous().view(torch.float16).view(rows, c // 8, 2, 8)
+        return (h[:, :, 0].float() + h[:, :, 1].float()).reshape(rows, c)
+
+    def pyramid(self) -> List[torch.Tensor]:
+        """P3, P4, P5 as fp32 rows whatever format the neck wrote them in."""
+        ps = [self.p3, self.p4, self.p5]
+        return [self.unsplit(p) for p in ps] if self._neck_split() else ps
+
     def _conv(self, a, w, b, c, *, hin, win, cin, lda, n, ldc, k=1, stride=1, act=L.ACT_NONE, res=None, ldres=0,
               res_alpha=1.0, **kw):
         self._gemm(a, w, b, c, hin=hin, win=win, cin=cin, lda=lda, kh=k, kw=k, stride=stride,
@@ -253,65 +279,76 @@ class ImageTower:
         h, w = hw
         nb = self.a.neck_repeats // 2
         cat = bf["cat"]
-        self._conv(x, f"{name}.cv1.w", f"{name}.cv1.b", bf["u0"], hin=h, win=w, cin=cin, lda=ldx, n=c_, ldc=c_,
-                   act=L.ACT_SILU)
-        cur, nxt = bf["u0"], bf["u1"]
+        S = self._neck_split()
+        fl = (L.SPLIT_A | L.SPLIT_C) if S else 0
+        sfx = "s" if S else ""
+        # cv1 output: the 3x3 chain reads it (split) AND the first BottleRep adds it back (fp32): dual write
+        self._conv(x, f"{name}.cv1.w", f"{name}.cv1.b", bf["u0" + sfx], hin=h, win=w, cin=cin, lda=ldx, n=c_, ldc=c_,
+                   act=L.ACT_SILU, split_flags=fl, c2=bf["u0"] if S else None, ldc2=c_ if S else 0)
+        cur, nxt = "u0", "u1"
         for j in range(nb):
             s = f"{name}.m{j}"
-            self._conv(cur, s + ".c1.w", s + ".c1.b", bf["t"], hin=h, win=w, cin=c_, lda=c_, n=c_, ldc=c_, k=3,
-                       act=L.ACT_SILU)
+            self._conv(bf[cur + sfx], s + ".c1.w", s + ".c1.b", bf["t"], hin=h, win=w, cin=c_, lda=c_, n=c_, ldc=c_, k=3,
+                       act=L.ACT_SILU, split_flags=fl)
             last = j == nb - 1
-            dst, ldd = (cat, 2 * c_) if last else (nxt, c_)
+            dst, ldd = (cat, 2 * c_) if last else (bf[nxt + sfx], c_)
             self._conv(bf["t"], s + ".c2.w", s + ".c2.b", dst, hin=h, win=w, cin=c_, lda=c_, n=c_, ldc=ldd, k=3,
-                       act=L.ACT_SILU, res=cur, ldres=c_, res_alpha=self.P.s[s + ".alpha"])
+                       act=L.ACT_SILU, res=bf[cur], ldres=c_, res_alpha=self.P.s[s + ".alpha"], split_flags=fl,
+                       c2=bf[nxt] if (S and not last) else None, ldc2=c_ if (S and not last) else 0)
             cur, nxt = nxt, cur
         self._conv(x, f"{name}.cv2.w", f"{name}.cv2.b", cat[:, c_:], hin=h, win=w, cin=cin, lda=ldx, n=c_,
-                   ldc=2 * c_, act=L.ACT_SILU)
+                   ldc=2 * c_, act=L.ACT_SILU, split_flags=fl)
         self._conv(cat, f"{name}.cv3.w", f"{name}.cv3.b", out, hin=h, win=w, cin=2 * c_, lda=2 * c_, n=cout,
-                   ldc=cout, act=L.ACT_SILU)
+                   ldc=cout, act=L.ACT_SILU, split_flags=fl)
 
     def _bifusion(self, name: str, top, ld_top: int, hw_top, mid, c_mid: int, hw_mid, low, c_low: int, hw_low,
                   cat, tbuf, out, cout: int):
         """cat = [upsample(top) | cv1(mid) | downsample(cv2(low))] -> cv3 -> out  (yolo_world_pafpn.py:711-715)."""
-        B = self.B
         ht, wt = hw_top
         hm, wm = hw_mid
         hl, wl = hw_low
+        S = self._neck_split()
+        fl = (L.SPLIT_A | L.SPLIT_C) if S else 0
+        fc = L.SPLIT_C if S else 0            # fp32 residual stream in (split by the loader), hi/lo groups out
         self._gemm(top, name + ".up.w", name + ".up.b", cat, hin=ht, win=wt, cin=cout, lda=ld_top, n=4 * cout,
-                   ldc=3 * cout, out_mode=L.OUT_DECONV2X2)
+                   ldc=3 * cout, out_mode=L.OUT_DECONV2X2, split_flags=fl)
         self._conv(mid, name + ".cv1.w", name + ".cv1.b", cat[:, cout:], hin=hm, win=wm, cin=c_mid, lda=c_mid, n=cout,
-                   ldc=3 * cout, act=L.ACT_RELU, fp32=True)          # mid / low are backbone residual streams
+                   ldc=3 * cout, act=L.ACT_RELU, fp32=True, split_flags=fc)   # mid / low are backbone residual streams
         self._conv(low, name + ".cv2.w", name + ".cv2.b", tbuf, hin=hl, win=wl, cin=c_low, lda=c_low, n=cout, ldc=cout,
-                   act=L.ACT_RELU, fp32=True)
+                   act=L.ACT_RELU, fp32=True, split_flags=fc)
         self._conv(tbuf, name + ".downsample.w", name + ".downsample.b", cat[:, 2 * cout:], hin=hl, win=wl, cin=cout,
-                   lda=cout, n=cout, ldc=3 * cout, k=3, stride=2, act=L.ACT_RELU)
+                   lda=cout, n=cout, ldc=3 * cout, k=3, stride=2, act=L.ACT_RELU, split_flags=fl)
         self._conv(cat, name + ".cv3.w", name + ".cv3.b", out, hin=hm, win=wm, cin=3 * cout, lda=3 * cout, n=cout,
-                   ldc=cout, act=L.ACT_RELU)
+                   ldc=cout, act=L.ACT_RELU, split_flags=fl)
 
     def neck(self) -> List[torch.Tensor]:
+        """P3, P4, P5 buffers.  In the pre-split mode (see __init__) they hold fp16 hi/lo groups, like every other neck
+        buffer: ``pyramid()`` gives fp32 views for diagnostics."""
         a = self.a
         nc = a.neck_channels
         c1, c2, c3, c4 = self.x
         hw2, hw3, hw4, hw5 = self.hw
         ld4 = nc["d1"] + nc["p5r"]
         ld3 = nc["d2"] + nc["p4r"]
+        S = self._neck_split()
+        fl = (L.SPLIT_A | L.SPLIT_C) if S else 0
         fpn_out0 = self.cat_n4[:, nc["d1"]:]
         self._conv(c4, "reduce_layer0.w", "reduce_layer0.b", fpn_out0, hin=hw5[0], win=hw5[1], cin=nc["c4"],
-                   lda=nc["c4"], n=nc["p5r"], ldc=ld4, act=L.ACT_RELU, fp32=True)
+                   lda=nc["c4"], n=nc["p5r"], ldc=ld4, act=L.ACT_RELU, fp32=True, split_flags=L.SPLIT_C if S else 0)
         self._bifusion("Bifusion0", fpn_out0, ld4, hw5, c3, nc["c3"], hw4, c2, nc["c2"], hw3, self.cat_b0, self.b0_t,
                        self.f0, nc["p5r"])
         self._bepc3("Rep_p4", self.f0, nc["p5r"], nc["p5r"], hw4, self.f_out0, nc["p5r"])
         fpn_out1 = self.cat_n3[:, nc["d2"]:]
         self._conv(self.f_out0, "reduce_layer1.w", "reduce_layer1.b", fpn_out1, hin=hw4[0], win=hw4[1], cin=nc["p5r"],
-                   lda=nc["p5r"], n=nc["p4r"], ldc=ld3, act=L.ACT_RELU)
+                   lda=nc["p5r"], n=nc["p4r"], ldc=ld3, act=L.ACT_RELU, split_flags=fl)
         self._bifusion("Bifusion1", fpn_out1, ld3, hw4, c2, nc["c2"], hw3, c1, nc["c1"], hw2, self.cat_b1, self.b1_t,
                        self.f1, nc["p4r"])
         self._bepc3("Rep_p3", self.f1, nc["p4r"], nc["p4r"], hw3, self.p3, nc["p4r"])
         self._conv(self.p3, "downsample2.w", "downsample2.b", self.cat_n3, hin=hw3[0], win=hw3[1], cin=nc["p4r"],
-                   lda=nc["p4r"], n=nc["d2"], ldc=ld3, k=3, stride=2, act=L.ACT_RELU)
+                   lda=nc["p4r"], n=nc["d2"], ldc=ld3, k=3, stride=2, act=L.ACT_RELU, split_flags=fl)
         self._bepc3("Rep_n3", self.cat_n3, ld3, ld3, hw4, self.p4, nc["n3"])
         self._conv(self.p4, "downsample1.w", "downsample1.b", self.cat_n4, hin=hw4[0], win=hw4[1], cin=nc["n3"],
-                   lda=nc["n3"], n=nc["d1"], ldc=ld4, k=3, stride=2, act=L.ACT_RELU)
+                   lda=nc["n3"], n=nc["d1"], ldc=ld4, k=3, stride=2, act=L.ACT_RELU, split_flags=fl)
         self._bepc3("Rep_n4", self.cat_n4, ld4, ld4, hw5, self.p5, nc["n4"])
         return [self.p3, self.p4, self.p5]
 
@@ -319,23 +356,26 @@ class ImageTower:
     def head(self) -> Tuple[torch.Tensor, torch.Tensor]:
         """Region embeddings (post contrastive-BN) [B, N, 768] and decoded boxes [B, N, 4]."""
         feats = [self.p3, self.p4, self.p5]
+        S = self._neck_split()                  # P3..P5 and the branch intermediates as fp16 hi/lo groups; embeddings and
+        fl = (L.SPLIT_A | L.SPLIT_C) if S else 0     # DFL logits (read by fp32 kernels) stay fp32
+        fa = L.SPLIT_A if S else 0
         for l, (feat, cin) in enumerate(zip(feats, self.a.head_in)):
             h, w = self.lv[l]
             c1, c2 = self.hc[l]
             self._conv(feat, f"head{l}.cls0.w", f"head{l}.cls0.b", c1, hin=h, win=w, cin=cin, lda=cin, n=CLS_MID,
-                       ldc=CLS_MID, k=3, act=L.ACT_SILU)
+                       ldc=CLS_MID, k=3, act=L.ACT_SILU, split_flags=fl)
             self._conv(c1, f"head{l}.cls1.w", f"head{l}.cls1.b", c2, hin=h, win=w, cin=CLS_MID, lda=CLS_MID, n=CLS_MID,
-                       ldc=CLS_MID, k=3, act=L.ACT_SILU)
+                       ldc=CLS_MID, k=3, act=L.ACT_SILU, split_flags=fl)
             dst = self.embed.view(-1, EMBED_DIM)[self.off[l]:]
             self._conv(c2, f"head{l}.embed.w", f"head{l}.embed.b", dst, hin=h, win=w, cin=CLS_MID, lda=CLS_MID,
-                       n=EMBED_DIM, ldc=EMBED_DIM, c_batch_stride=self.ntot)
+                       n=EMBED_DIM, ldc=EMBED_DIM, c_batch_stride=self.ntot, split_flags=fa)
             r1, r2, dist = self.hr[l]
             self._conv(feat, f"head{l}.reg0.w", f"head{l}.reg0.b", r1, hin=h, win=w, cin=cin, lda=cin, n=REG_MID,
-                       ldc=REG_MID, k=3, act=L.ACT_SILU)
+                       ldc=REG_MID, k=3, act=L.ACT_SILU, split_flags=fl)
             self._conv(r1, f"head{l}.reg1.w", f"head{l}.reg1.b", r2, hin=h, win=w, cin=REG_MID, lda=REG_MID, n=REG_MID,
-                       ldc=REG_MID, k=3, act=L.ACT_SILU)
+                       ldc=REG_MID, k=3, act=L.ACT_SILU, split_flags=fl)
             self._conv(r2, f"head{l}.dist.w", f"head{l}.dist.b", dist, hin=h, win=w, cin=REG_MID, lda=REG_MID, n=64,
-                       ldc=64)
+                       ldc=64, split_flags=fa)
             L.dfl_decode(dist, 64, self.boxes, self.B, h, w, STRIDES[l], self.off[l], self.ntot)
         return self.embed, self.boxes
 

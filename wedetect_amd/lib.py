@@ -207,7 +207,11 @@ def p8_workspace_bytes() -> int:
 
 
 def gemm_config(m: int, n: int, k: int, split: bool = False, conv: bool = False, presplit: bool = False,
-                park: bool = False) -> str:
+                park: bool = False, dma: bool = False) -> str:
+    """``dma``: a pre-split layer outside the plain-row 1x1 case (k x k / strided conv, scatter or batch-stride output,
+    residual or dual-format output of a SPLIT_C layer): the implicit-GEMM LDS-DMA kernel of split_gemm_conv.hip."""
+    if split and dma:
+        return LIB.wd_conv_gemm_split_config(m, n, k, 4).decode()
     if split:
         return LIB.wd_conv_gemm_split_config(m, n, k, 1 if conv else ((3 if park else 2) if presplit else 0)).decode()
     return LIB.wd_conv_gemm_config(m, n, k).decode()
