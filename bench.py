@@ -415,6 +415,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    tower.calibrate(images)                 # as the detectors do on a tower's first batch (untimed; all scales 1 here)
     timer.mode = "count"
     for _ in range(args.warmup):
         step()

@@ -103,6 +103,12 @@ typedef struct WdConvGemm {
                                 * stride ldc2) next to the fp16 hi/lo output in c — for consumers that read fp32 (the
                                 * BottleRep residual, yolo_world_pafpn.py:602-605); plain-row outputs only */
   int32_t ldc2;
+  /* fp16x3 range management: power-of-two scales (0 is read as 1) that keep an operand's fp16 (hi, lo) halves inside the
+   * fp16 normal range whatever the checkpoint's activation scale.  a_scale: fp32 activations are multiplied by it
+   * before the loader splits them (loader-split layers).  c_split_scale: a WD_SPLIT_C output is multiplied by it before
+   * it is split (the fp32 copy c2 is not).  The CONSUMER of a scaled operand divides it out by passing
+   * w_unscale / scale — exact, powers of two.  wedetect_amd.engine.ImageTower.calibrate() chooses them. */
+  float a_scale, c_split_scale;
 } WdConvGemm;
 
 int wd_conv_gemm(const WdConvGemm* p, void* stream);

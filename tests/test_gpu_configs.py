@@ -176,3 +176,45 @@ def test_config4_retrieval_against_a_1m_class_bank():
     o = torch.empty(n_img, len(sr), device="cuda")
     L.retrieval_max_split(e, L.split_weights(t[sr.start:sr.stop]), scale, bias, cnt, o, n_img, rows, len(sr), d)
     assert_close("1M bank fp16x3 shard 5 vs whole", o, out2[:, sr.start:sr.stop], 1e-6)
+
+
+def test_large_at_its_reference_default_1280():
+    """WeDetect-Large at the size its own config runs it at (config/wedetect_large.py:109 img_scale = (1280, 1280);
+    generate_proposal.py:1070): one 1280 x 1280 image, 33 600 anchors, the 1203-class LVIS bank -> 40.4 M scores through
+    the similarity GEMM, top-k and the mmcv-form NMS.  The CPU oracle runs the whole network on the same image:
+    embeddings / scores within 1e-3, boxes within 1e-2 px, the kept list order-exact; and the device post-process equals
+    the oracle's on the device's own tensors bit for bit."""
+    from oracle import postprocess as opp
+    from oracle import ref_cpu as orc
+    from wedetect_amd import weights as W
+    from wedetect_amd.arch import get_arch
+    from wedetect_amd.engine import ImageTower
+    from wedetect_amd.pack import pack
+    arch, hw, k = "large", 1280, 1203
+    sd = W.make_state_dict(arch, num_prompts=256)
+    tower = ImageTower(arch, pack(sd, arch), 1, hw, hw, max_classes=k)
+    assert tower.ntot == 33600
+    imgs = W.make_images(1, hw, hw, seed=4242)
+    text = torch.from_numpy(W.make_text_bank(k)).cuda()
+    meta = tower.identity_meta()
+    meta[:, 7] = 1.0
+    res = tower.detect(torch.from_numpy(imgs).cuda(), text, meta, normalize_text=True, score_thr=0.001, with_embed=True)
+    n = tower.checked_counts(res, lambda: None)[0]
+    assert 0 < n <= 300 and not tower.overflowed
+    scores = tower.scores.view(-1)[: tower.ntot * k].view(tower.ntot, k)
+    sd_t = orc.to_torch(sd)
+    with torch.no_grad():
+        _, p_cpu = orc.forward_features(sd_t, get_arch(arch), imgs)
+        flat = orc.head_flat(sd_t, p_cpu, text.cpu()[None], normalize_text=True)
+    assert_close("large@1280 embeddings vs CPU oracle", tower.embed[0], flat["embed"][0], 1e-3)
+    assert_close("large@1280 scores vs CPU oracle", scores, flat["scores"][0], 1e-3)
+    assert_close("large@1280 boxes vs CPU oracle", tower.boxes[0], flat["boxes"][0], 1e-2)
+    o = opp.mmdet_predict_image(flat["boxes"][0].numpy(), flat["scores"][0].numpy(), None, (1.0, 1.0), (hw, hw))
+    mg = o["margins"]
+    compare_kept_lists("large@1280 K=1203 mmdet vs CPU oracle network", res["anchors"][0, :n], res["labels"][0, :n], res["scores"][0, :n],
+                       o["anchors"], o["labels"], o["scores"], [mg["iou_margin"], mg["pair_gap"], mg["kept_gap"], mg["cut_gap"]],
+                       got_boxes=res["bboxes"][0, :n], ref_boxes=o["bboxes"])
+    o = opp.mmdet_predict_image(to_np(tower.boxes[0]), to_np(scores), None, (1.0, 1.0), (hw, hw))
+    assert n == o["scores"].shape[0] and np.array_equal(to_np(res["anchors"][0, :n]), o["anchors"])
+    assert np.array_equal(to_np(res["labels"][0, :n]), o["labels"]) and np.array_equal(to_np(res["bboxes"][0, :n]), o["bboxes"])
+    assert int(res["labels"][0, :n].max()) > 79, "the LVIS bank must produce labels beyond COCO's 80"

@@ -181,11 +181,12 @@ def test_fp16x3_range_guard_falls_back_to_fp32():
     rgb = W.make_images(2, 128, 128, seed=5)
     inputs = [torch.from_numpy(np.ascontiguousarray(im[..., ::-1].transpose(2, 0, 1))) for im in rgb]
 
-    def run(state, precision):
+    def run(state, precision, calibrate=False):
         m = YOLOWorldDetector("nano", test_cfg=dict(max_per_img=50), max_classes=20, precision=precision)
         m.load_state_dict({n: torch.from_numpy(v) for n, v in state.items()})
         m.cuda().eval()
         m.set_text_embeddings(bank)
+        m._h.auto_calibrate = calibrate          # off: the run-time guard itself is under test (calibration would pre-empt it)
         out = m.test_step(dict(inputs=inputs, data_samples=[DetDataSample(), DetDataSample()]))
         return m, out
     import warnings
@@ -204,6 +205,18 @@ def test_fp16x3_range_guard_falls_back_to_fp32():
         warnings.simplefilter("always")
         m_ok, _ = run(sd, "fp16x3")
     assert not any("fp16 range" in str(w.message) for w in wrec) and m_ok._h.tower(2, 128, 128).precision == "fp16x3"
+    # round 3: with the first-batch calibration on (the default) the hot checkpoint's hidden tensor gets a 2^-k split scale
+    # and the tower STAYS on the fp16x3 kernels — no fallback, same detections as the fp32 tower
+    with warnings.catch_warnings(record=True) as wrec:
+        warnings.simplefilter("always")
+        m_cal, o_cal = run(hot, "fp16x3", calibrate=True)
+    t_cal = m_cal._h.tower(2, 128, 128)
+    assert not any("fp16 range" in str(w.message) for w in wrec) and t_cal.precision == "fp16x3" and not t_cal.overflowed
+    assert any(v < 1.0 for v in t_cal.sscale.values())
+    for a, b in zip(o_cal, o32):
+        assert len(a.pred_instances) == len(b.pred_instances)
+        assert torch.equal(a.pred_instances.labels, b.pred_instances.labels)
+        assert float((a.pred_instances.scores - b.pred_instances.scores).abs().max()) < 1e-4
 
 
 def test_small_batches_replay_a_hipgraph_and_match_the_eager_step():

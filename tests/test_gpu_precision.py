@@ -63,3 +63,107 @@ def test_step_is_bitwise_deterministic(precision):
     first = run()
     for _ in range(6):
         assert all(torch.equal(x, y) for x, y in zip(run(), first))
+
+
+def _rescaled_checkpoint(arch, stream_scale, hidden_scale=1.0):
+    """A checkpoint whose residual streams c1..c4 live at ``stream_scale`` (per channel: an array works too) and whose
+    MLP hidden activations live at ``hidden_scale`` — with the layers that read them compensated, so that everything
+    downstream is O(1) again, as a trained network with such internal scales would be.  Same function of the input in
+    exact arithmetic for every choice of scales up to the GELU's nonlinearity (hidden_scale changes the function, the
+    fp32 tower is the reference either way)."""
+    from wedetect_amd import weights as W
+    from wedetect_amd.arch import get_arch
+    a = get_arch(arch)
+    sd = W.make_state_dict(arch)
+    bb = "backbone.image_model.model."
+
+    def chan(scale, c):
+        s = np.asarray(scale, np.float32)
+        return np.resize(s, c).astype(np.float32) if s.ndim else np.full(c, s, np.float32)
+    for i, c in enumerate(a.dims):
+        s = chan(stream_scale, c)
+        if i == 0:
+            sd[bb + "downsample_layers.0.1.weight"] = sd[bb + "downsample_layers.0.1.weight"] * s      # stem LayerNorm affine
+            sd[bb + "downsample_layers.0.1.bias"] = sd[bb + "downsample_layers.0.1.bias"] * s
+        else:
+            sd[bb + f"downsample_layers.{i}.1.weight"] = sd[bb + f"downsample_layers.{i}.1.weight"] * s[:, None, None, None]
+            sd[bb + f"downsample_layers.{i}.1.bias"] = sd[bb + f"downsample_layers.{i}.1.bias"] * s
+        for j in range(a.depths[i]):
+            q = bb + f"stages.{i}.{j}."
+            sd[q + "gamma"] = sd[q + "gamma"] * s
+            sd[q + "dwconv.weight"] = sd[q + "dwconv.weight"] / s[:, None, None, None]       # LayerNorm input back to O(1): keeps eps's role
+            sd[q + "pwconv1.weight"] = sd[q + "pwconv1.weight"] * np.float32(hidden_scale)
+            sd[q + "pwconv1.bias"] = sd[q + "pwconv1.bias"] * np.float32(hidden_scale)
+            sd[q + "pwconv2.weight"] = sd[q + "pwconv2.weight"] / np.float32(hidden_scale)
+    for name, i in (("reduce_layer0", 3), ("Bifusion0.cv1", 2), ("Bifusion0.cv2", 1), ("Bifusion1.cv1", 1), ("Bifusion1.cv2", 0)):
+        k = f"neck.{name}.block.conv.weight"
+        sd[k] = sd[k] / chan(stream_scale, a.dims[i])[None, :, None, None]
+    return sd
+
+
+@pytest.mark.parametrize("case", ["streams_1e-4", "hidden_1e-3", "streams_3e4", "mixed_channels"])
+def test_fp16x3_low_and_mixed_range_checkpoints(case):
+    """fp16 (hi, lo) pairs carry an fp32 value to 2^-22 RELATIVE only while lo is a normal fp16 number
+    (|x| >~ 2^-3); below that the pair has an ABSOLUTE error floor of ~3e-8, i.e. a tensor living at 1e-4 would be carried
+    to 3e-4 relative.  ImageTower.calibrate() (one fp32 pass on the first batch) gives every split tensor outside
+    [2^-3, 2^13] a power-of-two scale applied by its producer and divided out by its consumer.  Checked here against the
+    fp32-MFMA tower on checkpoints whose residual streams / hidden activations are tiny, huge, or mixed per channel:
+      * uniformly small or large tensors: calibrated fp16x3 is as close to fp32 as on ordinary checkpoints (<= 3e-5 of the
+        embeddings' rms), where the uncalibrated path is 10-100x worse or overflows;
+      * per-channel mixed scales inside ONE tensor (1e-4 next to 1e+1, five decades): with the maximum placed at 2^10 the
+        small channels' low halves stay normal down to 2^-13 of the maximum — the same bound holds."""
+    from wedetect_amd import weights as W
+    from wedetect_amd.engine import ImageTower
+    from wedetect_amd.pack import pack
+    arch, b, hw = "base", 2, 128
+    if case == "streams_1e-4":
+        sd = _rescaled_checkpoint(arch, 1e-4)
+    elif case == "hidden_1e-3":
+        sd = _rescaled_checkpoint(arch, 1.0, hidden_scale=1e-3)
+    elif case == "streams_3e4":
+        sd = _rescaled_checkpoint(arch, 3e4)                  # beyond the fp16 range without a scale: the guard would trip
+    else:
+        sd = _rescaled_checkpoint(arch, np.asarray([1e-4, 1e1], np.float32))
+    packed = pack(sd, arch)
+    x = torch.from_numpy(W.make_images(b, hw, hw, seed=7)).cuda()
+    ref = ImageTower(arch, packed, b, hw, hw, precision="fp32")
+    e_ref = ref.features(x)[0].clone()
+    rms = float(e_ref.pow(2).mean().sqrt())
+    raw = ImageTower(arch, packed, b, hw, hw, precision="fp16x3")
+    e_raw = raw.features(x)[0].clone()
+    tripped = bool(raw.range_flags.any())
+    err_raw = float((e_raw - e_ref).abs().max()) / rms if not tripped else float("inf")
+    cal = ImageTower(arch, packed, b, hw, hw, precision="fp16x3")
+    amax = cal.calibrate(x)
+    e_cal = cal.features(x)[0].clone()
+    assert not bool(cal.range_flags.any()), f"{case}: range guard tripped after calibration"
+    err_cal = float((e_cal - e_ref).abs().max()) / rms
+    print(f"[range] {case}: embeddings rms {rms:.3g}; max err / rms: uncalibrated {err_raw:.3g}"
+          f"{' (range guard tripped)' if tripped else ''}, calibrated {err_cal:.3g}; {len(cal.sscale)} of {len(amax)} tensors rescaled")
+    assert len(cal.sscale) > 0, "the calibration must have found tensors outside the window"
+    assert err_cal <= 3e-5, f"{case}: calibrated fp16x3 is {err_cal:.3g} of rms away from fp32"
+    assert tripped or err_raw > 3.0 * err_cal, f"{case}: the case must actually stress the uncalibrated path ({err_raw:.3g} vs {err_cal:.3g})"
+
+
+def test_calibration_on_an_ordinary_checkpoint_changes_nothing_above_the_fp32_noise():
+    """Power-of-two scales are exact: on the synthetic checkpoints (every tensor O(1)) the calibrated tower differs from
+    the uncalibrated one only through elements whose low halves were subnormal before — by less than the distance of
+    either from the fp32 tower."""
+    from wedetect_amd import weights as W
+    from wedetect_amd.engine import ImageTower
+    from wedetect_amd.pack import pack
+    arch, b, hw = "base", 1, 128
+    packed = pack(W.make_state_dict(arch), arch)
+    x = torch.from_numpy(W.make_images(b, hw, hw)).cuda()
+    e32 = ImageTower(arch, packed, b, hw, hw, precision="fp32").features(x)[0].clone()
+    t0 = ImageTower(arch, packed, b, hw, hw, precision="fp16x3")
+    e0 = t0.features(x)[0].clone()
+    t1 = ImageTower(arch, packed, b, hw, hw, precision="fp16x3")
+    amax = t1.calibrate(x)
+    assert len(amax) > 100 and len(t1.sscale) > 50 and all(v == 2.0 ** round(np.log2(v)) for v in t1.sscale.values())
+    assert all(2.0 ** 9 <= amax[k] * t1.sscale.get(k, 1.0) < 2.0 ** 10 for k in amax if amax[k] > 0)
+    e1 = t1.features(x)[0].clone()
+    assert not bool(t1.range_flags.any())
+    d01, d0, d1 = float((e0 - e1).abs().max()), float((e0 - e32).abs().max()), float((e1 - e32).abs().max())
+    print(f"[range] ordinary checkpoint: |calibrated - uncalibrated| {d01:.3g}; vs fp32: uncalibrated {d0:.3g}, calibrated {d1:.3g}")
+    assert d01 <= 2e-5 and d1 <= max(2e-5, 1.5 * d0)

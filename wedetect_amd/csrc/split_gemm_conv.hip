@@ -100,8 +100,9 @@ __device__ __forceinline__ void epi_oct(const WdConvGemm& p, float unscale, int 
   }
   if (CSPLIT) {
     u32x2 h0, l0, h1, l1;
-    split4(o0, h0, l0);
-    split4(o1, h1, l1);
+    const float cs = p.c_split_scale != 0.f ? p.c_split_scale : 1.0f;       // power of two (exact); 1 for ordinary checkpoints
+    split4(o0 * cs, h0, l0);
+    split4(o1 * cs, h1, l1);
     unsigned char* cp = reinterpret_cast<unsigned char*>(rowp) + (size_t)(col >> 3) * 32;
     *reinterpret_cast<u32x4*>(cp) = u32x4{h0[0], h0[1], h1[0], h1[1]};
     *reinterpret_cast<u32x4*>(cp + 16) = u32x4{l0[0], l0[1], l1[0], l1[1]};

@@ -242,8 +242,9 @@ __device__ __forceinline__ void epi_lds_tile_csplit(const WdConvGemm& p, const E
         o1[r] = sact<ACT>(fmaf(v1[r], ev.unscale, b1[r]));
       }
       u32x2 h0, l0, h1, l1;
-      split4(o0, h0, l0);
-      split4(o1, h1, l1);
+      const float cs = p.c_split_scale != 0.f ? p.c_split_scale : 1.0f;     // power of two (exact); 1 for ordinary checkpoints
+      split4(o0 * cs, h0, l0);
+      split4(o1 * cs, h1, l1);
       unsigned char* cp = reinterpret_cast<unsigned char*>(p.c + (size_t)m * p.ldc) + (size_t)(n >> 3) * 32;
       // non-temporal: the hi/lo output of a C-split layer is a write-once stream (1.7 GB per stage-1 pwconv1) that its consumer
       // re-reads only after this launch is over: keep it from displacing the operand panels in L2 (-0.3 ms per step, same box)
@@ -426,6 +427,7 @@ split_gemm_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, con
   const int m0 = bm * BM, n0 = bn * BN;
   const int kc = t % KCH, r0 = t / KCH;
   const int K = p.k;
+  const float a_scale = p.a_scale != 0.f ? p.a_scale : 1.0f;
   const int nk_all = (K + BK - 1) / BK;
   const int per_split = (nk_all + ksplits - 1) / ksplits;
   const int s_begin = ks * per_split;
@@ -477,7 +479,7 @@ split_gemm_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, con
         hi = u32x2{__builtin_bit_cast(unsigned, areg[S][i][0]), __builtin_bit_cast(unsigned, areg[S][i][1])};
         lo = u32x2{__builtin_bit_cast(unsigned, areg[S][i][2]), __builtin_bit_cast(unsigned, areg[S][i][3])};
       } else {
-        split4(areg[S][i], hi, lo);
+        split4(areg[S][i] * a_scale, hi, lo);      // a_scale: power of two (exact), 1 for ordinary checkpoints
       }
       *reinterpret_cast<u32x2*>(ad + i * RSTEP * ROWB) = hi;
       *reinterpret_cast<u32x2*>(ad + i * RSTEP * ROWB + 32) = lo;
@@ -687,6 +689,7 @@ int check_split_args(const WdConvGemm& p, const void* wsp, float unscale) {
   if (!wd_aligned16(p.a) || !wd_aligned16(wsp)) return WD_ERR_BAD_ARG;
   if (p.act < WD_ACT_NONE || p.act > WD_ACT_GELU) return WD_ERR_BAD_ARG;
   if (!(unscale > 0.0f)) return WD_ERR_BAD_ARG;
+  if (p.a_scale < 0.f || p.c_split_scale < 0.f || !(p.a_scale == p.a_scale) || !(p.c_split_scale == p.c_split_scale)) return WD_ERR_BAD_ARG;
   if (p.out_mode == WD_OUT_DECONV2X2) {
     if (p.n % 16 || p.kh != 1 || p.kw != 1 || p.stride != 1 || p.pad != 0 || p.res) return WD_ERR_BAD_ARG;
     if (p.ldc < p.n / 4) return WD_ERR_BAD_ARG;

@@ -119,6 +119,8 @@ class _TowerHolder:
         # batches up to this size replay the step from a captured hipGraph (launch-bound: ~380 launches per step);
         # 0 = always eager
         self.graph_max_batch = int(os.environ.get("WEDETECT_GRAPH_MAX_BATCH", "4"))
+        # fp16x3 split scales are chosen from the first batch a tower sees (engine.ImageTower.calibrate); "0": never
+        self.auto_calibrate = os.environ.get("WEDETECT_CALIBRATE", "1") != "0"
         self.device = None
 
     def load(self, sd, strict: bool):
@@ -169,6 +171,10 @@ class _TowerHolder:
         copied into the graph's static buffers, results are the tower's usual buffers — bit-identical to the eager
         step, tests/test_gpu_detector.py).  A graph belongs to one (tower, arithmetic mode, bank size, thresholds); the
         range guard's switch to fp32 therefore captures anew."""
+        if not tower.calibrated and self.auto_calibrate:
+            # first batch of this tower: one fp32 pass chooses the fp16x3 split scales for this checkpoint's activation
+            # ranges (engine.ImageTower.calibrate; scale 1 everywhere for ordinary checkpoints)
+            tower.calibrate(images_u8)
         if tower.B > self.graph_max_batch:
             return tower.detect(images_u8, text, meta, **kw)
         k = int(text.shape[0])

@@ -143,6 +143,12 @@ class ImageTower:
         # bumped whenever a buffer that captured hipGraphs hold raw pointers to is re-allocated (scores, top-k workspace,
         # normalised text bank): graphs captured under an older generation must be dropped, not replayed
         self.generation = 0
+        # fp16x3 range management (calibrate()): power-of-two scale per split buffer / loader-split input, 1.0 unless a
+        # calibration pass found the tensor outside the window in which fp16 (hi, lo) pairs carry fp32 accuracy
+        self.sscale: Dict[str, float] = {}
+        self._calib: Optional[Dict[str, torch.Tensor]] = None
+        self._ln_scaled: Dict[tuple, tuple] = {}
+        self.calibrated = False
         self._alloc_post(max_classes)
         self.nms_ws = torch.zeros(max(1, L.nms_workspace_bytes(B) // 4), dtype=torch.int32, device=self.dev)
         self.cand_idx = torch.empty(B, self.cap, dtype=torch.int32, device=self.dev)
@@ -170,7 +176,26 @@ class ImageTower:
         self.topk_ws = self.topk_ws[off:off + nbytes]
 
     # ------------------------------------------------------------------ helpers
-    def _gemm(self, a, w: str, b: Optional[str], c, *, fp32: bool = False, **kw):
+    def _record(self, key: Optional[str], t: torch.Tensor) -> None:
+        """calibrate(): running max |x| of the tensor behind a scale key (fp32 pass: ``t`` holds fp32 values)."""
+        if self._calib is None or key is None or t.numel() == 0:
+            return
+        m = t.abs().max()
+        self._calib[key] = torch.maximum(self._calib[key], m) if key in self._calib else m
+
+    def _ln_params(self, wname: str, bname: str, key: Optional[str]):
+        """LayerNorm affine parameters with the output's split scale folded in (a power of two: y * s == LN with
+        gamma * s, beta * s, exactly)."""
+        sc = self.sscale.get(key, 1.0) if key else 1.0
+        if sc == 1.0 or self.precision != "fp16x3":
+            return self.P[wname], self.P[bname]
+        ck = (wname, sc)
+        if ck not in self._ln_scaled:
+            self._ln_scaled[ck] = (self.P[wname] * sc, self.P[bname] * sc)
+        return self._ln_scaled[ck]
+
+    def _gemm(self, a, w: str, b: Optional[str], c, *, fp32: bool = False, a_key: Optional[str] = None,
+              c_key: Optional[str] = None, **kw):
         """One dense layer with packed weight ``w`` / bias ``b`` in the tower's precision.
         ``fp32=True`` pins the layer to the fp32 MFMA kernel: the neck layers that read the ConvNeXt
         residual streams c1..c4 directly — the only GEMM inputs that are neither LayerNorm outputs nor
@@ -195,9 +220,29 @@ class ImageTower:
                 work = self.park
             elif plain and self.p8_mode == "0" and kw["cin"] % 16 == 0:
                 kw = dict(kw, split_cfg=63 if m >= 131072 else 60)
+        if ws is not None:
+            flags = kw.get("split_flags", 0)
+            sa = self.sscale.get(a_key, 1.0) if a_key else 1.0
+            if sa != 1.0:                       # the operand was (or will be, by the loader) multiplied by sa: divide it out
+                ws = (ws[0], ws[1] / sa)
+                if not (flags & L.SPLIT_A):
+                    kw = dict(kw, a_scale=sa)
+            sc = self.sscale.get(c_key, 1.0) if (c_key and (flags & L.SPLIT_C)) else 1.0
+            if sc != 1.0:
+                kw = dict(kw, c_split_scale=sc)
         L.conv_gemm(a, None if ws is not None else self.P[w], self.P[b] if b else None, c, batch=self.B,
                     w_split=ws, workspace=work,
                     range_flag=(self.range_flag2 if guarded else self.range_flag) if ws is not None else None, **kw)
+        if self._calib is not None:
+            if fp32 and a_key:                  # a layer that reads an fp32 residual stream through the loader
+                self._record(a_key, a[..., : kw["cin"]])
+            if c_key:
+                n, kh_, st_, pd_ = kw["n"], kw.get("kh", 1), kw.get("stride", 1), kw.get("pad", 0)
+                m = self.B * ((kw["hin"] + 2 * pd_ - kh_) // st_ + 1) * ((kw["win"] + 2 * pd_ - kh_) // st_ + 1)
+                if c.dim() == 1:                # flat scratch buffer (the MLP hidden tensor): rows are dense
+                    self._record(c_key, c[: m * kw["ldc"]])
+                else:
+                    self._record(c_key, c[..., : n // 4] if kw.get("out_mode", 0) == L.OUT_DECONV2X2 else c[..., :n])
 
     def _neck_split(self) -> bool:
         """Is the neck / head running on pre-split activations in this step?  Not when the tower fell back to fp32 kernels,
@@ -248,32 +293,36 @@ class ImageTower:
                     # LayerNorm writes the 2 x 2 / stride-2 convolution's GEMM rows directly (space-to-depth, (kh, kw, cin)
                     # column order = the packed weight's): the downsample runs as a plain pre-split GEMM with K = 4 cp on
                     # the DMA-fed kernels instead of the register-staged conv loader.  Same K order, same bits.
-                    L.layernorm_rows_split_s2d(self.x[i - 1], self.tmp, self.P[f"down{i}.ln_w"], self.P[f"down{i}.ln_b"],
-                                               B, hp, wp, cp)
+                    g_, b_ = self._ln_params(f"down{i}.ln_w", f"down{i}.ln_b", f"down{i}.ln")
+                    L.layernorm_rows_split_s2d(self.x[i - 1], self.tmp, g_, b_, B, hp, wp, cp)
                     self._gemm(self.tmp, f"down{i}.w", f"down{i}.b", self.x[i], hin=h, win=w, cin=4 * cp, lda=4 * cp, n=c,
-                               ldc=c, split_flags=fa)
+                               ldc=c, split_flags=fa, a_key=f"down{i}.ln")
                 else:
-                    L.layernorm_rows(self.x[i - 1], self.tmp, self.P[f"down{i}.ln_w"], self.P[f"down{i}.ln_b"],
-                                     self.M[i - 1], cp, split=pre)
+                    g_, b_ = self._ln_params(f"down{i}.ln_w", f"down{i}.ln_b", f"down{i}.ln" if pre else None)
+                    L.layernorm_rows(self.x[i - 1], self.tmp, g_, b_, self.M[i - 1], cp, split=pre)
+                    self._record(f"down{i}.ln", self.tmp[: self.M[i - 1] * cp])
                     self._gemm(self.tmp, f"down{i}.w", f"down{i}.b", self.x[i], hin=hp, win=wp, cin=cp, lda=cp, kh=2, kw=2,
-                               stride=2, pad=0, n=c, ldc=c, split_flags=fa)
+                               stride=2, pad=0, n=c, ldc=c, split_flags=fa, a_key=f"down{i}.ln" if pre else None)
             for j in range(a.depths[i]):
                 q = f"s{i}.{j}."
+                g_, b_ = self._ln_params(q + "ln_w", q + "ln_b", q + "ln" if pre else None)
                 if c % 32 == 0 and self.fuse_dwln:   # dwconv -> norm in one kernel (bit-identical to the pair; one HBM round trip less)
-                    L.dwconv7_ln(self.x[i], self.P[q + "dw_w"], self.P[q + "dw_b"], self.tmp, self.P[q + "ln_w"],
-                                 self.P[q + "ln_b"], B, h, w, c, split=pre)
+                    L.dwconv7_ln(self.x[i], self.P[q + "dw_w"], self.P[q + "dw_b"], self.tmp, g_, b_, B, h, w, c, split=pre)
                 else:
                     L.dwconv7(self.x[i], self.P[q + "dw_w"], self.P[q + "dw_b"], self.tmp, B, h, w, c)
-                    L.layernorm_rows(self.tmp, self.tmp, self.P[q + "ln_w"], self.P[q + "ln_b"], self.M[i], c, split=pre)
+                    L.layernorm_rows(self.tmp, self.tmp, g_, b_, self.M[i], c, split=pre)
+                self._record(q + "ln", self.tmp[: self.M[i] * c])
                 self._conv(self.tmp, q + "w1", q + "b1", self.hid, hin=h, win=w, cin=c, lda=c, n=4 * c, ldc=4 * c,
-                           act=L.ACT_GELU, split_flags=(L.SPLIT_A | L.SPLIT_C) if pre else 0)
+                           act=L.ACT_GELU, split_flags=(L.SPLIT_A | L.SPLIT_C) if pre else 0,
+                           a_key=q + "ln" if pre else None, c_key=q + "hid")
                 # x <- x + (gamma*W2) hid + gamma*b2   (in place: each element is read then written by one lane)
                 self._conv(self.hid, q + "w2", q + "b2", self.x[i], hin=h, win=w, cin=4 * c, lda=4 * c, n=c, ldc=c,
-                           res=self.x[i], ldres=c, split_flags=fa)
+                           res=self.x[i], ldres=c, split_flags=fa, a_key=q + "hid" if pre else None)
         return self.x
 
     # ------------------------------------------------------------------ neck
-    def _bepc3(self, name: str, x, ldx: int, cin: int, hw: Tuple[int, int], out, cout: int):
+    def _bepc3(self, name: str, x, ldx: int, cin: int, hw: Tuple[int, int], out, cout: int, xkey: str, okey: str):
+        """xkey / okey: split-scale keys of the input / output buffers (calibrate())."""
         bf = self._bep[name]
         c_ = bf["c_"]
         h, w = hw
@@ -284,25 +333,26 @@ class ImageTower:
         sfx = "s" if S else ""
         # cv1 output: the 3x3 chain reads it (split) AND the first BottleRep adds it back (fp32): dual write
         self._conv(x, f"{name}.cv1.w", f"{name}.cv1.b", bf["u0" + sfx], hin=h, win=w, cin=cin, lda=ldx, n=c_, ldc=c_,
-                   act=L.ACT_SILU, split_flags=fl, c2=bf["u0"] if S else None, ldc2=c_ if S else 0)
+                   act=L.ACT_SILU, split_flags=fl, c2=bf["u0"] if S else None, ldc2=c_ if S else 0, a_key=xkey, c_key=name + ".u0")
         cur, nxt = "u0", "u1"
         for j in range(nb):
             s = f"{name}.m{j}"
             self._conv(bf[cur + sfx], s + ".c1.w", s + ".c1.b", bf["t"], hin=h, win=w, cin=c_, lda=c_, n=c_, ldc=c_, k=3,
-                       act=L.ACT_SILU, split_flags=fl)
+                       act=L.ACT_SILU, split_flags=fl, a_key=f"{name}.{cur}", c_key=name + ".t")
             last = j == nb - 1
             dst, ldd = (cat, 2 * c_) if last else (bf[nxt + sfx], c_)
             self._conv(bf["t"], s + ".c2.w", s + ".c2.b", dst, hin=h, win=w, cin=c_, lda=c_, n=c_, ldc=ldd, k=3,
                        act=L.ACT_SILU, res=bf[cur], ldres=c_, res_alpha=self.P.s[s + ".alpha"], split_flags=fl,
-                       c2=bf[nxt] if (S and not last) else None, ldc2=c_ if (S and not last) else 0)
+                       c2=bf[nxt] if (S and not last) else None, ldc2=c_ if (S and not last) else 0,
+                       a_key=name + ".t", c_key=name + ".cat" if last else f"{name}.{nxt}")
             cur, nxt = nxt, cur
         self._conv(x, f"{name}.cv2.w", f"{name}.cv2.b", cat[:, c_:], hin=h, win=w, cin=cin, lda=ldx, n=c_,
-                   ldc=2 * c_, act=L.ACT_SILU, split_flags=fl)
+                   ldc=2 * c_, act=L.ACT_SILU, split_flags=fl, a_key=xkey, c_key=name + ".cat")
         self._conv(cat, f"{name}.cv3.w", f"{name}.cv3.b", out, hin=h, win=w, cin=2 * c_, lda=2 * c_, n=cout,
-                   ldc=cout, act=L.ACT_SILU, split_flags=fl)
+                   ldc=cout, act=L.ACT_SILU, split_flags=fl, a_key=name + ".cat", c_key=okey)
 
     def _bifusion(self, name: str, top, ld_top: int, hw_top, mid, c_mid: int, hw_mid, low, c_low: int, hw_low,
-                  cat, tbuf, out, cout: int):
+                  cat, tbuf, out, cout: int, topkey: str, midkey: str, lowkey: str, okey: str):
         """cat = [upsample(top) | cv1(mid) | downsample(cv2(low))] -> cv3 -> out  (yolo_world_pafpn.py:711-715)."""
         ht, wt = hw_top
         hm, wm = hw_mid
@@ -311,15 +361,16 @@ class ImageTower:
         fl = (L.SPLIT_A | L.SPLIT_C) if S else 0
         fc = L.SPLIT_C if S else 0            # fp32 residual stream in (split by the loader), hi/lo groups out
         self._gemm(top, name + ".up.w", name + ".up.b", cat, hin=ht, win=wt, cin=cout, lda=ld_top, n=4 * cout,
-                   ldc=3 * cout, out_mode=L.OUT_DECONV2X2, split_flags=fl)
+                   ldc=3 * cout, out_mode=L.OUT_DECONV2X2, split_flags=fl, a_key=topkey, c_key=name + ".cat")
         self._conv(mid, name + ".cv1.w", name + ".cv1.b", cat[:, cout:], hin=hm, win=wm, cin=c_mid, lda=c_mid, n=cout,
-                   ldc=3 * cout, act=L.ACT_RELU, fp32=True, split_flags=fc)   # mid / low are backbone residual streams
+                   ldc=3 * cout, act=L.ACT_RELU, fp32=True, split_flags=fc, a_key=midkey, c_key=name + ".cat")   # mid / low: residual streams
         self._conv(low, name + ".cv2.w", name + ".cv2.b", tbuf, hin=hl, win=wl, cin=c_low, lda=c_low, n=cout, ldc=cout,
-                   act=L.ACT_RELU, fp32=True, split_flags=fc)
+                   act=L.ACT_RELU, fp32=True, split_flags=fc, a_key=lowkey, c_key=name + ".t")
         self._conv(tbuf, name + ".downsample.w", name + ".downsample.b", cat[:, 2 * cout:], hin=hl, win=wl, cin=cout,
-                   lda=cout, n=cout, ldc=3 * cout, k=3, stride=2, act=L.ACT_RELU, split_flags=fl)
+                   lda=cout, n=cout, ldc=3 * cout, k=3, stride=2, act=L.ACT_RELU, split_flags=fl, a_key=name + ".t",
+                   c_key=name + ".cat")
         self._conv(cat, name + ".cv3.w", name + ".cv3.b", out, hin=hm, win=wm, cin=3 * cout, lda=3 * cout, n=cout,
-                   ldc=cout, act=L.ACT_RELU, split_flags=fl)
+                   ldc=cout, act=L.ACT_RELU, split_flags=fl, a_key=name + ".cat", c_key=okey)
 
     def neck(self) -> List[torch.Tensor]:
         """P3, P4, P5 buffers.  In the pre-split mode (see __init__) they hold fp16 hi/lo groups, like every other neck
@@ -334,22 +385,23 @@ class ImageTower:
         fl = (L.SPLIT_A | L.SPLIT_C) if S else 0
         fpn_out0 = self.cat_n4[:, nc["d1"]:]
         self._conv(c4, "reduce_layer0.w", "reduce_layer0.b", fpn_out0, hin=hw5[0], win=hw5[1], cin=nc["c4"],
-                   lda=nc["c4"], n=nc["p5r"], ldc=ld4, act=L.ACT_RELU, fp32=True, split_flags=L.SPLIT_C if S else 0)
+                   lda=nc["c4"], n=nc["p5r"], ldc=ld4, act=L.ACT_RELU, fp32=True, split_flags=L.SPLIT_C if S else 0,
+                   a_key="c4", c_key="cat_n4")
         self._bifusion("Bifusion0", fpn_out0, ld4, hw5, c3, nc["c3"], hw4, c2, nc["c2"], hw3, self.cat_b0, self.b0_t,
-                       self.f0, nc["p5r"])
-        self._bepc3("Rep_p4", self.f0, nc["p5r"], nc["p5r"], hw4, self.f_out0, nc["p5r"])
+                       self.f0, nc["p5r"], "cat_n4", "c3", "c2", "f0")
+        self._bepc3("Rep_p4", self.f0, nc["p5r"], nc["p5r"], hw4, self.f_out0, nc["p5r"], "f0", "f_out0")
         fpn_out1 = self.cat_n3[:, nc["d2"]:]
         self._conv(self.f_out0, "reduce_layer1.w", "reduce_layer1.b", fpn_out1, hin=hw4[0], win=hw4[1], cin=nc["p5r"],
-                   lda=nc["p5r"], n=nc["p4r"], ldc=ld3, act=L.ACT_RELU, split_flags=fl)
+                   lda=nc["p5r"], n=nc["p4r"], ldc=ld3, act=L.ACT_RELU, split_flags=fl, a_key="f_out0", c_key="cat_n3")
         self._bifusion("Bifusion1", fpn_out1, ld3, hw4, c2, nc["c2"], hw3, c1, nc["c1"], hw2, self.cat_b1, self.b1_t,
-                       self.f1, nc["p4r"])
-        self._bepc3("Rep_p3", self.f1, nc["p4r"], nc["p4r"], hw3, self.p3, nc["p4r"])
+                       self.f1, nc["p4r"], "cat_n3", "c2", "c1", "f1")
+        self._bepc3("Rep_p3", self.f1, nc["p4r"], nc["p4r"], hw3, self.p3, nc["p4r"], "f1", "p3")
         self._conv(self.p3, "downsample2.w", "downsample2.b", self.cat_n3, hin=hw3[0], win=hw3[1], cin=nc["p4r"],
-                   lda=nc["p4r"], n=nc["d2"], ldc=ld3, k=3, stride=2, act=L.ACT_RELU, split_flags=fl)
-        self._bepc3("Rep_n3", self.cat_n3, ld3, ld3, hw4, self.p4, nc["n3"])
+                   lda=nc["p4r"], n=nc["d2"], ldc=ld3, k=3, stride=2, act=L.ACT_RELU, split_flags=fl, a_key="p3", c_key="cat_n3")
+        self._bepc3("Rep_n3", self.cat_n3, ld3, ld3, hw4, self.p4, nc["n3"], "cat_n3", "p4")
         self._conv(self.p4, "downsample1.w", "downsample1.b", self.cat_n4, hin=hw4[0], win=hw4[1], cin=nc["n3"],
-                   lda=nc["n3"], n=nc["d1"], ldc=ld4, k=3, stride=2, act=L.ACT_RELU, split_flags=fl)
-        self._bepc3("Rep_n4", self.cat_n4, ld4, ld4, hw5, self.p5, nc["n4"])
+                   lda=nc["n3"], n=nc["d1"], ldc=ld4, k=3, stride=2, act=L.ACT_RELU, split_flags=fl, a_key="p4", c_key="cat_n4")
+        self._bepc3("Rep_n4", self.cat_n4, ld4, ld4, hw5, self.p5, nc["n4"], "cat_n4", "p5")
         return [self.p3, self.p4, self.p5]
 
     # ------------------------------------------------------------------ head
@@ -363,19 +415,19 @@ class ImageTower:
             h, w = self.lv[l]
             c1, c2 = self.hc[l]
             self._conv(feat, f"head{l}.cls0.w", f"head{l}.cls0.b", c1, hin=h, win=w, cin=cin, lda=cin, n=CLS_MID,
-                       ldc=CLS_MID, k=3, act=L.ACT_SILU, split_flags=fl)
+                       ldc=CLS_MID, k=3, act=L.ACT_SILU, split_flags=fl, a_key=f"p{l + 3}", c_key=f"h{l}.c1")
             self._conv(c1, f"head{l}.cls1.w", f"head{l}.cls1.b", c2, hin=h, win=w, cin=CLS_MID, lda=CLS_MID, n=CLS_MID,
-                       ldc=CLS_MID, k=3, act=L.ACT_SILU, split_flags=fl)
+                       ldc=CLS_MID, k=3, act=L.ACT_SILU, split_flags=fl, a_key=f"h{l}.c1", c_key=f"h{l}.c2")
             dst = self.embed.view(-1, EMBED_DIM)[self.off[l]:]
             self._conv(c2, f"head{l}.embed.w", f"head{l}.embed.b", dst, hin=h, win=w, cin=CLS_MID, lda=CLS_MID,
-                       n=EMBED_DIM, ldc=EMBED_DIM, c_batch_stride=self.ntot, split_flags=fa)
+                       n=EMBED_DIM, ldc=EMBED_DIM, c_batch_stride=self.ntot, split_flags=fa, a_key=f"h{l}.c2")
             r1, r2, dist = self.hr[l]
             self._conv(feat, f"head{l}.reg0.w", f"head{l}.reg0.b", r1, hin=h, win=w, cin=cin, lda=cin, n=REG_MID,
-                       ldc=REG_MID, k=3, act=L.ACT_SILU, split_flags=fl)
+                       ldc=REG_MID, k=3, act=L.ACT_SILU, split_flags=fl, a_key=f"p{l + 3}", c_key=f"h{l}.r1")
             self._conv(r1, f"head{l}.reg1.w", f"head{l}.reg1.b", r2, hin=h, win=w, cin=REG_MID, lda=REG_MID, n=REG_MID,
-                       ldc=REG_MID, k=3, act=L.ACT_SILU, split_flags=fl)
+                       ldc=REG_MID, k=3, act=L.ACT_SILU, split_flags=fl, a_key=f"h{l}.r1", c_key=f"h{l}.r2")
             self._conv(r2, f"head{l}.dist.w", f"head{l}.dist.b", dist, hin=h, win=w, cin=REG_MID, lda=REG_MID, n=64,
-                       ldc=64, split_flags=fa)
+                       ldc=64, split_flags=fa, a_key=f"h{l}.r2")
             L.dfl_decode(dist, 64, self.boxes, self.B, h, w, STRIDES[l], self.off[l], self.ntot)
         return self.embed, self.boxes
 
@@ -428,6 +480,52 @@ class ImageTower:
         if with_embed:
             res["embeddings"] = self.out_embed
         return res
+
+    # ------------------------------------------------------------------ fp16x3 range calibration
+    SCALE_TARGET_LOG2 = 10       # calibrate() places max |x| of every split tensor at 2^10: 2^6 of headroom below the fp16 maximum
+
+    def calibrate(self, images_u8: torch.Tensor) -> Dict[str, float]:
+        """Choose the power-of-two split scales for this checkpoint's activation ranges from ONE batch.
+
+        An fp32 value travels through the fp16x3 GEMMs as hi = fp16(x), lo = fp16(x - hi).  That pair reproduces x to 2^-22
+        relative only while lo stays a NORMAL fp16 number, i.e. for |x| >~ 2^-3; below, lo is quantised to 2^-24 and the
+        pair carries an ABSOLUTE error of ~3e-8.  That floor is harmless for a homogeneous O(1) tensor (it is below the
+        fp32 rounding of the tensor's large elements), but a tensor that lives at 1e-4, or CHANNELS that do while others
+        sit at 10 (residual streams with outlier channels, compensated by the next layer's weights), would be carried to
+        3e-4 relative.  Above 65504 the hi half overflows (the run-time range guard catches that and falls back to fp32
+        kernels).  This pass runs the tower once with the fp32 kernels on ``images_u8``, records max |x| of every tensor
+        that is split (LayerNorm outputs, GELU hidden tensors, neck / head activations, the residual streams the neck
+        reads) and gives each the power of two that moves its maximum to 2^10: elements down to 2^-13 of the maximum
+        (four decades) keep full fp32 accuracy, 64 x of headroom remain before the guard would trip.  The producer
+        multiplies by the scale right before the split (LayerNorm: folded into gamma / beta; GEMM epilogues:
+        WdConvGemm.c_split_scale; loader-split layers: a_scale), the consumer's weight unscale divides it out — exact
+        operations: values whose halves were normal before come out bit-identical, the others more accurate.
+        Measured (tests/test_gpu_precision.py, error of the region embeddings against the fp32-MFMA tower, in units of
+        their rms): streams at 1e-4: 5.4e-4 uncalibrated -> 7.5e-6; hidden activations at 1e-3: 9.4e-5 -> 8.4e-6; streams at
+        3e4: guard trips -> 1.0e-5.  Returns the recorded maxima.  Detectors call it on the first batch a tower sees."""
+        self.calibrated = True
+        if self.precision != "fp16x3":
+            return {}
+        saved = self.precision
+        self.precision, self._calib = "fp32", {}
+        try:
+            self.features(images_u8)
+            keys = list(self._calib)
+            vals = torch.stack([self._calib[k] for k in keys]).tolist() if keys else []
+        finally:
+            self.precision, self._calib = saved, None
+        amax = dict(zip(keys, vals))
+        new = {}
+        for k, m in amax.items():
+            if math.isfinite(m) and m > 0.0:
+                sc = 2.0 ** (self.SCALE_TARGET_LOG2 - math.floor(math.log2(m)) - 1)      # max lands in [2^9, 2^10)
+                if sc != 1.0:
+                    new[k] = sc
+        if new != self.sscale:
+            self.sscale = new
+            self._ln_scaled.clear()
+            self.generation += 1               # scales are kernel arguments baked into captured graphs
+        return amax
 
     def identity_meta(self) -> torch.Tensor:
         """Letterbox metadata of a network-sized image: pad 0, scale 1, clamp to H x W."""

@@ -59,6 +59,7 @@ class ConvGemm(C.Structure):
         ("seg_scale", C.c_float * 3), ("seg_bias", C.c_float * 3),
         ("range_flag", C.c_void_p),
         ("c2", C.c_void_p), ("ldc2", C.c_int32),
+        ("a_scale", C.c_float), ("c_split_scale", C.c_float),
     ]
 
 
@@ -153,7 +154,7 @@ def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
 def conv_gemm(a, w, bias, c, *, batch, hin, win, cin, lda, kh=1, kw=1, stride=1, pad=0, hout=None, wout=None,
               n, ldc, act=ACT_NONE, res=None, ldres=0, res_alpha=1.0, out_mode=OUT_ROWS,
               out_scale=1.0, out_bias=0.0, sigmoid=False, c_batch_stride=0, seg=None, tuned_cfg=None,
-              w_split=None, split_cfg=-1, split_flags=0, workspace=None, k_splits=0, range_flag=None, c2=None, ldc2=0) -> None:
+              w_split=None, split_cfg=-1, split_flags=0, workspace=None, k_splits=0, range_flag=None, c2=None, ldc2=0, a_scale=1.0, c_split_scale=1.0) -> None:
     """``seg`` = (seg_rows, seg_end0, seg_end1, (s0, s1, s2), (b0, b1, b2)) or None.
     ``w_split`` = (split weight buffer, unscale) from :func:`split_weights` selects the fp16x3 kernel;
     ``split_flags`` = SPLIT_A / SPLIT_C: activations / output stored as fp16 hi/lo groups; ``workspace`` (a device
@@ -164,7 +165,7 @@ def conv_gemm(a, w, bias, c, *, batch, hin, win, cin, lda, kh=1, kw=1, stride=1,
                  lda=lda, kh=kh, kw=kw, stride=stride, pad=pad, hout=hout, wout=wout,
                  m=batch * hout * wout, n=n, k=kh * kw * cin, ldc=ldc, ldres=ldres, act=act, out_mode=out_mode,
                  res_alpha=res_alpha, out_scale=out_scale, out_bias=out_bias, sigmoid=int(bool(sigmoid)),
-                 c_batch_stride=c_batch_stride, range_flag=_p(range_flag), c2=_p(c2), ldc2=ldc2)
+                 c_batch_stride=c_batch_stride, range_flag=_p(range_flag), c2=_p(c2), ldc2=ldc2, a_scale=a_scale, c_split_scale=c_split_scale)
     if seg is not None:
         p.seg_rows, p.seg_end0, p.seg_end1 = int(seg[0]), int(seg[1]), int(seg[2])
         p.seg_scale = (C.c_float * 3)(*[float(v) for v in seg[3]])
