@@ -296,6 +296,14 @@ int wd_layernorm_rows_split_s2d(const float* x, void* y, const float* gamma, con
  * With split K (wd_conv_gemm_split_ws choosing > 1 splits) only the first of the two kernels is stamped. */
 int wd_time_next_gemm(void* start_event, void* stop_event);
 
+/* Diagnostic micro-benchmark (not on the product path): the global -> LDS byte rate the LDS-fed GEMM kernels can draw on.
+ * `grid` workgroups of 8 waves each stream iters x 8 x 8 KB with global_load_lds_dwordx4 from their own window of
+ * window_bytes (walked cyclically: small = cache-resident, large = HBM stream); pattern 0 = 1 KB contiguous per
+ * instruction, 1 = 16 rows x 64 B at a row pitch of pitch_bytes (a K = 16 operand stage).  src: grid * window_bytes bytes;
+ * sink: grid words.  scripts/lds_dma_probe.py turns it into TB/s. */
+int wd_probe_lds_dma(const void* src, int64_t window_bytes, int32_t grid, int32_t iters, int32_t pattern,
+                     int32_t pitch_bytes, void* sink, void* stream);
+
 /* sizeof(WdConvGemm) as compiled into the library, so a binding can verify its mirror. */
 int wd_sizeof_conv_gemm(void);
 

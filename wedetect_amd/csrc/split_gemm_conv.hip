@@ -338,9 +338,12 @@ split_conv_pp_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, 
   // Steady state, all eight waves in phase, ONE barrier per K stage:
   //   read the fragments of stage s | issue the DMA of stage s + NBUF - 1 into the buffer every wave finished reading
   //   before the last barrier | 12 MFMAs | wait (counted) until the own share of stage s + 1 has landed | barrier
-  // A ping-pong schedule (two wave groups half a stage apart, two barriers per stage) and fragment reads software-
-  // pipelined inside the wave were built on this kernel, are bit-identical, and measured 5-12 % slower on every neck / head
-  // shape (profiles/r03_convpp_modes.txt): the launches are bound by the global -> LDS byte rate, not by issue slots.
+  // Built on this kernel, bit-identical, measured and dropped: a ping-pong schedule (two wave groups half a stage apart,
+  // two barriers per stage: +5-12 %), fragment reads software-pipelined inside the wave (second register set: +-0), and
+  // four dedicated loader waves that issue every DMA while the eight compute waves only read and multiply (12 waves, ring
+  // of 5-6: +6-9 %) — profiles/r03_convpp_modes.txt, r03_convpp_loader_waves.txt.  The timing-only ablations
+  // (r03_convpp_ablations_inphase.txt) price the 32 x 40 x 40, 128 -> 128 layer at 21 us launch + prologue + barriers,
+  // 27 us MFMAs, 9 us epilogue and 18 us of operand movement that none of the four schedules hides.
   int bcur = 0, bfill = DIST % NBUF;
   for (int s = 0; s < nk; ++s) {
     read(bcur);
