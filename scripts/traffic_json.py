@@ -31,8 +31,13 @@ def per_kernel(path, counter):
 def main():
     fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from wedetect_amd.build import source_hash
     out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes over `bench.py --steps 2 --warmup 1`; "
                    "KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of 16 B/lane coalesced reads)",
+           # provenance: bench.py prints these beside roofline.traffic and says whether the running library was built from the same sources
+           "commit": os.environ.get("WD_COMMIT"), "kernel_source_sha256": source_hash(),
            "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
         f, nf = fetch.get(k, (0.0, 0))

@@ -154,7 +154,11 @@ __global__ void __launch_bounds__(256) dwconv7_tiled_kernel(const float* __restr
   __syncthreads();
 
   const int q = t & 7;                   // channel quad
-  const int wg = (t >> 3) & 3;           // 4-pixel strip inside the 16-wide tile
+  // 4-pixel strip inside the 16-wide tile.  A ds_read_b128 is served 16 lanes at a time (2 x 128 B over the 64 banks):
+  // lanes 8-15 must sit 32 banks from lanes 0-7.  Strips are 4 pixels = 576 B = 16 banks apart (with the 36-float pixel
+  // pitch), so neighbouring lane octets take strips 0 and 2 (1152 B = 32 banks), then 1 and 3 — the natural order
+  // (0, 1, 2, 3) overlapped 16 banks per pair: SQ_LDS_BANK_CONFLICT = 33 % of the LDS cycles in round 2.
+  const int wg = ((t >> 3) & 1) * 2 + ((t >> 4) & 1);
   const int oy = t >> 5;                 // output row inside the tile
   f32x4 acc[4];
   const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c0 + q * 4);
@@ -337,18 +341,19 @@ __device__ __forceinline__ void ln_row(const float* __restrict__ xr, float* __re
   }
 }
 
-template <int NV, bool SPLIT>
+// R rows per lane group, their loads all issued before the first reduction (narrow rows — C = 128 / 256 — give a lane a
+// single 16-byte load per row: with one row per group the kernel ran at 3.5 TB/s, latency-bound).  Per row the same
+// operations in the same order as ln_row: identical bits.
+template <int NV, bool SPLIT, int R>
 __global__ void __launch_bounds__(256) layernorm_rows_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, long long rows, int c,
                                                              int ldx, int ldy, float eps, int g, int s2d_h, int s2d_w) {
   const int t = threadIdx.x;
   const int rows_per_block = 256 / g;
-  const long long row = (long long)blockIdx.x * rows_per_block + t / g;
-  const bool row_ok = row < rows;      // keep every lane alive for the shuffles
-  const long long r = row_ok ? row : 0;
-  float* yr = y + r * ldy;
-  if (s2d_w > 0) {
+  const long long row0 = ((long long)blockIdx.x * rows_per_block + t / g) * R;
+  auto dst = [&](long long r) -> float* {
+    if (s2d_w <= 0) return y + r * ldy;
     // space-to-depth output (wd_layernorm_rows_split_s2d): pixel (b, py, px) of an h x w map -> row (b, py / 2, px / 2) of
     // the [B * h/2 * w/2, 4 c] matrix, columns [((py & 1) * 2 + (px & 1)) * c, + c): the (kh, kw, cin) order of a 2 x 2 /
     // stride-2 convolution's GEMM rows, so that the convolution becomes a plain GEMM
@@ -357,9 +362,57 @@ __global__ void __launch_bounds__(256) layernorm_rows_kernel(const float* __rest
     const int py = (int)(q % s2d_h);
     const long long b = q / s2d_h;
     const long long drow = (b * (s2d_h >> 1) + (py >> 1)) * (s2d_w >> 1) + (px >> 1);
-    yr = y + drow * ldy + ((py & 1) * 2 + (px & 1)) * c;
+    return y + drow * ldy + ((py & 1) * 2 + (px & 1)) * c;
+  };
+  if (R == 1) {
+    const bool row_ok = row0 < rows;      // keep every lane alive for the shuffles
+    const long long r = row_ok ? row0 : 0;
+    ln_row<NV, SPLIT>(x + r * ldx, dst(r), gamma, beta, c, eps, g, t % g, row_ok);
+    return;
   }
-  ln_row<NV, SPLIT>(x + r * ldx, yr, gamma, beta, c, eps, g, t % g, row_ok);
+  static_assert(R == 1 || NV == 1, "multi-row groups are for rows of one float4 per lane");
+  const int gl = t % g, nq = c >> 2;
+  const bool lane_ok = gl < nq;
+  f32x4 v[R];
+  bool ok[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    ok[k] = row0 + k < rows;
+    v[k] = (ok[k] && lane_ok) ? *reinterpret_cast<const f32x4*>(x + (row0 + k) * ldx + gl * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const f32x4 gm = lane_ok ? *reinterpret_cast<const f32x4*>(gamma + gl * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 bt = lane_ok ? *reinterpret_cast<const f32x4*>(beta + gl * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    float s = 0.f;
+    s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+    s = wd_group_sum(s, g);
+    const float mean = s / (float)c;
+    float sq = 0.f;
+    if (lane_ok) {
+      const f32x4 d = v[k] - mean;
+      sq += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+    }
+    sq = wd_group_sum(sq, g);
+    const float rstd = 1.0f / sqrtf(sq / (float)c + eps);
+    if (!ok[k] || !lane_ok) continue;
+    const f32x4 o = (v[k] - mean) * rstd * gm + bt;
+    float* yr = dst(row0 + k);
+    if (SPLIT) {
+      typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      const f32x2 a = {o[0], o[1]}, b = {o[2], o[3]};
+      const h2 ha = __builtin_convertvector(a, h2), hb = __builtin_convertvector(b, h2);
+      const h2 la = __builtin_convertvector(a - __builtin_convertvector(ha, f32x2), h2);
+      const h2 lb = __builtin_convertvector(b - __builtin_convertvector(hb, f32x2), h2);
+      unsigned char* gp = reinterpret_cast<unsigned char*>(yr) + (size_t)(gl >> 1) * 32 + (gl & 1) * 8;
+      *reinterpret_cast<u32x2*>(gp) = u32x2{__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)};
+      *reinterpret_cast<u32x2*>(gp + 16) = u32x2{__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)};
+    } else {
+      *reinterpret_cast<f32x4*>(yr + gl * 4) = o;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -386,7 +439,11 @@ __global__ void __launch_bounds__(256) dwconv7_ln_kernel(const float* __restrict
   const long long b = bid / tiles_h;
   const int h0 = ty * DT_TH, w0 = tx * DT_TW;
   const int q = t & 7;                   // channel quad
-  const int wg = (t >> 3) & 3;           // 4-pixel strip inside the 16-wide tile
+  // 4-pixel strip inside the 16-wide tile.  A ds_read_b128 is served 16 lanes at a time (2 x 128 B over the 64 banks):
+  // lanes 8-15 must sit 32 banks from lanes 0-7.  Strips are 4 pixels = 576 B = 16 banks apart (with the 36-float pixel
+  // pitch), so neighbouring lane octets take strips 0 and 2 (1152 B = 32 banks), then 1 and 3 — the natural order
+  // (0, 1, 2, 3) overlapped 16 banks per pair: SQ_LDS_BANK_CONFLICT = 33 % of the LDS cycles in round 2.
+  const int wg = ((t >> 3) & 1) * 2 + ((t >> 4) & 1);
   const int oy = t >> 5;                 // output row inside the tile
   constexpr int NST = (DT_IH * DT_IW * 8 + 255) / 256;
   for (int cb = 0; cb < ncb; ++cb) {
@@ -603,12 +660,19 @@ static int launch_layernorm(const float* x, float* y, const float* gamma, const 
   while (g < 64 && g < nq) g <<= 1;
   const int nv = (nq + g - 1) / g;
   const int rpb = 256 / g;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (nv == 1 && rows >= 65536) {                    // narrow rows, many of them: four rows per lane group (in place is fine: a group loads its rows before it stores them)
+    const long long grid4 = (rows + 4 * rpb - 1) / (4 * rpb);
+    if (grid4 > 0x7fffffffLL) return WD_ERR_BAD_ARG;
+    hipLaunchKernelGGL((layernorm_rows_kernel<1, SPLIT, 4>), dim3((unsigned)grid4), dim3(256), 0, st, x, y, gamma, beta,
+                       (long long)rows, c, ldx, ldy, eps, g, s2d_h, s2d_w);
+    return wd_launch_status();
+  }
   const long long grid = (rows + rpb - 1) / rpb;
   if (grid > 0x7fffffffLL) return WD_ERR_BAD_ARG;
-  hipStream_t st = static_cast<hipStream_t>(stream);
 #define WD_LN_CASE(NV)                                                                                              \
   case NV:                                                                                                          \
-    hipLaunchKernelGGL((layernorm_rows_kernel<NV, SPLIT>), dim3((unsigned)grid), dim3(256), 0, st, x, y, gamma,     \
+    hipLaunchKernelGGL((layernorm_rows_kernel<NV, SPLIT, 1>), dim3((unsigned)grid), dim3(256), 0, st, x, y, gamma,  \
                        beta, (long long)rows, c, ldx, ldy, eps, g, s2d_h, s2d_w);                                   \
     break;
   switch (nv) {

@@ -14,7 +14,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwedetect_hip.so")
+# $WEDETECT_LIB: another build of the same ABI (same-box A/B runs of two kernel versions); default = the in-tree library
+LIB_PATH = os.environ.get("WEDETECT_LIB") or os.path.join(_HERE, "libwedetect_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU = 0, 1, 2, 3
 OUT_ROWS, OUT_DECONV2X2 = 0, 1
