@@ -244,3 +244,56 @@ def test_generate_proposal_and_retrieval_entries(tmp_path, monkeypatch):
     results = rm.main(["--model", "uni", "--dataset", "coco", "--thre", str(thre), "--ann-path", str(tmp_path / "ann.json"), "--pred", outp])
     assert set(results) == {"cat", "dog"}                                       # 'kite' has no ground truth: skipped (retrieval_metric.py:28-29)
     assert all(0.0 <= v["precision"] <= 1.0 and v["support"] >= 1 for v in results.values())
+
+
+def test_eval_recall_entry(tmp_path, monkeypatch):
+    """eval_recall/eval_recall.py (the reference's third Uni script, eval_recall.py:1491-1589): one rank over RCCL, batch 2
+    with a ragged tail, COCO-style annotations with a crowd and an ignored box.  AR@100 / AR@300 printed by the entry ==
+    the reference evaluator's numbers (oracle.evaluate, pinned to recall.py) on the detector's own proposals; a planted
+    ground truth equal to one proposal of each image makes the recall non-trivial."""
+    import importlib.util
+    from PIL import Image
+    import generate_proposal as gp
+    from oracle import evaluate as oev
+    from wedetect_amd import detector as D
+    from wedetect_amd import weights as W
+    monkeypatch.setattr(gp, "model_size_of", lambda p: "nano")
+    monkeypatch.setitem(D._IMG_SIZE, "nano", (128, 128))
+    sd = {k: torch.from_numpy(v) for k, v in W.to_uni_keys(W.make_state_dict("nano", num_prompts=256)).items()}
+    uni = str(tmp_path / "wedetect_base_uni.pth")
+    torch.save(sd, uni)
+    g = np.random.default_rng(18)
+    sizes = [(120, 200), (128, 64), (90, 90), (128, 128), (64, 100)]
+    (tmp_path / "imgs").mkdir()
+    images = []
+    for i, (h, w) in enumerate(sizes):
+        Image.fromarray(g.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(str(tmp_path / "imgs" / f"{i}.png"))
+        images.append(dict(id=500 + i, file_name=f"{i}.png"))
+    model = gp.load_uni_detector(uni)
+    direct = [model([str(tmp_path / "imgs" / im["file_name"])])[0]["bboxes"].cpu().numpy() for im in images]
+    anns = []
+    for i, (im, bx) in enumerate(zip(images, direct)):
+        if i == 3:
+            continue                                                           # an image without ground truth
+        x1, y1, x2, y2 = [float(v) for v in bx[min(7, len(bx) - 1)]]
+        anns.append(dict(image_id=im["id"], bbox=[x1, y1, x2 - x1, y2 - y1], iscrowd=0))            # exactly one proposal
+        anns.append(dict(image_id=im["id"], bbox=[1.0, 2.0, 30.0, 25.0], iscrowd=0))
+        anns.append(dict(image_id=im["id"], bbox=[0.0, 0.0, 50.0, 50.0], iscrowd=1))                # dropped for COCO
+        anns.append(dict(image_id=im["id"], bbox=[5.0, 5.0, 20.0, 20.0], iscrowd=0, ignore=True))   # dropped
+    (tmp_path / "ann.json").write_text(json.dumps(dict(images=images, annotations=anns)))
+    spec = importlib.util.spec_from_file_location("eval_recall_entry", os.path.join(ROOT, "eval_recall", "eval_recall.py"))
+    er = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(er)
+    monkeypatch.setattr(er, "load_uni_detector", gp.load_uni_detector)
+    for k, v in dict(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0").items():
+        monkeypatch.setenv(k, v)
+    ar100, ar300 = er.main(["--wedetect_uni_checkpoint", uni, "--dataset", "coco", "--batch-size", "2", "--num-workers", "0",
+                            "--ann-path", str(tmp_path / "ann.json"), "--image-path", str(tmp_path / "imgs")])
+    gts = er.ground_truth_boxes(anns, [im["id"] for im in images], drop_crowd=True)
+    assert [g_.shape[0] for g_ in gts] == [2, 2, 2, 0, 2]
+    iou_thrs = np.linspace(.5, 0.95, 10, endpoint=True)
+    ref = oev.eval_recalls(gts, [np.asarray(b, np.float32) for b in direct], [100, 300], iou_thrs)
+    assert ar100 == float(sum(ref[0]) / len(ref[0])) and ar300 == float(sum(ref[1]) / len(ref[1]))
+    assert 0.4 <= ar300 <= 1.0                                                 # the planted boxes are recalled at every IoU
+    lv = er.ground_truth_boxes(anns, [images[0]["id"]], drop_crowd=False)      # LVIS / PACO keep crowd boxes (eval_recall.py:95-99)
+    assert lv[0].shape[0] == 3
