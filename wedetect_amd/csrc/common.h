@@ -66,6 +66,10 @@ __device__ __forceinline__ float wd_sigmoid_fast(float x) { return __builtin_amd
 // instruction division sequence per element (a third of this function's instructions) for an error term of 6e-8
 // relative on erfc, below the approximation's own 1.5e-7.
 __device__ __forceinline__ float wd_gelu(float x) {
+  // Every fused multiply-add of this function is written as fmaf; nothing else may be contracted.  The GEMM epilogues of
+  // different kernels must produce the SAME bits for the same accumulator (pre-split and loader-split paths are compared bit
+  // for bit), and an optional contraction — here "2 - (y * t) * e" — is decided per inlining context by the compiler.
+#pragma clang fp contract(off)
   const float ax = fabsf(x) * 0.70710678118654752440f;
   const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
   float y = fmaf(1.061405429f, t, -1.453152027f);

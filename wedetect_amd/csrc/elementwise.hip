@@ -292,6 +292,9 @@ __global__ void __launch_bounds__(TH * 16) dwconv7_strip_kernel(const float* __r
 template <int NV, bool SPLIT>
 __device__ __forceinline__ void ln_row(const float* __restrict__ xr, float* __restrict__ yr, const float* __restrict__ gamma,
                                        const float* __restrict__ beta, int c, float eps, int g, int gl, bool row_ok) {
+  // no optional contraction: this row code exists twice (here and in the four-rows-per-group kernel below) and both must
+  // produce the same bits — a batch of one image takes the former, a batch of 32 the latter
+#pragma clang fp contract(off)
   const int nq = c >> 2;
   f32x4 v[NV];
   float s = 0.f;
@@ -321,7 +324,10 @@ __device__ __forceinline__ void ln_row(const float* __restrict__ xr, float* __re
     if (q < nq) {
       const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + q * 4);
       const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + q * 4);
-      const f32x4 o = (v[i] - mean) * rstd * gm + bt;
+      const f32x4 tn = (v[i] - mean) * rstd;
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = fmaf(tn[e], gm[e], bt[e]);
       if (SPLIT) {
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
         typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -371,6 +377,8 @@ __global__ void __launch_bounds__(256) layernorm_rows_kernel(const float* __rest
     return;
   }
   static_assert(R == 1 || NV == 1, "multi-row groups are for rows of one float4 per lane");
+  {
+#pragma clang fp contract(off)
   const int gl = t % g, nq = c >> 2;
   const bool lane_ok = gl < nq;
   f32x4 v[R];
@@ -396,7 +404,10 @@ __global__ void __launch_bounds__(256) layernorm_rows_kernel(const float* __rest
     sq = wd_group_sum(sq, g);
     const float rstd = 1.0f / sqrtf(sq / (float)c + eps);
     if (!ok[k] || !lane_ok) continue;
-    const f32x4 o = (v[k] - mean) * rstd * gm + bt;
+    const f32x4 tn = (v[k] - mean) * rstd;
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = fmaf(tn[e], gm[e], bt[e]);
     float* yr = dst(row0 + k);
     if (SPLIT) {
       typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -413,6 +424,7 @@ __global__ void __launch_bounds__(256) layernorm_rows_kernel(const float* __rest
       *reinterpret_cast<f32x4*>(yr + gl * 4) = o;
     }
   }
+}
 }
 
 // ---------------------------------------------------------------------------------------

@@ -67,8 +67,8 @@ __device__ __forceinline__ void epi_oct(const WdConvGemm& p, float unscale, int 
     float x0 = sact<ACT>(fmaf(v0[r], unscale, b0[r]));
     float x1 = sact<ACT>(fmaf(v1[r], unscale, b1[r]));
     if (SPECIAL) {
-      x0 = x0 * er.oscale + er.obias;
-      x1 = x1 * er.oscale + er.obias;
+      x0 = fmaf(x0, er.oscale, er.obias);
+      x1 = fmaf(x1, er.oscale, er.obias);
       if (p.sigmoid) { x0 = wd_sigmoid_fast(x0); x1 = wd_sigmoid_fast(x1); }
     }
     o0[r] = x0;
@@ -79,8 +79,8 @@ __device__ __forceinline__ void epi_oct(const WdConvGemm& p, float unscale, int 
     const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      o0[r] += p.res_alpha * r0[r];
-      o1[r] += p.res_alpha * r1[r];
+      o0[r] = fmaf(p.res_alpha, r0[r], o0[r]);
+      o1[r] = fmaf(p.res_alpha, r1[r], o1[r]);
     }
   }
   if (p.c2 != nullptr) {
@@ -100,9 +100,13 @@ __device__ __forceinline__ void epi_oct(const WdConvGemm& p, float unscale, int 
   }
   if (CSPLIT) {
     u32x2 h0, l0, h1, l1;
-    const float cs = p.c_split_scale != 0.f ? p.c_split_scale : 1.0f;       // power of two (exact); 1 for ordinary checkpoints
-    split4(o0 * cs, h0, l0);
-    split4(o1 * cs, h1, l1);
+    f32x4 s0 = o0, s1 = o1;
+    if (p.c_split_scale != 0.f && p.c_split_scale != 1.0f) {       // power of two (exact); wave-uniform branch, see epi_lds_tile_csplit
+      s0 = o0 * p.c_split_scale;
+      s1 = o1 * p.c_split_scale;
+    }
+    split4(s0, h0, l0);
+    split4(s1, h1, l1);
     unsigned char* cp = reinterpret_cast<unsigned char*>(rowp) + (size_t)(col >> 3) * 32;
     *reinterpret_cast<u32x4*>(cp) = u32x4{h0[0], h0[1], h1[0], h1[1]};
     *reinterpret_cast<u32x4*>(cp + 16) = u32x4{l0[0], l0[1], l1[0], l1[1]};

@@ -120,7 +120,7 @@ __device__ __forceinline__ void epi_quad(const WdConvGemm& p, const EpiRow& er, 
   for (int r = 0; r < 4; ++r) {
     float x = sact<ACT>(fmaf(v[r], ev.unscale, b4[r]));     // unscale is a power of two: exact
     if (SPECIAL) {
-      x = x * er.oscale + er.obias;
+      x = fmaf(x, er.oscale, er.obias);           // explicit fma: the same bits in every kernel's epilogue
       if (p.sigmoid) x = wd_sigmoid_fast(x);
     }
     o[r] = x;
@@ -130,10 +130,10 @@ __device__ __forceinline__ void epi_quad(const WdConvGemm& p, const EpiRow& er, 
     if (full && ev.res) {
       const f32x4 rv = *reinterpret_cast<const f32x4*>(rp);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] += p.res_alpha * rv[r];
+      for (int r = 0; r < 4; ++r) o[r] = fmaf(p.res_alpha, rv[r], o[r]);
     } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) if (n + r < p.n) o[r] += p.res_alpha * rp[r];
+      for (int r = 0; r < 4; ++r) if (n + r < p.n) o[r] = fmaf(p.res_alpha, rp[r], o[r]);
     }
   }
   float* cp;
@@ -242,9 +242,14 @@ __device__ __forceinline__ void epi_lds_tile_csplit(const WdConvGemm& p, const E
         o1[r] = sact<ACT>(fmaf(v1[r], ev.unscale, b1[r]));
       }
       u32x2 h0, l0, h1, l1;
-      const float cs = p.c_split_scale != 0.f ? p.c_split_scale : 1.0f;     // power of two (exact); 1 for ordinary checkpoints
-      split4(o0 * cs, h0, l0);
-      split4(o1 * cs, h1, l1);
+      // c_split_scale: a power of two (exact).  Applied under a (wave-uniform) branch: with the scale at 1 the instruction
+      // stream is the unscaled one, so that path stays bit-identical to the loader-split kernels by construction
+      if (p.c_split_scale != 0.f && p.c_split_scale != 1.0f) {
+        o0 = o0 * p.c_split_scale;
+        o1 = o1 * p.c_split_scale;
+      }
+      split4(o0, h0, l0);
+      split4(o1, h1, l1);
       unsigned char* cp = reinterpret_cast<unsigned char*>(p.c + (size_t)m * p.ldc) + (size_t)(n >> 3) * 32;
       // non-temporal: the hi/lo output of a C-split layer is a write-once stream (1.7 GB per stage-1 pwconv1) that its consumer
       // re-reads only after this launch is over: keep it from displacing the operand panels in L2 (-0.3 ms per step, same box)
@@ -344,7 +349,7 @@ struct EpiResWalk {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         o[r] = fmaf(v[ps][r], ev.unscale, b4[r]);
-        o[r] += p.res_alpha * rv[IJ % D][ps][r];
+        o[r] = fmaf(p.res_alpha, rv[IJ % D][ps][r], o[r]);
       }
       if (m < p.m) *reinterpret_cast<f32x4*>(p.c + (size_t)m * p.ldc + n) = f32x4{o[0], o[1], o[2], o[3]};
     }
@@ -479,7 +484,9 @@ split_gemm_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, con
         hi = u32x2{__builtin_bit_cast(unsigned, areg[S][i][0]), __builtin_bit_cast(unsigned, areg[S][i][1])};
         lo = u32x2{__builtin_bit_cast(unsigned, areg[S][i][2]), __builtin_bit_cast(unsigned, areg[S][i][3])};
       } else {
-        split4(areg[S][i] * a_scale, hi, lo);      // a_scale: power of two (exact), 1 for ordinary checkpoints
+        f32x4 av = areg[S][i];
+        if (a_scale != 1.0f) av = av * a_scale;    // power of two (exact); wave-uniform branch: scale 1 = the unscaled instruction stream
+        split4(av, hi, lo);
       }
       *reinterpret_cast<u32x2*>(ad + i * RSTEP * ROWB) = hi;
       *reinterpret_cast<u32x2*>(ad + i * RSTEP * ROWB + 32) = lo;
