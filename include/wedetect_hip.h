@@ -156,6 +156,17 @@ int wd_conv_gemm_split(const WdConvGemm* p, const void* w_split, float w_unscale
  * splits > 0: forced. */
 int wd_conv_gemm_split_ws(const WdConvGemm* p, const void* w_split, float w_unscale, int32_t flags, int32_t cfg,
                           void* workspace, int64_t workspace_bytes, int32_t splits, void* stream);
+/* ---- ConvNeXt block MLP as one kernel (narrow stage: c == 128, hidden == 512; other widths: WD_ERR_UNSUPPORTED) ------------
+ *   x[m, :] <- x[m, :] + W2 . GELU(W1 . a[m, :] + b1) + b2       (mm_backbone.py:117-124, gamma folded into W2 / b2)
+ * a_split: the LayerNorm rows as fp16 hi/lo groups [rows][c] (wd_layernorm_rows_split); w1_split [hidden][c] and w2_split
+ * [c][hidden] from wd_split_weights with their unscales; b1 [hidden], b2 [c]; x fp32 [rows][c], in place; rows % 128 == 0.
+ * hid_scale: the power-of-two range scale applied to the hidden activations before they are split (the caller passes
+ * w2_unscale already divided by it; 1 = none).  The 4c hidden activation never leaves the CU: bit-identical to
+ * wd_conv_gemm_split(WD_SPLIT_A | WD_SPLIT_C, GELU) followed by wd_conv_gemm_split(WD_SPLIT_A, residual in place). */
+int wd_mlp_fused_split(const void* a_split, int64_t rows, int32_t c, int32_t hidden, const void* w1_split, float w1_unscale,
+                       const float* b1, const void* w2_split, float w2_unscale, const float* b2, float* x, float hid_scale,
+                       uint32_t* range_flag, void* stream);
+
 /* Name of the tile wd_conv_gemm_split picks with cfg < 0 for an (m, n, k) problem; is_conv != 0:
  * not a 1x1 / stride 1 / pad 0 layer (diagnostic). */
 const char* wd_conv_gemm_split_config(int32_t m, int32_t n, int32_t k, int32_t is_conv);

@@ -537,3 +537,57 @@ def test_conv_pp_split_k_deconv_and_c_only_split():
     assert torch.equal(got[:, co:2 * co].contiguous().view(torch.int32), _to_split(ref[:, co:2 * co].contiguous()).view(torch.int32))
     assert float(got[:, :co].abs().max()) == 0.0 and float(got[:, 2 * co:].abs().max()) == 0.0
     assert float((_from_split(got[:, co:2 * co].contiguous()) - ref[:, co:2 * co].double()).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("m", [128, 1280, 128 * 257])
+@pytest.mark.parametrize("hid_scale", [1.0, 0.25])
+def test_fused_mlp_bit_identical_to_the_two_kernel_chain(m, hid_scale):
+    """wd_mlp_fused_split (LN rows -> pwconv1 -> GELU -> split -> pwconv2 -> + residual in one kernel, hidden tensor in LDS)
+    against the chain the engine otherwise runs: wd_conv_gemm_split(SPLIT_A | SPLIT_C, GELU) into a hidden buffer, then
+    wd_conv_gemm_split(SPLIT_A, residual in place).  Same halves, same K order, same epilogue arithmetic: the same bits,
+    with and without a range scale on the hidden activations; repeated launches agree (no race on the LDS operands)."""
+    from wedetect_amd import lib as L
+    c, h = 128, 512
+    x0, g, b = _rand((m, c), 301, 2.0), _rand((c,), 302), _rand((c,), 303, 0.1)
+    w1, b1 = _rand((h, c), 304, c ** -0.5), _rand((h,), 305, 0.1)
+    w2, b2 = _rand((c, h), 306, h ** -0.5), _rand((c,), 307, 0.1)
+    ws1, ws2 = L.split_weights(w1), L.split_weights(w2)
+    ws2s = (ws2[0], ws2[1] / hid_scale)
+    xs = torch.empty(m, c, device="cuda")
+    L.layernorm_rows(x0, xs, g, b, m, c, split=True)
+    hid = torch.empty(m, h, device="cuda")
+    want = x0.clone()
+    L.conv_gemm(xs, None, b1, hid, w_split=ws1, batch=1, hin=1, win=m, cin=c, lda=c, n=h, ldc=h, act=L.ACT_GELU,
+                split_flags=L.SPLIT_A | L.SPLIT_C, c_split_scale=hid_scale)
+    L.conv_gemm(hid, None, b2, want, w_split=ws2s, batch=1, hin=1, win=m, cin=h, lda=h, n=c, ldc=c, res=want, ldres=c,
+                split_flags=L.SPLIT_A)
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for _ in range(3):
+        got = x0.clone()
+        L.mlp_fused(xs, m, c, h, ws1, b1, ws2s, b2, got, hid_scale=hid_scale, range_flag=flag)
+        torch.cuda.synchronize()
+        assert torch.equal(got.view(torch.int32), want.view(torch.int32)), f"max|d| {float((got - want).abs().max())}"
+    assert int(flag.item()) == 0
+    # and it is a real MLP: against float64
+    y = torch.nn.functional.layer_norm(x0.double(), (c,), g.double(), b.double(), 1e-6)
+    ref = x0.double() + torch.nn.functional.gelu(y @ w1.double().T + b1.double()) @ w2.double().T + b2.double()
+    assert float((got.double() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+
+
+def test_fused_mlp_refuses_other_shapes_and_flags_overflow():
+    from wedetect_amd import lib as L
+    c, h, m = 128, 512, 256
+    assert L.mlp_fused_supported(m, c, h) and not L.mlp_fused_supported(m + 8, c, h) and not L.mlp_fused_supported(m, 256, 1024)
+    xs = torch.zeros(m, c, device="cuda")
+    ws1, ws2 = L.split_weights(_rand((h, c), 1, 0.1)), L.split_weights(_rand((c, h), 2, 0.1))
+    b1, b2, x = torch.zeros(h, device="cuda"), torch.zeros(c, device="cuda"), torch.zeros(m, c, device="cuda")
+    with pytest.raises(L.WedetectHipError):
+        L.mlp_fused(xs, m + 8, c, h, ws1, b1, ws2, b2, x)
+    with pytest.raises(L.WedetectHipError):
+        L.mlp_fused(xs, m, 256, 1024, ws1, b1, ws2, b2, x)
+    # hidden activations beyond the fp16 range: the halves overflow to inf, the accumulators of GEMM 2 go non-finite, flag set
+    b1big = torch.full((h,), 1e6, device="cuda")
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    L.mlp_fused(xs, m, c, h, ws1, b1big, ws2, b2, x, range_flag=flag)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 1

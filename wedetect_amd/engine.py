@@ -76,6 +76,7 @@ class ImageTower:
         if precision == "fp16x3" and self.p8_mode == "persist" and L.p8_workspace_bytes() > 0:
             self.park = torch.zeros(L.p8_workspace_bytes() // 4, dtype=torch.float32, device=torch.device(device))
         self.B, self.H, self.W = batch, height, width
+        self.fuse_mlp = os.environ.get("WEDETECT_FUSE_MLP", "0") == "1"        # stage-1 block MLP as one kernel (bit-identical)
         self.fuse_dwln = os.environ.get("WEDETECT_FUSE_DWLN", "0") == "1"      # measured slower at every stage (profiles/r02_dwln_ab.txt): opt-in
         self.overflowed = False
         # sticky range flag of the fp16x3 GEMMs (WdConvGemm.range_flag): set by a launch whose accumulators are inf / NaN
@@ -244,6 +245,22 @@ class ImageTower:
                 else:
                     self._record(c_key, c[..., : n // 4] if kw.get("out_mode", 0) == L.OUT_DECONV2X2 else c[..., :n])
 
+    def _mlp_fused(self, q: str, i: int) -> None:
+        """One ConvNeXt block MLP on the narrow stage as a single launch (wd_mlp_fused_split): the 4c hidden activation stays in
+        LDS.  The range scales are applied exactly as the two-kernel path does (``_gemm``): LN scale divided out of W1's
+        unscale, the hidden scale applied before the split and divided out of W2's."""
+        c = self.a.dims[i]
+        ws = []
+        for name in (q + "w1", q + "w2"):
+            s_ = self.Ws.get(name)
+            if s_ is None:
+                wt = self.P[name]
+                s_ = self.Ws[name] = L.split_weights(wt.view(wt.shape[0], -1))
+            ws.append(s_)
+        sa, sh = self.sscale.get(q + "ln", 1.0), self.sscale.get(q + "hid", 1.0)
+        L.mlp_fused(self.tmp, self.M[i], c, 4 * c, (ws[0][0], ws[0][1] / sa), self.P[q + "b1"], (ws[1][0], ws[1][1] / sh),
+                    self.P[q + "b2"], self.x[i], hid_scale=sh, range_flag=self.range_flag)
+
     def _neck_split(self) -> bool:
         """Is the neck / head running on pre-split activations in this step?  Not when the tower fell back to fp32 kernels,
         nor when the five neck input layers are pinned to fp32 (their outputs would have to be re-split)."""
@@ -312,6 +329,9 @@ class ImageTower:
                     L.dwconv7(self.x[i], self.P[q + "dw_w"], self.P[q + "dw_b"], self.tmp, B, h, w, c)
                     L.layernorm_rows(self.tmp, self.tmp, g_, b_, self.M[i], c, split=pre)
                 self._record(q + "ln", self.tmp[: self.M[i] * c])
+                if pre and self.fuse_mlp and L.mlp_fused_supported(self.M[i], c, 4 * c):
+                    self._mlp_fused(q, i)       # pwconv1 -> GELU -> pwconv2 -> residual in one kernel: same bits
+                    continue
                 self._conv(self.tmp, q + "w1", q + "b1", self.hid, hin=h, win=w, cin=c, lda=c, n=4 * c, ldc=4 * c,
                            act=L.ACT_GELU, split_flags=(L.SPLIT_A | L.SPLIT_C) if pre else 0,
                            a_key=q + "ln" if pre else None, c_key=q + "hid")

@@ -31,7 +31,7 @@ EXPORTS = (
     "wd_topk_candidates", "wd_nms_workspace_bytes", "wd_nms_gather", "wd_retrieval_max",
     "wd_split_weights_bytes", "wd_split_weights", "wd_conv_gemm_split", "wd_conv_gemm_split_ws", "wd_conv_gemm_split_config", "wd_layernorm_rows_split", "wd_layernorm_rows_split_s2d", "wd_letterbox_u8", "wd_retrieval_max_split", "wd_text_embed", "wd_attention_small", "wd_recall_scratch_floats", "wd_recall_match",
     "wd_max_sigmoid_attn", "wd_adaptive_maxpool_nhwc", "wd_cross_attention_small", "wd_time_next_gemm",
-    "wd_cv_resize_paste_u8", "wd_chw_to_hwc_u8", "wd_p8_workspace_bytes", "wd_dwconv7_ln", "wd_probe_lds_dma",
+    "wd_cv_resize_paste_u8", "wd_chw_to_hwc_u8", "wd_p8_workspace_bytes", "wd_dwconv7_ln", "wd_probe_lds_dma", "wd_mlp_fused_split",
 )
 
 
@@ -116,6 +116,7 @@ def _load():
     lib.wd_cv_resize_paste_u8.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.wd_chw_to_hwc_u8.argtypes = [vp, i32, vp, i32, i32, i32, vp]
     lib.wd_dwconv7_ln.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]
+    lib.wd_mlp_fused_split.argtypes = [vp, i64, i32, i32, vp, f32, vp, vp, f32, vp, vp, f32, vp, vp]
     lib.wd_probe_lds_dma.argtypes = [vp, i64, i32, i32, i32, i32, vp, vp]
     lib.wd_p8_workspace_bytes.restype = i64
     lib.wd_p8_workspace_bytes.argtypes = []
@@ -186,6 +187,17 @@ def conv_gemm(a, w, bias, c, *, batch, hin, win, cin, lda, kh=1, kw=1, stride=1,
         check(LIB.wd_conv_gemm_tuned(C.byref(p), int(tuned_cfg), stream_ptr()), f"wd_conv_gemm_tuned[{tuned_cfg}]")
         return
     check(LIB.wd_conv_gemm(C.byref(p), stream_ptr()), "wd_conv_gemm")
+
+
+def mlp_fused_supported(rows: int, c: int, hidden: int) -> bool:
+    return c == 128 and hidden == 512 and rows > 0 and rows % 128 == 0
+
+
+def mlp_fused(a_split, rows, c, hidden, w1_split, b1, w2_split, b2, x, hid_scale=1.0, range_flag=None) -> None:
+    """x <- x + W2 GELU(W1 a + b1) + b2 in one kernel (wd_mlp_fused_split); ``w*_split`` = (buffer, unscale) pairs."""
+    check(LIB.wd_mlp_fused_split(_p(a_split), rows, c, hidden, _p(w1_split[0]), float(w1_split[1]), _p(b1), _p(w2_split[0]),
+                                 float(w2_split[1]), _p(b2), _p(x), float(hid_scale), _p(range_flag), stream_ptr()),
+          "wd_mlp_fused_split")
 
 
 def split_weights(w: torch.Tensor):
