@@ -315,6 +315,12 @@ int wd_time_next_gemm(void* start_event, void* stop_event);
 int wd_probe_lds_dma(const void* src, int64_t window_bytes, int32_t grid, int32_t iters, int32_t pattern,
                      int32_t pitch_bytes, void* sink, void* stream);
 
+/* Diagnostic: what a wave pays for VALU instructions placed between its own MFMAs.  Every wave of `grid` workgroups of 256
+ * threads runs iters x 8 slots of { one v_mfma_f32_32x32x16_f16 + nv VALU instructions of `kind` }; mode 0: both, 1: MFMAs
+ * only, 2: VALU only, 3 / 4: as 1 / 0 with ONE dependent MFMA chain.  out[0] = shader-clock ticks, out[1] = 100 MHz ticks of
+ * workgroup 0.  Only the (mode, kind, nv) combinations scripts/issue_probe.py uses are instantiated (others: UNSUPPORTED). */
+int wd_probe_issue(int32_t mode, int32_t kind, int32_t nv, int32_t grid, int32_t iters, void* out, void* sink, void* stream);
+
 /* sizeof(WdConvGemm) as compiled into the library, so a binding can verify its mirror. */
 int wd_sizeof_conv_gemm(void);
 

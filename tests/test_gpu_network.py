@@ -315,3 +315,38 @@ def test_presplit_neck_head_is_bit_identical_to_the_loader_split_path(arch, b, h
         bound = 2.0 ** -21 * p_old.double().abs() + 1e-7          # hi + lo carries the fp32 value to 2^-22 relative (3e-8 absolute below the fp16 normal range)
         assert bool((d <= bound).all()), f"{arch} P{i+3}: split storage off by {float(d.max()):.3e}"
     assert int(t_new.range_flags.sum()) == 0
+
+
+@pytest.mark.parametrize("arch,b,hw,calibrate", [("base", 2, 128, False), ("base", 1, 640, True), ("base", 3, 96, False)])
+def test_fused_block_mlp_is_bit_identical_to_the_two_launch_path(arch, b, hw, calibrate, monkeypatch):
+    """Round 3: the stage-1 ConvNeXt block MLP (C = 128) runs as ONE kernel that keeps the 4C hidden activation in registers
+    (split_gemm_mlp.hip; $WEDETECT_FUSE_MLP=0 restores pwconv1 / pwconv2 as two launches).  Stage-1 row counts that are not
+    a multiple of 128 (b = 3 at 96 x 96: 1728 rows) keep the two launches.  Residual streams, embeddings, boxes and
+    scores must be BIT-IDENTICAL, with and without calibrated range scales on the LayerNorm / hidden tensors."""
+    from wedetect_amd import lib as L
+    from wedetect_amd import weights as W
+    from wedetect_amd.engine import ImageTower
+    from wedetect_amd.pack import pack
+    sd = W.make_state_dict(arch, num_prompts=64)
+    packed = pack(sd, arch)
+    x = torch.from_numpy(W.make_images(b, hw, hw)).cuda()
+    monkeypatch.setenv("WEDETECT_FUSE_MLP", "0")
+    t_old = ImageTower(arch, packed, b, hw, hw, precision="fp16x3")
+    monkeypatch.setenv("WEDETECT_FUSE_MLP", "1")
+    t_new = ImageTower(arch, packed, b, hw, hw, precision="fp16x3")
+    assert not t_old.fuse_mlp and t_new.fuse_mlp
+    assert L.mlp_fused_supported(t_new.M[0], 128, 512) == (b * (hw // 4) ** 2 % 128 == 0)
+    if calibrate:
+        t_old.calibrate(x)
+        t_new.calibrate(x)
+        assert t_new.sscale == t_old.sscale and any(v != 1.0 for v in t_new.sscale.values())
+    e0, b0 = t_old.features(x)
+    s0 = t_old.similarity(t_old.P["prompts"], normalize=False).clone()
+    c0 = [c.clone() for c in t_old.x]
+    e1, b1 = t_new.features(x)
+    s1 = t_new.similarity(t_new.P["prompts"], normalize=False)
+    torch.cuda.synchronize()
+    for i, (u, v) in enumerate(zip(c0, t_new.x)):
+        assert torch.equal(u, v), f"residual stream c{i+1} differs (max |d| {float((u - v).abs().max()):.3e})"
+    assert torch.equal(e0, e1) and torch.equal(b0, b1) and torch.equal(s0, s1)
+    assert int(t_new.range_flags.sum()) == 0

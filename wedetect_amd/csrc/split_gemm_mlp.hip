@@ -1,32 +1,41 @@
 // split_gemm_mlp.hip — the ConvNeXt block's pointwise MLP as ONE kernel for the narrow stage (C = 128, hidden 512):
 //     x <- x + W2 · GELU(W1 · LN(x) + b1) + b2          (mm_backbone.py:117-124, gamma folded into W2 / b2)
 // fp16x3 arithmetic on pre-split operands, like the two-kernel form (wd_conv_gemm_split twice), but the 4C hidden
-// activation never leaves the CU.  At WeDetect-Base batch 32 the stage-1 hidden tensor is 1.68 GB per block: the
-// two-kernel form writes it (the pwconv1 launch is an epilogue: 420 M GELUs + 1.7 GB of stores, 710-740 us) and reads
-// it back (pwconv2: 2.5 GB of HBM traffic, 515 us).  Here a workgroup owns 128 rows:
-//   * the LayerNorm rows [128 x 128] (fp16 hi/lo groups, 64 KB) are DMA'd into LDS once; every wave then holds the MFMA
-//     fragments of its 64 rows in registers (128 VGPRs) for all eight chunks — GEMM 1 reads only weight fragments from LDS;
-//   * the hidden dimension is walked in chunks of 64 columns: GEMM 1 (K = 128: 8 k16 steps) -> accumulators ->
-//     bias + GELU + hi/lo split IN REGISTERS -> written straight into LDS in the operand layout of GEMM 2 (a lane holds 4
-//     channels of a pixel = half of an 8-channel hi/lo group: two ds_write_b64 per group, no transpose) -> GEMM 2
-//     (K = 64: 4 k16 steps) accumulates the [128 x 128] output tile in registers across all eight chunks;
-//   * the chunk's weights — W1 rows [64 x 128] and W2 columns [128 x 64], 32 KB each — come by LDS-DMA one chunk ahead:
-//     W2_j and W1_{j+1} are requested when GEMM 1 of chunk j has finished reading W1_j, and land under the GELU epilogue /
-//     GEMM 2; bias vectors are loaded before the requests so that no compiler-inserted wait drains the DMA queue;
-//   * LDS: 64 (rows) + 32 (W1) + 32 (hidden chunk) + 32 (W2) = 160 KB, one workgroup of four waves per CU; a wave owns
-//     64 rows x 32 hidden columns in GEMM 1 and 64 x 64 outputs in GEMM 2 (32 + 64 accumulator registers);
-//   * three barriers per chunk (W1 landed | W1 consumed, request next | hidden chunk + W2 ready).
-// Same halves, same K order per output (hidden columns ascending, 16 at a time), the same epilogue arithmetic as the
-// two kernels it replaces: BIT-IDENTICAL (tests/test_gpu_split.py::test_fused_mlp_*).
+// activation never leaves the CU — not even for LDS.  At WeDetect-Base batch 32 the stage-1 hidden tensor is 1.68 GB per
+// block: the two-kernel form writes it (pwconv1: 420 M GELUs + 1.7 GB of stores, 710-740 us) and reads it back (pwconv2:
+// 2.5 GB of HBM traffic, 490-515 us).  Here a workgroup of four waves owns 128 rows, a wave 32 of them end to end:
+//   * its LayerNorm rows [32 x 128] live in registers as MFMA fragments (64 VGPRs), loaded straight from memory;
+//   * the hidden dimension is walked in 16 chunks of 32 columns.  GEMM 1 (K = 128: 8 k16 steps, one accumulator) ->
+//     bias + GELU + hi/lo split on the accumulator where it lies -> one v_permlane32_swap per dword turns the accumulator
+//     layout (lane = pixel, 4 channels of each 8-channel group per lane half) into GEMM 2's operand layout (lane half =
+//     8 consecutive k) -> GEMM 2 (K = 32: 2 k16 steps) accumulates the wave's [32 x 128] output tile across all chunks;
+//   * the only thing the four waves share is the weight chunks: W1 rows [32 x 128] and W2 columns [128 x 32] (16 KB each),
+//     double-buffered rings filled by LDS-DMA a chunk ahead, ONE barrier per chunk; the pwconv1 bias vector sits in LDS too;
+//   * 66 KB of LDS and <= 256 VGPRs: two workgroups per CU.  The loop is software-pipelined inside the wave — an iteration
+//     carries GEMM 2 of chunk j - 1, the GELU / split of chunk j and GEMM 1 of chunk j + 1 as four regions of 12 MFMAs + one
+//     epilogue group each, interleaved one MFMA : seven VALU by sched_group_barrier.
+// Same halves, same K order per output (hidden columns ascending, 16 at a time), the same epilogue arithmetic as the two
+// kernels it replaces: BIT-IDENTICAL (tests/test_gpu_split.py::test_fused_mlp_*).
+//
+// Measured (MI355X, 819200 rows, profiles/r03_mlp_fused.txt): 750-760 us against 1190-1290 us for the two launches.  The
+// road there: one workgroup per CU with 64-row waves and the hidden chunk through LDS (three barriers per chunk): 1157 us;
+// this wave-per-32-rows form without the in-wave pipelining: 843 us; pipelined: 760 us.  What bounds it now is VALU issue,
+// not MFMA (MFMA-busy 44 %, VALU-busy 50 %, and they do not overlap: dropping the GELU arithmetic gives 471 us): ~27 VALU
+// instructions per hidden value against 3 MFMAs.  Packed fp32 instructions (half the count) bought nothing — they
+// serialise with the matrix pipe — and neither did one wave per SIMD (942 us).
 #include "split_epi_oct.h"
 
 namespace {
 
-constexpr int ML_C = 128, ML_H = 512, ML_BM = 128, ML_HC = 64;
-constexpr int ML_ASTAGE = ML_BM * 64, ML_W1STAGE = ML_HC * 64, ML_W2STAGE = ML_C * 64;
-constexpr int ML_A = 0, ML_W1 = ML_A + 8 * ML_ASTAGE, ML_HID = ML_W1 + 8 * ML_W1STAGE, ML_W2 = ML_HID + 4 * ML_ASTAGE;
-constexpr int ML_LDS = ML_W2 + 4 * ML_W2STAGE;
-static_assert(ML_LDS == 160 * 1024, "the fused MLP uses the whole LDS");
+constexpr int ML_C = 128, ML_H = 512, ML_BM = 128;
+constexpr int MB_HC = 32, MB_NCH = ML_H / MB_HC;
+constexpr int MB_W1STAGE = MB_HC * 64, MB_W2STAGE = ML_C * 64;       // a k16 step of a chunk: rows x 64 B, XOR-swizzled
+constexpr int MB_W1BUF = 8 * MB_W1STAGE, MB_W2BUF = 2 * MB_W2STAGE;  // one ring slot
+constexpr int MC_W1 = 0, MC_W2 = 2 * MB_W1BUF;
+constexpr int MC_B1 = 2 * MB_W1BUF + 2 * MB_W2BUF, MC_LDS = MC_B1 + ML_H * 4;   // + the pwconv1 bias vector
+constexpr int MC_VHEAD = 12, MC_VPM = 7;           // VALU instructions ahead of a region's first MFMA / behind each MFMA
+static_assert(4 * 32 * EPI_LDT * 4 <= MC_B1, "the epilogue patches reuse the weight rings");
+static_assert(2 * MC_LDS <= 160 * 1024, "two workgroups per CU");
 
 // one 1 KB LDS-DMA: 64 lanes x 16 B from base + voff[lane] to LDS [lds_addr, +1024)
 __device__ __forceinline__ void ml_dma(unsigned lds_addr, unsigned voff, const unsigned char* base) {
@@ -45,218 +54,84 @@ struct MlpArgs {
   float unscale1, unscale2, hid_scale;
 };
 
-__global__ void __launch_bounds__(256) fused_mlp128_kernel(const MlpArgs q) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int t = threadIdx.x, lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  int tile = blockIdx.x;
-  {
-    const int nwg = gridDim.x, xcd = tile & 7, idx = tile >> 3;
-    const int qq = nwg >> 3, r = nwg & 7;
-    tile = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + idx;
+// one group of the epilogue: 4 channels of a pixel (accumulator registers 4 g .. 4 g + 3): bias, GELU, range scale, hi/lo
+// split.  One value at a time, scalar instructions only — v_pk_{fma,mul,add}_f32 do not overlap with MFMAs at all
+// (scripts/issue_probe.py: an MFMA hides six v_fma_f32 behind it, four v_pk_fma_f32 cost their full 18 cycles on top).  No
+// range check here: a non-finite accumulator or a hidden value beyond the fp16 range becomes an inf / NaN half, then a NaN
+// output accumulator, which the final epilogue reports (GELU maps +inf to inf, -inf and NaN to NaN).
+__device__ __forceinline__ void mc_epi_group(const f32x16& hid, int g, const f32x4 bq, float unscale1, float hid_scale, u32x2& hi, u32x2& lo) {
+#pragma clang fp contract(off)
+  typedef _Float16 ph2 __attribute__((ext_vector_type(2)));
+  _Float16 h[4], l[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float o = wd_gelu(fmaf(hid[4 * g + r], unscale1, bq[r])) * hid_scale;   // scale: a power of two, 1 = none — exact either
+    asm("" : "+v"(o));                               // way, and no branch in the region; opaque to the SLP vectoriser
+    h[r] = (_Float16)o;
+    const float res = o - (float)h[r];               // the residual of the ROUNDED fp32 value, as split4 takes it
+    l[r] = (_Float16)res;
   }
-  const int m0 = tile * ML_BM;
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_raw;
-
-  // lane part of every DMA source: row (lane >> 2) of a 16-row group + the 16-byte chunk that belongs in physical slot
-  // (lane & 3) of that row (slots XOR-swizzled by (row / 4) & 3; group starts are multiples of 16, so the swizzle term
-  // only depends on the lane)
-  const int lrow = lane >> 2;
-  const int logical = (lane & 3) ^ ((lrow >> 2) & 3);
-  const int memchunk = ((logical & 1) << 1) | ((logical >> 1) & 1);
-  const unsigned va = (unsigned)lrow * 512u + memchunk * 16;          // activation rows and W1 rows: 512 B pitch
-  const unsigned vw2 = (unsigned)lrow * 2048u + memchunk * 16;        // W2 rows: 2048 B pitch
-
-  // W1 chunk j: 8 stages x 4 row groups = 32 DMAs, 8 per wave; W2 chunk j: 4 stages x 8 row groups = 32 DMAs, 8 per wave
-  auto issue_w1 = [&](int j) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int idx = wave * 8 + i, s = idx >> 2, rg = idx & 3;
-      ml_dma(lds0 + ML_W1 + s * ML_W1STAGE + rg * 1024, va, q.w1 + (size_t)(j * ML_HC + rg * 16) * 512 + s * 64);
-    }
-  };
-  auto issue_w2 = [&](int j) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int idx = wave * 8 + i, s = idx >> 3, rg = idx & 7;
-      ml_dma(lds0 + ML_W2 + s * ML_W2STAGE + rg * 1024, vw2, q.w2 + (size_t)(rg * 16) * 2048 + (size_t)(j * 4 + s) * 64);
-    }
-  };
-  // the tile's rows: 8 stages x 8 row groups = 64 DMAs, 16 per wave
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int idx = wave * 16 + i, s = idx >> 3, rg = idx & 7;
-    ml_dma(lds0 + ML_A + s * ML_ASTAGE + rg * 1024, va, q.a + (size_t)(m0 + rg * 16) * 512 + s * 64);
-  }
-  issue_w1(0);
-
-  // fragment addresses (byte offsets inside a k16 stage)
-  const int hsel = lane >> 5;
-  int aoff_h[2], aoff_l[2], w1off_h, w1off_l, w2off_h[2], w2off_l[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = wm * 64 + i * 32 + (lane & 31), f = (row >> 2) & 3;
-    aoff_h[i] = row * 64 + ((hsel ^ f) << 4);
-    aoff_l[i] = row * 64 + (((2 + hsel) ^ f) << 4);
-  }
-  {
-    const int row = wn * 32 + (lane & 31), f = (row >> 2) & 3;
-    w1off_h = row * 64 + ((hsel ^ f) << 4);
-    w1off_l = row * 64 + (((2 + hsel) ^ f) << 4);
-  }
-#pragma unroll
-  for (int jn = 0; jn < 2; ++jn) {
-    const int row = wn * 64 + jn * 32 + (lane & 31), f = (row >> 2) & 3;
-    w2off_h[jn] = row * 64 + ((hsel ^ f) << 4);
-    w2off_l[jn] = row * 64 + (((2 + hsel) ^ f) << 4);
-  }
-  // where this lane's hidden values go: row (64 wm + 32 i + lane & 31), chunk column 32 wn + 8 g + 4 (lane >> 5) + 0..3
-  // = k16 stage 2 wn + (g >> 1), 8-channel group g & 1, half (lane >> 5) of the group
-  int hid_off[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = wm * 64 + i * 32 + (lane & 31);
-    hid_off[i] = ML_HID + (2 * wn) * ML_ASTAGE + row * 64 + hsel * 8;
-  }
-  const int hid_f = ((lane & 31) >> 2) & 3;          // (row >> 2) & 3: rows are 32 i + 64 wm + (lane & 31)
-
-  f32x16 out[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int jn = 0; jn < 2; ++jn)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) out[i][jn][r] = 0.0f;
-
-  h8 afh[8][2], afl[8][2];                           // this wave's 64 rows x K = 128 as MFMA fragments, loaded once
-  for (int j = 0; j < ML_H / ML_HC; ++j) {
-    // the chunk's bias quads BEFORE any DMA of this chunk is issued, and pinned as "ready" right after the wait below: a
-    // load (or the compiler's own wait for one) placed behind the DMAs would drain the whole queue — loads retire in order
-    f32x4 bq[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const f32x4*>(q.b1 + j * ML_HC + wn * 32 + 8 * g + 4 * hsel);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // rows (first chunk) + W1_j (+ the bias loads) have landed
-#pragma unroll
-    for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(bq[g]));
-    __syncthreads();
-    if (j == 0) {
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const unsigned char* as = smem_raw + ML_A + s * ML_ASTAGE;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          afh[s][i] = *reinterpret_cast<const h8*>(as + aoff_h[i]);
-          afl[s][i] = *reinterpret_cast<const h8*>(as + aoff_l[i]);
-        }
-      }
-    }
-
-    // ---- GEMM 1: hidden chunk [64 rows of this wave x 32 columns], K = 128
-    f32x16 hid[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) hid[i][r] = 0.0f;
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const unsigned char* ws = smem_raw + ML_W1 + s * ML_W1STAGE;
-      const h8 wh = *reinterpret_cast<const h8*>(ws + w1off_h), wl = *reinterpret_cast<const h8*>(ws + w1off_l);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) hid[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, afh[s][i], hid[i], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) hid[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, afl[s][i], hid[i], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) hid[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, afh[s][i], hid[i], 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();                                 // W1_j consumed by every wave; GEMM 2 of chunk j - 1 is over too
-    __builtin_amdgcn_sched_barrier(0);
-    issue_w2(j);
-    if (j + 1 < ML_H / ML_HC) issue_w1(j + 1);
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---- epilogue 1 in registers: bias + GELU (+ range scale) + hi/lo split, straight into GEMM 2's operand layout
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 v = {hid[i][4 * g], hid[i][4 * g + 1], hid[i][4 * g + 2], hid[i][4 * g + 3]};
-        if (q.range_flag) {
-          if (wd_any_nonfinite4(v[0], v[1], v[2], v[3])) *q.range_flag = 1u;
-        }
-        f32x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = sact<WD_ACT_GELU>(fmaf(v[r], q.unscale1, bq[g][r]));
-        if (q.hid_scale != 1.0f) o = o * q.hid_scale;
-        u32x2 hi, lo;
-        split4(o, hi, lo);
-        unsigned char* dst = smem_raw + hid_off[i] + (g >> 1) * ML_ASTAGE;
-        const int sh = (g & 1) ^ hid_f, sl = (2 + (g & 1)) ^ hid_f;
-        *reinterpret_cast<u32x2*>(dst + (sh << 4)) = hi;
-        *reinterpret_cast<u32x2*>(dst + (sl << 4)) = lo;
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (j + 1 < ML_H / ML_HC) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // W2_j landed; W1_{j+1} may still fly
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                 // hidden chunk written by all four waves, W2_j complete
-
-    // ---- GEMM 2: out[64 x 64 of this wave] += hidden chunk [64 x 64] . W2_j^T
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const unsigned char* hs = smem_raw + ML_HID + s * ML_ASTAGE;
-      const unsigned char* ws = smem_raw + ML_W2 + s * ML_W2STAGE;
-      h8 xh[2], xl[2], wh[2], wl[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        xh[i] = *reinterpret_cast<const h8*>(hs + aoff_h[i]);
-        xl[i] = *reinterpret_cast<const h8*>(hs + aoff_l[i]);
-      }
-#pragma unroll
-      for (int jn = 0; jn < 2; ++jn) {
-        wh[jn] = *reinterpret_cast<const h8*>(ws + w2off_h[jn]);
-        wl[jn] = *reinterpret_cast<const h8*>(ws + w2off_l[jn]);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int jn = 0; jn < 2; ++jn) out[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[jn], xh[i], out[i][jn], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int jn = 0; jn < 2; ++jn) out[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[jn], xl[i], out[i][jn], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int jn = 0; jn < 2; ++jn) out[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[jn], xh[i], out[i][jn], 0, 0, 0);
-    }
-  }
-  __syncthreads();                                   // every wave is done with the LDS operands: the patches may reuse them
-
-  // ---- epilogue 2: + b2 + residual, fp32 rows in place (the row / 8-channel epilogue of the pre-split kernels)
-  WdConvGemm pe{};
-  pe.bias = q.b2; pe.res = q.x; pe.c = q.x; pe.m = q.m; pe.n = ML_C; pe.ldc = ML_C; pe.ldres = ML_C;
-  pe.act = WD_ACT_NONE; pe.out_mode = WD_OUT_ROWS; pe.res_alpha = 1.0f; pe.out_scale = 1.0f; pe.range_flag = q.range_flag;
-  float* patch = reinterpret_cast<float*>(smem_raw) + wave * 32 * EPI_LDT;
-  EpiOctWalk<0, 2, 2, WD_ACT_NONE, false, false>::run(pe, q.unscale2, m0 + wm * 64, wn * 64, lane, out, patch);
+  hi = u32x2{__builtin_bit_cast(unsigned, ph2{h[0], h[1]}), __builtin_bit_cast(unsigned, ph2{h[2], h[3]})};
+  lo = u32x2{__builtin_bit_cast(unsigned, ph2{l[0], l[1]}), __builtin_bit_cast(unsigned, ph2{l[2], l[3]})};
 }
+// Groups 2 s and 2 s + 1 -> the operand fragments of k16 step s, without touching LDS.  The accumulator gives a lane
+// (pixel p, half h) channels 8 g + 4 h + 0..3; the operand of k16 step s wants k = 16 s + 8 h + 0..7: lane (p, 0) keeps its
+// group 2 s and takes lane (p, 1)'s group 2 s; lane (p, 1) takes lane (p, 0)'s group 2 s + 1 and keeps its own —
+// v_permlane32_swap(X = group 2 s, Y = group 2 s + 1) swaps X's upper 32 lanes with Y's lower 32: fragment = [X' | Y'].
+__device__ __forceinline__ void mc_epi_swap(const u32x2 (&hi)[4], const u32x2 (&lo)[4], int s, h8& fh8, h8& fl8) {
+  u32x4 fh, fl;
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const auto a = __builtin_amdgcn_permlane32_swap(hi[2 * s][d], hi[2 * s + 1][d], false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(lo[2 * s][d], lo[2 * s + 1][d], false, false);
+    fh[d] = a[0]; fh[2 + d] = a[1];
+    fl[d] = b[0]; fl[2 + d] = b[1];
+  }
+  fh8 = __builtin_bit_cast(h8, fh);
+  fl8 = __builtin_bit_cast(h8, fl);
+}
+// one k16 step of GEMM 2 (12 MFMAs) / four k16 steps of GEMM 1 (12 MFMAs)
+__device__ __forceinline__ void mc_gemm2_step(const unsigned char* w2s, int off_h, int off_l, const h8 xh, const h8 xl, f32x16 (&out)[1][4]) {
+  h8 wh[4], wl[4];
+#pragma unroll
+  for (int jn = 0; jn < 4; ++jn) {
+    wl[jn] = *reinterpret_cast<const h8*>(w2s + jn * 2048 + off_l);
+    wh[jn] = *reinterpret_cast<const h8*>(w2s + jn * 2048 + off_h);
+  }
+#pragma unroll
+  for (int jn = 0; jn < 4; ++jn) out[0][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[jn], xh, out[0][jn], 0, 0, 0);
+#pragma unroll
+  for (int jn = 0; jn < 4; ++jn) out[0][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[jn], xl, out[0][jn], 0, 0, 0);
+#pragma unroll
+  for (int jn = 0; jn < 4; ++jn) out[0][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[jn], xh, out[0][jn], 0, 0, 0);
+}
+template <int S0>
+__device__ __forceinline__ void mc_gemm1_steps(const unsigned char* w1b, int off_h, int off_l, const h8 (&afh)[8], const h8 (&afl)[8], f32x16& hid) {
+  h8 wh[4], wl[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    wl[s] = *reinterpret_cast<const h8*>(w1b + (S0 + s) * MB_W1STAGE + off_l);
+    wh[s] = *reinterpret_cast<const h8*>(w1b + (S0 + s) * MB_W1STAGE + off_h);
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    hid = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[s], afh[S0 + s], hid, 0, 0, 0);
+    hid = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[s], afl[S0 + s], hid, 0, 0, 0);
+    hid = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[s], afh[S0 + s], hid, 0, 0, 0);
+  }
+}
+// the order inside a region of 12 MFMAs + one epilogue group: LDS reads, a head of VALU while they fly, then every MFMA
+// followed by its share of the VALU
+#define MC_REGION(NDS)                                             \
+  __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0);             \
+  __builtin_amdgcn_sched_group_barrier(0x002, MC_VHEAD, 0);        \
+  _Pragma("unroll") for (int i_ = 0; i_ < 12; ++i_) {              \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             \
+    __builtin_amdgcn_sched_group_barrier(0x002, MC_VPM, 0);        \
+  }                                                                \
+  __builtin_amdgcn_sched_barrier(0);
 
-// ---------------------------------------------------------------------------------------
-// Variant B: two workgroups per CU.  A wave owns 32 rows end to end (its LayerNorm fragments in registers, its hidden chunk
-// in a private 4 KB LDS patch, a [32 x 128] output tile), so the only thing the four waves share is the weight chunks —
-// hidden chunks of 32 columns, W1 [32 x 128] and W2 [128 x 32] (16 KB each) double-buffered, ONE barrier per chunk.
-// 80 KB of LDS: with two workgroups (eight waves) on a CU the GELU epilogue (VALU) of one wave runs under the MFMAs of
-// another — the one-workgroup form above serialises them (a wave per SIMD, three barriers per chunk).
-// ---------------------------------------------------------------------------------------
-constexpr int MB_HC = 32, MB_NCH = ML_H / MB_HC;
-constexpr int MB_W1STAGE = MB_HC * 64, MB_W2STAGE = ML_C * 64, MB_HSTAGE = 32 * 64;
-constexpr int MB_W1 = 0, MB_W1BUF = 8 * MB_W1STAGE, MB_W2 = MB_W1 + 2 * MB_W1BUF, MB_W2BUF = 2 * MB_W2STAGE;
-constexpr int MB_HID = MB_W2 + 2 * MB_W2BUF, MB_HIDW = 2 * MB_HSTAGE, MB_LDS = MB_HID + 4 * MB_HIDW;
-static_assert(MB_LDS == 80 * 1024, "two workgroups per CU");
-static_assert(4 * 32 * EPI_LDT * 4 <= MB_HID, "the epilogue patches reuse the weight buffers");
-
-__global__ void __launch_bounds__(256, 2) fused_mlp128_rows_kernel(const MlpArgs q) {
+__global__ void __launch_bounds__(256, 2) fused_mlp128_kernel(const MlpArgs q) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -266,7 +141,7 @@ __global__ void __launch_bounds__(256, 2) fused_mlp128_rows_kernel(const MlpArgs
     const int qq = nwg >> 3, r = nwg & 7;
     tile = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + idx;
   }
-  const int m0 = tile * ML_BM + wave * 32;           // this wave's rows
+  const int m0 = tile * ML_BM + wave * 32;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_raw;
 
   const int lrow = lane >> 2;
@@ -274,28 +149,27 @@ __global__ void __launch_bounds__(256, 2) fused_mlp128_rows_kernel(const MlpArgs
   const int memchunk = ((logical & 1) << 1) | ((logical >> 1) & 1);
   const unsigned va = (unsigned)lrow * 512u + memchunk * 16;
   const unsigned vw2 = (unsigned)lrow * 2048u + memchunk * 16;
-  // chunk j -> buffer j & 1: W1 rows [32 j, +32) as 8 stages x 2 row groups, W2 columns [32 j, +32) as 2 stages x 8 row
-  // groups: 32 DMAs of 1 KB, 8 per wave
-  auto issue = [&](int j) {
-    const int b = j & 1;
+  auto issue_w1 = [&](int j) {                       // W1 rows [32 j, +32) -> ring slot j & 1: 16 DMAs, 4 per wave
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = wave * 4 + i, s = idx >> 1, rg = idx & 1;
-      ml_dma(lds0 + MB_W1 + b * MB_W1BUF + s * MB_W1STAGE + rg * 1024, va, q.w1 + (size_t)(j * MB_HC + rg * 16) * 512 + s * 64);
+      ml_dma(lds0 + MC_W1 + (j & 1) * MB_W1BUF + s * MB_W1STAGE + rg * 1024, va, q.w1 + (size_t)(j * MB_HC + rg * 16) * 512 + s * 64);
     }
+  };
+  auto issue_w2 = [&](int j) {                       // W2 columns [32 j, +32) -> ring slot j & 1
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = wave * 4 + i, s = idx >> 3, rg = idx & 7;
-      ml_dma(lds0 + MB_W2 + b * MB_W2BUF + s * MB_W2STAGE + rg * 1024, vw2, q.w2 + (size_t)(rg * 16) * 2048 + (size_t)(j * 2 + s) * 64);
+      ml_dma(lds0 + MC_W2 + (j & 1) * MB_W2BUF + s * MB_W2STAGE + rg * 1024, vw2, q.w2 + (size_t)(rg * 16) * 2048 + (size_t)(j * 2 + s) * 64);
     }
   };
-  issue(0);
+  issue_w1(0);
+  issue_w1(1);
+  if (t < ML_H / 4) *reinterpret_cast<f32x4*>(smem_raw + MC_B1 + t * 16) = *reinterpret_cast<const f32x4*>(q.b1 + t * 4);
 
   const int hsel = lane >> 5, prow = lane & 31, f = (prow >> 2) & 3;
-  // the wave's 32 LayerNorm rows as MFMA fragments, straight from memory: 8 k16 steps x (hi, lo) x 16 B per lane
   h8 afh[8], afl[8];
   {
-    // memory: per k16 step [hi k0-7 | lo k0-7 | hi k8-15 | lo k8-15], 16 B each; lane half (lane >> 5) holds k 8 (lane >> 5) ..
     const unsigned char* ar = q.a + (size_t)(m0 + prow) * 512 + hsel * 32;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
@@ -303,96 +177,92 @@ __global__ void __launch_bounds__(256, 2) fused_mlp128_rows_kernel(const MlpArgs
       afl[s] = *reinterpret_cast<const h8*>(ar + s * 64 + 16);
     }
   }
-  const int off_h = prow * 64 + ((hsel ^ f) << 4), off_l = prow * 64 + (((2 + hsel) ^ f) << 4);   // fragment of row (lane & 31)
-  unsigned char* hidw = smem_raw + MB_HID + wave * MB_HIDW;
-  const int hid_off = prow * 64 + hsel * 8;
+  const int off_h = prow * 64 + ((hsel ^ f) << 4), off_l = prow * 64 + (((2 + hsel) ^ f) << 4);
+  const unsigned char* bl = smem_raw + MC_B1 + hsel * 16;           // bias quads of chunk j: bl + 128 j + 32 g
 
   f32x16 out[1][4];
 #pragma unroll
   for (int jn = 0; jn < 4; ++jn)
 #pragma unroll
     for (int r = 0; r < 16; ++r) out[0][jn][r] = 0.0f;
+  f32x16 hid, hidn;
+  h8 xh[2], xl[2];                                   // the hidden chunk GEMM 2 consumes next, as operand fragments
+  u32x2 hi[4], lo[4];
+  f32x4 bq[4];
 
-  // bias quads of the NEXT chunk are requested a chunk ahead, behind that chunk's DMAs: loads retire in order, so the wait
-  // at the top of a chunk (everything requested during the previous one) covers them and nothing else ever waits on memory
-  f32x4 bqn[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) bqn[g] = *reinterpret_cast<const f32x4*>(q.b1 + 8 * g + 4 * hsel);
-  bool bad = false;
+#define MC_TOP()                                   \
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+  __syncthreads();
+#define MC_BIAS(J)                                 \
+  _Pragma("unroll") for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const f32x4*>(bl + (J) * 128 + g * 32);
+#define MC_ZERO(H)                                 \
+  _Pragma("unroll") for (int r = 0; r < 16; ++r) H[r] = 0.0f;
 
-  for (int j = 0; j < MB_NCH; ++j) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    f32x4 bq[4];
+  // prologue: GEMM 1 of chunk 0, then iteration 0 without a GEMM 2
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      bq[g] = bqn[g];
-      asm volatile("" : "+v"(bq[g]));
-    }
-    if (j == 0) {
+  for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(afh[s]), "+v"(afl[s]));
+  __syncthreads();
+  MC_ZERO(hid);
+  mc_gemm1_steps<0>(smem_raw + MC_W1, off_h, off_l, afh, afl, hid);
+  mc_gemm1_steps<4>(smem_raw + MC_W1, off_h, off_l, afh, afl, hid);
+  MC_TOP();                                          // every wave has left GEMM 1 of chunk 0
+  issue_w1(2);
+  issue_w2(0);
+  MC_BIAS(0);
+  MC_ZERO(hidn);
 #pragma unroll
-      for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(afh[s]), "+v"(afl[s]));
-    }
-    __syncthreads();                                 // chunk j's weights are complete; every wave has left chunk j - 1
-    if (j + 1 < MB_NCH) {
-      issue(j + 1);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) bqn[g] = *reinterpret_cast<const f32x4*>(q.b1 + (j + 1) * MB_HC + 8 * g + 4 * hsel);
-    }
-    const unsigned char* w1b = smem_raw + MB_W1 + (j & 1) * MB_W1BUF;
-    const unsigned char* w2b = smem_raw + MB_W2 + (j & 1) * MB_W2BUF;
+  for (int g = 0; g < 4; ++g) mc_epi_group(hid, g, bq[g], q.unscale1, q.hid_scale, hi[g], lo[g]);
+  mc_epi_swap(hi, lo, 0, xh[0], xl[0]);
+  mc_epi_swap(hi, lo, 1, xh[1], xl[1]);
+  mc_gemm1_steps<0>(smem_raw + MC_W1 + MB_W1BUF, off_h, off_l, afh, afl, hidn);
+  mc_gemm1_steps<4>(smem_raw + MC_W1 + MB_W1BUF, off_h, off_l, afh, afl, hidn);
+  hid = hidn;
 
-    // ---- GEMM 1: [32 rows x 32 hidden columns], K = 128
-    f32x16 hid;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) hid[r] = 0.0f;
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const h8 wh = *reinterpret_cast<const h8*>(w1b + s * MB_W1STAGE + off_h), wl = *reinterpret_cast<const h8*>(w1b + s * MB_W1STAGE + off_l);
-      hid = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, afh[s], hid, 0, 0, 0);
-      hid = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, afl[s], hid, 0, 0, 0);
-      hid = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, afh[s], hid, 0, 0, 0);
-    }
-
-    // ---- epilogue 1: bias + GELU (+ range scale) + hi/lo split into the wave's own patch, GEMM 2's operand layout
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 v = {hid[4 * g], hid[4 * g + 1], hid[4 * g + 2], hid[4 * g + 3]};
-      bad |= wd_any_nonfinite4(v[0], v[1], v[2], v[3]);
-      f32x4 o;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = sact<WD_ACT_GELU>(fmaf(v[r], q.unscale1, bq[g][r]));
-      if (q.hid_scale != 1.0f) o = o * q.hid_scale;
-      u32x2 hi, lo;
-      split4(o, hi, lo);
-      unsigned char* dst = hidw + (g >> 1) * MB_HSTAGE + hid_off;
-      *reinterpret_cast<u32x2*>(dst + (((g & 1) ^ f) << 4)) = hi;
-      *reinterpret_cast<u32x2*>(dst + (((2 + (g & 1)) ^ f) << 4)) = lo;
-    }
-    // the patch is written and read by this wave only: LDS operations of a wave execute in order
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-    // ---- GEMM 2: out[32 x 128] += hidden chunk [32 x 32] . W2_j^T
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const h8 xh = *reinterpret_cast<const h8*>(hidw + s * MB_HSTAGE + off_h), xl = *reinterpret_cast<const h8*>(hidw + s * MB_HSTAGE + off_l);
-      h8 wh[4], wl[4];
-#pragma unroll
-      for (int jn = 0; jn < 4; ++jn) {
-        wh[jn] = *reinterpret_cast<const h8*>(w2b + s * MB_W2STAGE + jn * 2048 + off_h);
-        wl[jn] = *reinterpret_cast<const h8*>(w2b + s * MB_W2STAGE + jn * 2048 + off_l);
-      }
-#pragma unroll
-      for (int jn = 0; jn < 4; ++jn) out[0][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[jn], xh, out[0][jn], 0, 0, 0);
-#pragma unroll
-      for (int jn = 0; jn < 4; ++jn) out[0][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[jn], xl, out[0][jn], 0, 0, 0);
-#pragma unroll
-      for (int jn = 0; jn < 4; ++jn) out[0][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[jn], xh, out[0][jn], 0, 0, 0);
-    }
+  for (int j = 1; j < MB_NCH - 1; ++j) {
+    MC_TOP();                                        // W1_{j+1} and W2_{j-1} are complete; ring slots j & 1 are free
+    if (j + 2 < MB_NCH) issue_w1(j + 2);
+    issue_w2(j);
+    const unsigned char* w2b = smem_raw + MC_W2 + ((j - 1) & 1) * MB_W2BUF;
+    const unsigned char* w1b = smem_raw + MC_W1 + ((j + 1) & 1) * MB_W1BUF;
+    __builtin_amdgcn_sched_barrier(0);
+    // four regions of 12 MFMAs, each carrying one group of chunk j's GELU / split: GEMM 2 of chunk j - 1 (two k16 steps),
+    // then GEMM 1 of chunk j + 1 (two halves)
+    MC_BIAS(j);
+    mc_gemm2_step(w2b, off_h, off_l, xh[0], xl[0], out);
+    mc_epi_group(hid, 0, bq[0], q.unscale1, q.hid_scale, hi[0], lo[0]);
+    MC_REGION(12)
+    mc_gemm2_step(w2b + MB_W2STAGE, off_h, off_l, xh[1], xl[1], out);
+    mc_epi_group(hid, 1, bq[1], q.unscale1, q.hid_scale, hi[1], lo[1]);
+    mc_epi_swap(hi, lo, 0, xh[0], xl[0]);
+    MC_REGION(8)
+    MC_ZERO(hidn);
+    mc_gemm1_steps<0>(w1b, off_h, off_l, afh, afl, hidn);
+    mc_epi_group(hid, 2, bq[2], q.unscale1, q.hid_scale, hi[2], lo[2]);
+    MC_REGION(8)
+    mc_gemm1_steps<4>(w1b, off_h, off_l, afh, afl, hidn);
+    mc_epi_group(hid, 3, bq[3], q.unscale1, q.hid_scale, hi[3], lo[3]);
+    mc_epi_swap(hi, lo, 1, xh[1], xl[1]);
+    MC_REGION(8)
+    hid = hidn;
   }
-  if (q.range_flag && bad) *q.range_flag = 1u;
-  __syncthreads();                                   // the weight buffers are free: the epilogue patches reuse them
+  // last chunk: no GEMM 1 left
+  MC_TOP();
+  issue_w2(MB_NCH - 1);
+  MC_BIAS(MB_NCH - 1);
+  mc_gemm2_step(smem_raw + MC_W2 + ((MB_NCH - 2) & 1) * MB_W2BUF, off_h, off_l, xh[0], xl[0], out);
+  mc_gemm2_step(smem_raw + MC_W2 + ((MB_NCH - 2) & 1) * MB_W2BUF + MB_W2STAGE, off_h, off_l, xh[1], xl[1], out);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) mc_epi_group(hid, g, bq[g], q.unscale1, q.hid_scale, hi[g], lo[g]);
+  mc_epi_swap(hi, lo, 0, xh[0], xl[0]);
+  mc_epi_swap(hi, lo, 1, xh[1], xl[1]);
+  MC_TOP();
+  mc_gemm2_step(smem_raw + MC_W2 + ((MB_NCH - 1) & 1) * MB_W2BUF, off_h, off_l, xh[0], xl[0], out);
+  mc_gemm2_step(smem_raw + MC_W2 + ((MB_NCH - 1) & 1) * MB_W2BUF + MB_W2STAGE, off_h, off_l, xh[1], xl[1], out);
+#undef MC_TOP
+#undef MC_BIAS
+#undef MC_ZERO
+  __syncthreads();                                   // the weight rings are free: the epilogue patches reuse them
 
   WdConvGemm pe{};
   pe.bias = q.b2; pe.res = q.x; pe.c = q.x; pe.m = q.m; pe.n = ML_C; pe.ldc = ML_C; pe.ldres = ML_C;
@@ -401,11 +271,7 @@ __global__ void __launch_bounds__(256, 2) fused_mlp128_rows_kernel(const MlpArgs
   EpiOctWalk<0, 1, 4, WD_ACT_NONE, false, false>::run(pe, q.unscale2, m0, 0, lane, out, patch);
 }
 
-int g_mlp_variant = 1;
-
 }  // namespace
-
-extern "C" void wd_debug_mlp_variant(int v) { g_mlp_variant = v; }
 
 extern "C" int wd_mlp_fused_split(const void* a_split, int64_t rows, int32_t c, int32_t hidden, const void* w1_split,
                                   float w1_unscale, const float* b1, const void* w2_split, float w2_unscale, const float* b2,
@@ -417,14 +283,10 @@ extern "C" int wd_mlp_fused_split(const void* a_split, int64_t rows, int32_t c, 
       !wd_aligned16(x))
     return WD_ERR_BAD_ARG;
   if (!(w1_unscale > 0.f) || !(w2_unscale > 0.f) || !(hid_scale > 0.f)) return WD_ERR_BAD_ARG;
-  static WdAttrOnce attr, attr_b;
-  if (wd_set_max_lds(attr, reinterpret_cast<const void*>(fused_mlp128_kernel), ML_LDS) != WD_OK) return WD_ERR_LAUNCH;
-  if (wd_set_max_lds(attr_b, reinterpret_cast<const void*>(fused_mlp128_rows_kernel), MB_LDS) != WD_OK) return WD_ERR_LAUNCH;
+  static WdAttrOnce attr;
+  if (wd_set_max_lds(attr, reinterpret_cast<const void*>(fused_mlp128_kernel), MC_LDS) != WD_OK) return WD_ERR_LAUNCH;
   MlpArgs q{static_cast<const unsigned char*>(a_split), static_cast<const unsigned char*>(w1_split),
             static_cast<const unsigned char*>(w2_split), b1, b2, x, range_flag, (int)rows, w1_unscale, w2_unscale, hid_scale};
-  if (g_mlp_variant == 1)
-    WD_LAUNCH_GEMM(fused_mlp128_rows_kernel, dim3((unsigned)(rows / ML_BM)), dim3(256), MB_LDS, static_cast<hipStream_t>(stream), q);
-  else
-    WD_LAUNCH_GEMM(fused_mlp128_kernel, dim3((unsigned)(rows / ML_BM)), dim3(256), ML_LDS, static_cast<hipStream_t>(stream), q);
+  WD_LAUNCH_GEMM(fused_mlp128_kernel, dim3((unsigned)(rows / ML_BM)), dim3(256), MC_LDS, static_cast<hipStream_t>(stream), q);
   return wd_launch_status();
 }
