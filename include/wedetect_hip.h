@@ -337,6 +337,14 @@ const char* wd_conv_gemm_config(int32_t m, int32_t n, int32_t k);
  * ---------------------------------------------------------------------------------- */
 int wd_stem_patchify(const uint8_t* img, float* out, int32_t batch, int32_t h, int32_t w, void* stream);
 
+/* The whole stem in one kernel: uint8 RGB NHWC image -> x / 255 -> Conv2d(3, c0, 4, stride 4) + bias -> LayerNorm over
+ * channels (eps) -> fp32 rows [batch * h/4 * w/4, c0]   (mm_backbone.py:185-190; LayerNorm channels_first :25-47).
+ * wgt: [c0, 48] in (kh, kw, cin) column order (the packed stem weight), bias / gamma / beta: [c0]; c0 in {64, 96, 128, 192}
+ * (others: WD_ERR_UNSUPPORTED); h % 4 == 0, w % 4 == 0.  The image is read once and the rows are written once; results are
+ * BIT-IDENTICAL to wd_stem_patchify -> wd_conv_gemm (fp32) -> wd_layernorm_rows. */
+int wd_stem_fused(const uint8_t* img, int32_t batch, int32_t h, int32_t w, const float* wgt, const float* bias,
+                  const float* gamma, const float* beta, int32_t c0, float eps, float* out, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * wd_dwconv7 — depthwise 7x7, pad 3, + bias, NHWC.  w7 is [49][c] (tap-major).
  * Replaces nn.Conv2d(dim, dim, 7, padding=3, groups=dim)  mm_backbone.py:96-98, 114.

@@ -143,6 +143,43 @@ def test_stem_patchify(L):
     assert torch.equal(out.cpu(), ref), "patchify must be bit-exact (uint8 -> float, one division)"
 
 
+@pytest.mark.parametrize("c0,b,h,w", [(128, 2, 64, 48), (96, 1, 36, 44), (192, 3, 20, 28), (64, 1, 8, 12), (128, 32, 160, 160),
+                                      (128, 5, 640, 644)])
+def test_stem_fused_bit_identical_to_the_three_kernels(L, c0, b, h, w):
+    """wd_stem_fused (patchify + 4 x 4 stride-4 conv + bias + LayerNorm in one kernel, the weight matrix in registers as
+    MFMA fragments) against wd_stem_patchify -> wd_conv_gemm (fp32 kernel) -> wd_layernorm_rows: the same K order per
+    accumulator, the same reduction trees, the same bits.  Widths 64 / 96 / 128 / 192 (LayerNorm groups of 16, 32, 32, 64
+    lanes), pixel counts that are not a multiple of 16, map widths that are not, rows >= 65536 (the four-rows-per-group
+    LayerNorm) and fewer; and against float64 math."""
+    rng = np.random.default_rng(31)
+    img = torch.from_numpy(rng.integers(0, 256, size=(b, h, w, 3), dtype=np.uint8)).cuda()
+    wt, bias = dev(rnd(32, c0, 48, scale=0.3)), dev(rnd(33, c0, scale=0.1))
+    g, bt = dev(rnd(34, c0) * 0.2 + 1.0), dev(rnd(35, c0) * 0.1)
+    m = b * (h // 4) * (w // 4)
+    patches = torch.empty(m, 48, device="cuda")
+    want = torch.empty(m, c0, device="cuda")
+    L.stem_patchify(img, patches)
+    L.conv_gemm(patches, wt, bias, want, batch=b, hin=h // 4, win=w // 4, cin=48, lda=48, n=c0, ldc=c0)
+    L.layernorm_rows(want, want, g, bt, m, c0)
+    got = torch.full((m, c0), float("nan"), device="cuda")
+    L.stem_fused(img, wt, bias, g, bt, got)
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int32), want.view(torch.int32)), f"max|d| {float((got - want).abs().max())}"
+    if m <= 4096:
+        x = (img.double() / 255.0).view(b, h // 4, 4, w // 4, 4, 3).permute(0, 1, 3, 2, 4, 5).reshape(m, 48)
+        ref = F.layer_norm(x @ wt.double().T + bias.double(), (c0,), g.double(), bt.double(), 1e-6)
+        assert_close(f"stem c0={c0}", got, ref.cpu().numpy(), 2e-5, 2e-5)
+
+
+def test_stem_fused_rejects_bad_arguments(L):
+    img = torch.zeros(1, 8, 8, 3, dtype=torch.uint8, device="cuda")
+    z = lambda *s_: torch.zeros(*s_, device="cuda")
+    with pytest.raises(L.WedetectHipError):
+        L.stem_fused(img, z(80, 48), z(80), z(80), z(80), z(4, 80))              # width without an instantiation
+    with pytest.raises(L.WedetectHipError):
+        L.stem_fused(torch.zeros(1, 8, 6, 3, dtype=torch.uint8, device="cuda"), z(128, 48), z(128), z(128), z(128), z(2, 128))
+
+
 @pytest.mark.parametrize("c,h,w", [(32, 16, 16), (96, 9, 11), (128, 20, 20), (192, 5, 3), (512, 8, 8), (1536, 2, 2), (64, 64, 48), (32, 80, 37),
                                    (128, 160, 160)])
 def test_dwconv7(L, c, h, w):

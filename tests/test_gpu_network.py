@@ -350,3 +350,30 @@ def test_fused_block_mlp_is_bit_identical_to_the_two_launch_path(arch, b, hw, ca
         assert torch.equal(u, v), f"residual stream c{i+1} differs (max |d| {float((u - v).abs().max()):.3e})"
     assert torch.equal(e0, e1) and torch.equal(b0, b1) and torch.equal(s0, s1)
     assert int(t_new.range_flags.sum()) == 0
+
+
+@pytest.mark.parametrize("arch,b,hw", [("base", 2, 128), ("tiny", 3, 96), ("large", 1, 64)])
+def test_fused_stem_matches_the_three_launch_path(arch, b, hw, monkeypatch, precision):
+    """Round 3: patchify + stem conv + LayerNorm as one kernel (stem.hip; $WEDETECT_FUSE_STEM=0 restores the three launches).
+    The kernel computes in fp32 (v_mfma_f32_16x16x4_f32): with precision="fp32" the first residual stream — hence
+    everything after it — must not change by a bit; the fp16x3 tower ran its stem GEMM on the fp16x3 kernel, which carries
+    fp32 values to 2^-22, so there the two towers agree to fp32 rounding noise.  96 / 128 / 192-wide stems."""
+    from wedetect_amd import weights as W
+    from wedetect_amd.engine import ImageTower
+    from wedetect_amd.pack import pack
+    sd = W.make_state_dict(arch, num_prompts=64)
+    packed = pack(sd, arch)
+    x = torch.from_numpy(W.make_images(b, hw, hw)).cuda()
+    monkeypatch.setenv("WEDETECT_FUSE_STEM", "0")
+    t_old = ImageTower(arch, packed, b, hw, hw, precision=precision)
+    monkeypatch.setenv("WEDETECT_FUSE_STEM", "1")
+    t_new = ImageTower(arch, packed, b, hw, hw, precision=precision)
+    assert not t_old.fuse_stem and t_new.fuse_stem
+    e0, b0 = t_old.features(x)
+    c0 = t_old.x[0].clone()
+    e1, b1 = t_new.features(x)
+    torch.cuda.synchronize()
+    if precision == "fp32":
+        assert torch.equal(c0, t_new.x[0]) and torch.equal(e0, e1) and torch.equal(b0, b1)
+    else:
+        assert float((e0 - e1).abs().max()) < 2e-5 and float((b0 - b1).abs().max()) < 2e-4

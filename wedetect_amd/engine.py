@@ -76,6 +76,7 @@ class ImageTower:
         if precision == "fp16x3" and self.p8_mode == "persist" and L.p8_workspace_bytes() > 0:
             self.park = torch.zeros(L.p8_workspace_bytes() // 4, dtype=torch.float32, device=torch.device(device))
         self.B, self.H, self.W = batch, height, width
+        self.fuse_stem = os.environ.get("WEDETECT_FUSE_STEM", "1") == "1"      # stem as one fp32 kernel (bit-identical to the fp32 three-launch form)
         self.fuse_mlp = os.environ.get("WEDETECT_FUSE_MLP", "1") == "1"        # stage-1 block MLP as one kernel (bit-identical; profiles/r03_mlp_fused.txt)
         self.fuse_dwln = os.environ.get("WEDETECT_FUSE_DWLN", "0") == "1"      # measured slower at every stage (profiles/r02_dwln_ab.txt): opt-in
         self.overflowed = False
@@ -291,11 +292,15 @@ class ImageTower:
             raise L.WedetectHipError(f"images must be uint8 [{B},{self.H},{self.W},3] (RGB, NHWC)")
         if not images_u8.is_contiguous():
             images_u8 = images_u8.contiguous()
-        L.stem_patchify(images_u8, self.patches)
-        h0, w0 = self.hw[0]
-        self._conv(self.patches, "stem.w", "stem.b", self.x[0], hin=h0, win=w0, cin=48, lda=48, n=a.dims[0],
-                   ldc=a.dims[0])
-        L.layernorm_rows(self.x[0], self.x[0], self.P["stem.ln_w"], self.P["stem.ln_b"], self.M[0], a.dims[0])
+        if self.fuse_stem and a.dims[0] in L.STEM_FUSED_WIDTHS:
+            # patchify + conv + LayerNorm in one fp32 kernel: the image is read once, the rows written once
+            L.stem_fused(images_u8, self.P["stem.w"], self.P["stem.b"], self.P["stem.ln_w"], self.P["stem.ln_b"], self.x[0])
+        else:
+            L.stem_patchify(images_u8, self.patches)
+            h0, w0 = self.hw[0]
+            self._conv(self.patches, "stem.w", "stem.b", self.x[0], hin=h0, win=w0, cin=48, lda=48, n=a.dims[0],
+                       ldc=a.dims[0])
+            L.layernorm_rows(self.x[0], self.x[0], self.P["stem.ln_w"], self.P["stem.ln_b"], self.M[0], a.dims[0])
         for i in range(4):
             c = a.dims[i]
             h, w = self.hw[i]

@@ -31,7 +31,7 @@ EXPORTS = (
     "wd_topk_candidates", "wd_nms_workspace_bytes", "wd_nms_gather", "wd_retrieval_max",
     "wd_split_weights_bytes", "wd_split_weights", "wd_conv_gemm_split", "wd_conv_gemm_split_ws", "wd_conv_gemm_split_config", "wd_layernorm_rows_split", "wd_layernorm_rows_split_s2d", "wd_letterbox_u8", "wd_retrieval_max_split", "wd_text_embed", "wd_attention_small", "wd_recall_scratch_floats", "wd_recall_match",
     "wd_max_sigmoid_attn", "wd_adaptive_maxpool_nhwc", "wd_cross_attention_small", "wd_time_next_gemm",
-    "wd_cv_resize_paste_u8", "wd_chw_to_hwc_u8", "wd_p8_workspace_bytes", "wd_dwconv7_ln", "wd_probe_lds_dma", "wd_probe_issue", "wd_mlp_fused_split",
+    "wd_cv_resize_paste_u8", "wd_chw_to_hwc_u8", "wd_p8_workspace_bytes", "wd_dwconv7_ln", "wd_probe_lds_dma", "wd_probe_issue", "wd_mlp_fused_split", "wd_stem_fused",
 )
 
 
@@ -117,6 +117,7 @@ def _load():
     lib.wd_chw_to_hwc_u8.argtypes = [vp, i32, vp, i32, i32, i32, vp]
     lib.wd_dwconv7_ln.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]
     lib.wd_mlp_fused_split.argtypes = [vp, i64, i32, i32, vp, f32, vp, vp, f32, vp, vp, f32, vp, vp]
+    lib.wd_stem_fused.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, i32, f32, vp, vp]
     lib.wd_probe_issue.argtypes = [i32, i32, i32, i32, i32, vp, vp, vp]
     lib.wd_probe_lds_dma.argtypes = [vp, i64, i32, i32, i32, i32, vp, vp]
     lib.wd_p8_workspace_bytes.restype = i64
@@ -236,6 +237,16 @@ def gemm_config(m: int, n: int, k: int, split: bool = False, conv: bool = False,
 def stem_patchify(img_u8: torch.Tensor, out: torch.Tensor) -> None:
     b, h, w, _ = img_u8.shape
     check(LIB.wd_stem_patchify(_p(img_u8), _p(out), b, h, w, stream_ptr()), "wd_stem_patchify")
+
+
+STEM_FUSED_WIDTHS = (64, 96, 128, 192)
+
+
+def stem_fused(img_u8: torch.Tensor, wgt, bias, gamma, beta, out, eps=1e-6) -> None:
+    """uint8 NHWC image -> / 255 -> 4 x 4 stride-4 conv + bias -> LayerNorm -> fp32 rows, one kernel (wd_stem_fused)."""
+    b, h, w, _ = img_u8.shape
+    check(LIB.wd_stem_fused(_p(img_u8), b, h, w, _p(wgt), _p(bias), _p(gamma), _p(beta), wgt.shape[0], eps, _p(out),
+                            stream_ptr()), "wd_stem_fused")
 
 
 def dwconv7(x, w7, bias, y, batch, h, w, c) -> None:
