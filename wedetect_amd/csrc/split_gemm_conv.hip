@@ -253,10 +253,12 @@ split_conv_pp_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, 
     pr.c = ws + (size_t)ks * p.m * p.n; pr.ldc = p.n;
     pr.out_mode = WD_OUT_ROWS; pr.c_batch_stride = 0; pr.seg_rows = 0; pr.sigmoid = 0; pr.out_scale = 1.0f; pr.out_bias = 0.0f;
     pr.act = WD_ACT_NONE;
-    EpiOctWalk<0, TM, TN, WD_ACT_NONE, false, false>::run(pr, 1.0f, mw, nw, lane, acc, patch);
+    EpiOctOperands<TM, TN, false> ops;               // no bias, no residual: nothing to load
+    ops.load(pr, mw, nw, lane);
+    EpiOctWalk<0, TM, TN, WD_ACT_NONE, false, false, false>::run(pr, 1.0f, mw, nw, lane, acc, patch, ops);
     return;
   }
-  epi_oct_all<TM, TN, CSPLIT>(p, unscale, mw, nw, lane, acc, patch);
+  epi_oct_all<TM, TN, CSPLIT, (NBUF == 4 || TN == 1)>(p, unscale, mw, nw, lane, acc, patch);   // the 128-register forms keep their residual loads in the walk
 }
 
 // split-K second pass: one thread per (row, 8 channels); partial sums added in split order (deterministic, and the

@@ -268,7 +268,9 @@ __global__ void __launch_bounds__(256, 2) fused_mlp128_kernel(const MlpArgs q) {
   pe.bias = q.b2; pe.res = q.x; pe.c = q.x; pe.m = q.m; pe.n = ML_C; pe.ldc = ML_C; pe.ldres = ML_C;
   pe.act = WD_ACT_NONE; pe.out_mode = WD_OUT_ROWS; pe.res_alpha = 1.0f; pe.out_scale = 1.0f; pe.range_flag = q.range_flag;
   float* patch = reinterpret_cast<float*>(smem_raw) + wave * 32 * EPI_LDT;
-  EpiOctWalk<0, 1, 4, WD_ACT_NONE, false, false>::run(pe, q.unscale2, m0, 0, lane, out, patch);
+  EpiOctOperands<1, 4> ops;
+  ops.load(pe, m0, 0, lane);
+  EpiOctWalk<0, 1, 4, WD_ACT_NONE, false, false>::run(pe, q.unscale2, m0, 0, lane, out, patch, ops);
 }
 
 }  // namespace
