@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from wedetect_amd import lib as L
 dev = "cuda"
-for name, (b, h, w, c) in {"s1 160x160x128": (32, 160, 160, 128), "s2 80x80x256": (32, 80, 80, 256), "s3 40x40x512": (32, 40, 40, 512),
+for name, (b, h, w, c) in {"s1 160x160x128": (32, 160, 160, 128), "tiny s1 160x160x96": (32, 160, 160, 96), "s2 80x80x256": (32, 80, 80, 256), "s3 40x40x512": (32, 40, 40, 512),
                            "s4 20x20x1024": (32, 20, 20, 1024)}.items():
     x = torch.randn(b * h * w, c, device=dev)
     w7 = torch.randn(49, c, device=dev) * 0.1

@@ -528,6 +528,233 @@ __global__ void __launch_bounds__(256) dwconv7_ln_kernel(const float* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// depthwise 7x7 + LayerNorm for narrow maps (c = 32 NBLK <= 128), the pre-norm values never leave the registers.
+// A workgroup owns a 16 x 16 pixel tile for ALL channels: it runs the 1 x 8-strip depthwise conv of dwconv7_strip_kernel
+// over the NBLK channel blocks of 32 (the next block's halo tile is requested before the current one is computed), keeping
+// its 8 pixels x 4 channels of every block in registers (32 NBLK VGPRs), then normalises: a pixel's channels sit in the 8
+// lanes t & 7 (channel quad q) x NBLK blocks, so the row sums are register adds over the blocks and three lane exchanges —
+// arranged as the xor butterfly of wd_layernorm_rows over the quad index 8 blk + q (offsets 16, 8 = block bits; 4, 2, 1 =
+// lanes), hence the same bits as dwconv -> LayerNorm run as two kernels.  HBM sees the input once (plus the halo, from L2)
+// and the normalised rows once; at WeDetect-Base stage 1 the pair moved 1.7 GB per block (166 + 130 us).
+// ---------------------------------------------------------------------------------------
+template <int NBLK, bool SPLIT, int NPX>
+__device__ __forceinline__ void dwln_reg_rows(const f32x4 (&acc)[NBLK][NPX], float* __restrict__ y, const float* __restrict__ gamma,
+                                              const float* __restrict__ beta, long long pix_row0, int w, int wo0, int c, float eps,
+                                              int q, bool row_ok) {
+  // no optional contraction: the same operations as ln_row, one rounding each
+#pragma clang fp contract(off)
+  f32x4 gm[NBLK], bt[NBLK];
+#pragma unroll
+  for (int k = 0; k < NBLK; ++k) {
+    gm[k] = *reinterpret_cast<const f32x4*>(gamma + k * DT_CB + q * 4);
+    bt[k] = *reinterpret_cast<const f32x4*>(beta + k * DT_CB + q * 4);
+  }
+#pragma unroll
+  for (int j = 0; j < NPX; ++j) {
+    float ts[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < NBLK; ++k) ts[k] = 0.f + ((acc[k][j][0] + acc[k][j][1]) + (acc[k][j][2] + acc[k][j][3]));
+    float s = (ts[0] + ts[2]) + (ts[1] + ts[3]);
+    s += __shfl_xor(s, 4, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 1, 64);
+    const float mean = s / (float)c;
+    f32x4 d[NBLK];
+    float tq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < NBLK; ++k) {
+      d[k] = acc[k][j] - mean;
+      tq[k] = 0.f + ((d[k][0] * d[k][0] + d[k][1] * d[k][1]) + (d[k][2] * d[k][2] + d[k][3] * d[k][3]));
+    }
+    float sq = (tq[0] + tq[2]) + (tq[1] + tq[3]);
+    sq += __shfl_xor(sq, 4, 64);
+    sq += __shfl_xor(sq, 2, 64);
+    sq += __shfl_xor(sq, 1, 64);
+    const float rstd = 1.0f / sqrtf(sq / (float)c + eps);
+    if (!row_ok || wo0 + j >= w) continue;
+    float* yr = y + (pix_row0 + wo0 + j) * c;
+#pragma unroll
+    for (int k = 0; k < NBLK; ++k) {
+      const f32x4 tn = d[k] * rstd;
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = fmaf(tn[e], gm[k][e], bt[k][e]);
+      const int qg = k * 8 + q;
+      if (SPLIT) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 a = {o[0], o[1]}, b = {o[2], o[3]};
+        const h2 ha = __builtin_convertvector(a, h2), hb = __builtin_convertvector(b, h2);
+        const h2 la = __builtin_convertvector(a - __builtin_convertvector(ha, f32x2), h2);
+        const h2 lb = __builtin_convertvector(b - __builtin_convertvector(hb, f32x2), h2);
+        unsigned char* gp = reinterpret_cast<unsigned char*>(yr) + (size_t)(qg >> 1) * 32 + (qg & 1) * 8;
+        *reinterpret_cast<u32x2*>(gp) = u32x2{__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)};
+        *reinterpret_cast<u32x2*>(gp + 16) = u32x2{__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)};
+      } else {
+        *reinterpret_cast<f32x4*>(yr + qg * 4) = o;
+      }
+    }
+  }
+}
+
+template <int NBLK, bool SPLIT>
+__global__ void __launch_bounds__(256) dwconv7_ln_reg_kernel(const float* __restrict__ x, const float* __restrict__ w7,
+                                                             const float* __restrict__ bias, float* __restrict__ y,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             int h, int w, int tiles_h, int tiles_w, float eps) {
+  constexpr int TH = 16, NT = 256, IH = TH + 6, C = NBLK * DT_CB;
+  __shared__ __attribute__((aligned(16))) float lds[IH * DS_IWP * DT_CB + 49 * DT_CB];
+  float* tin = lds;
+  float* tw = lds + IH * DS_IWP * DT_CB;
+  const int t = threadIdx.x;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_w; bid /= tiles_w;
+  const int ty = bid % tiles_h;
+  const long long b = bid / tiles_h;
+  const int h0 = ty * TH, w0 = tx * DT_TW;
+  const float* xb = x + (b * h) * (long long)w * C;
+  constexpr int NST = (IH * DS_IW * 8 + NT - 1) / NT, NWS = (49 * 8 + NT - 1) / NT;
+  f32x4 stage[NST], wst[NWS];
+  auto request = [&](int cb) {                         // the halo tile and the 49 taps of channel block cb -> registers
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const int e = t + i * NT;
+      const int pix = e >> 3;
+      const int py = pix / DS_IW, px = pix - py * DS_IW;
+      const int hi = h0 + py - 3, wi = w0 + px - 3;
+      const bool ok = e < IH * DS_IW * 8 && (unsigned)hi < (unsigned)h && (unsigned)wi < (unsigned)w;
+      stage[i] = *reinterpret_cast<const f32x4*>(ok ? xb + ((long long)hi * w + wi) * C + cb * DT_CB + (e & 7) * 4 : g_zero4e);
+    }
+#pragma unroll
+    for (int i = 0; i < NWS; ++i) {
+      const int e = t + i * NT;
+      wst[i] = *reinterpret_cast<const f32x4*>(e < 49 * 8 ? w7 + (e >> 3) * C + cb * DT_CB + (e & 7) * 4 : g_zero4e);
+    }
+  };
+  const int q = t & 7;                   // channel quad
+  const int strip = (t >> 3) & 1;        // 8-pixel strip inside the 16-wide tile
+  const int oy = t >> 4;                 // output row inside the tile
+  f32x4 acc[NBLK][8];
+  request(0);
+#pragma unroll
+  for (int cb = 0; cb < NBLK; ++cb) {
+    if (cb > 0) __syncthreads();                       // everyone is done reading the previous channel block's tile
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const int e = t + i * NT;
+      const int pix = e >> 3;
+      const int py = pix / DS_IW, px = pix - py * DS_IW;
+      if (e < IH * DS_IW * 8) *reinterpret_cast<f32x4*>(tin + (py * DS_IWP + px) * DT_CB + (e & 7) * 4) = stage[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NWS; ++i) {
+      const int e = t + i * NT;
+      if (e < 49 * 8) *reinterpret_cast<f32x4*>(tw + (e >> 3) * DT_CB + (e & 7) * 4) = wst[i];
+    }
+    __syncthreads();
+    if (cb + 1 < NBLK) request(cb + 1);                // flies under this block's 49 taps
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + cb * DT_CB + q * 4);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[cb][j] = bv;
+#pragma unroll 1
+    for (int kh = 0; kh < 7; ++kh) {
+      const float* row = tin + ((oy + kh) * DS_IWP + strip * 8) * DT_CB + q * 4;
+      f32x4 in[14];
+#pragma unroll
+      for (int j = 0; j < 14; ++j) in[j] = *reinterpret_cast<const f32x4*>(row + j * DT_CB);
+#pragma unroll
+      for (int kw = 0; kw < 7; ++kw) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(tw + (kh * 7 + kw) * DT_CB + q * 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[cb][j] += in[j + kw] * wv;
+      }
+    }
+  }
+  const int ho = h0 + oy;
+  const bool row_ok = ho < h;
+  dwln_reg_rows<NBLK, SPLIT, 8>(acc, y, gamma, beta, (b * h + (row_ok ? ho : h0)) * (long long)w, w, w0 + strip * 8, C, eps, q, row_ok);
+}
+
+// The same on the 8 x 16 tile / 1 x 4-strip form of dwconv7_tiled_kernel: 16 NBLK accumulator registers instead of 32 NBLK
+// and 44 KB of LDS — three workgroups per CU where the 16 x 16 form, at 128 channels, is alone with one wave per SIMD.
+template <int NBLK, bool SPLIT>
+__global__ void __launch_bounds__(256) dwconv7_ln_reg4_kernel(const float* __restrict__ x, const float* __restrict__ w7,
+                                                              const float* __restrict__ bias, float* __restrict__ y,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              int h, int w, int tiles_h, int tiles_w, float eps) {
+  constexpr int C = NBLK * DT_CB;
+  __shared__ __attribute__((aligned(16))) float lds[DT_LDS_FLOATS];
+  float* tin = lds;
+  float* tw = lds + DT_IH * DT_IW * DT_CP;
+  const int t = threadIdx.x;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_w; bid /= tiles_w;
+  const int ty = bid % tiles_h;
+  const long long b = bid / tiles_h;
+  const int h0 = ty * DT_TH, w0 = tx * DT_TW;
+  const int q = t & 7;
+  const int wg = ((t >> 3) & 1) * 2 + ((t >> 4) & 1);   // strip order: see dwconv7_tiled_kernel
+  const int oy = t >> 5;
+  const float* xb = x + (b * h) * (long long)w * C;
+  constexpr int NST = (DT_IH * DT_IW * 8 + 255) / 256;
+  f32x4 stage[NST], wst[2];
+  auto request = [&](int cb) {
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const int e = t + i * 256;
+      const int pix = e >> 3;
+      const int py = pix / DT_IW, px = pix - py * DT_IW;
+      const int hi = h0 + py - 3, wi = w0 + px - 3;
+      const bool ok = e < DT_IH * DT_IW * 8 && (unsigned)hi < (unsigned)h && (unsigned)wi < (unsigned)w;
+      stage[i] = *reinterpret_cast<const f32x4*>(ok ? xb + ((long long)hi * w + wi) * C + cb * DT_CB + (e & 7) * 4 : g_zero4e);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = t + i * 256;
+      wst[i] = *reinterpret_cast<const f32x4*>(e < 49 * 8 ? w7 + (e >> 3) * C + cb * DT_CB + (e & 7) * 4 : g_zero4e);
+    }
+  };
+  f32x4 acc[NBLK][4];
+  request(0);
+#pragma unroll
+  for (int cb = 0; cb < NBLK; ++cb) {
+    if (cb > 0) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const int e = t + i * 256;
+      if (e < DT_IH * DT_IW * 8) *reinterpret_cast<f32x4*>(tin + (e >> 3) * DT_CP + (e & 7) * 4) = stage[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = t + i * 256;
+      if (e < 49 * 8) *reinterpret_cast<f32x4*>(tw + (e >> 3) * DT_CB + (e & 7) * 4) = wst[i];
+    }
+    __syncthreads();
+    if (cb + 1 < NBLK) request(cb + 1);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + cb * DT_CB + q * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[cb][j] = bv;
+#pragma unroll 1
+    for (int kh = 0; kh < 7; ++kh) {
+      const float* row = tin + ((oy + kh) * DT_IW + wg * 4) * DT_CP + q * 4;
+      f32x4 in[10];
+#pragma unroll
+      for (int j = 0; j < 10; ++j) in[j] = *reinterpret_cast<const f32x4*>(row + j * DT_CP);
+#pragma unroll
+      for (int kw = 0; kw < 7; ++kw) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(tw + (kh * 7 + kw) * DT_CB + q * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[cb][j] += in[j + kw] * wv;
+      }
+    }
+  }
+  const int ho = h0 + oy;
+  const bool row_ok = ho < h;
+  dwln_reg_rows<NBLK, SPLIT, 4>(acc, y, gamma, beta, (b * h + (row_ok ? ho : h0)) * (long long)w, w, w0 + wg * 4, C, eps, q, row_ok);
+}
+
 // L2 row normalisation, one wave per row (rows are few: the text bank).
 __global__ void __launch_bounds__(256) l2norm_rows_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                           long long rows, int c) {
@@ -637,6 +864,37 @@ extern "C" int wd_dwconv7_ln(const float* x, const float* w7, const float* bias,
   if (batch <= 0 || h <= 0 || w <= 0 || c <= 0 || c % DT_CB || c > 2048) return WD_ERR_BAD_ARG;
   if (!wd_aligned16(x) || !wd_aligned16(w7) || !wd_aligned16(bias) || !wd_aligned16(y) || !wd_aligned16(gamma) ||
       !wd_aligned16(beta)) return WD_ERR_BAD_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (c <= 4 * DT_CB) {                                // narrow maps: the pre-norm values stay in registers
+    const int th16 = (h + 15) / 16, tw16 = (w + DT_TW - 1) / DT_TW;
+    const long long nb16 = (long long)batch * th16 * tw16;
+    if (nb16 > 0x7fffffffLL) return WD_ERR_BAD_ARG;
+#define WD_DWLN_REG(NB_)                                                                                                       \
+  case NB_:                                                                                                                    \
+    if (split) hipLaunchKernelGGL((dwconv7_ln_reg_kernel<NB_, true>), dim3((unsigned)nb16), dim3(256), 0, st, x, w7, bias, y,  \
+                                  gamma, beta, h, w, th16, tw16, eps);                                                          \
+    else hipLaunchKernelGGL((dwconv7_ln_reg_kernel<NB_, false>), dim3((unsigned)nb16), dim3(256), 0, st, x, w7, bias, y,       \
+                            gamma, beta, h, w, th16, tw16, eps);                                                                \
+    break;
+    if (c == 4 * DT_CB) {                              // 128 channels: the 1 x 4-strip form (two workgroups per CU; 331 vs 400 us)
+      const int th8 = (h + DT_TH - 1) / DT_TH;
+      const long long nb8 = (long long)batch * th8 * tw16;
+      if (nb8 > 0x7fffffffLL) return WD_ERR_BAD_ARG;
+#define WD_DWLN_REG4(NB_)                                                                                                      \
+  case NB_:                                                                                                                    \
+    if (split) hipLaunchKernelGGL((dwconv7_ln_reg4_kernel<NB_, true>), dim3((unsigned)nb8), dim3(256), 0, st, x, w7, bias, y,  \
+                                  gamma, beta, h, w, th8, tw16, eps);                                                           \
+    else hipLaunchKernelGGL((dwconv7_ln_reg4_kernel<NB_, false>), dim3((unsigned)nb8), dim3(256), 0, st, x, w7, bias, y,       \
+                            gamma, beta, h, w, th8, tw16, eps);                                                                 \
+    break;
+      switch (c / DT_CB) { WD_DWLN_REG4(1) WD_DWLN_REG4(2) WD_DWLN_REG4(3) WD_DWLN_REG4(4) }
+#undef WD_DWLN_REG4
+      return wd_launch_status();
+    }
+    switch (c / DT_CB) { WD_DWLN_REG(1) WD_DWLN_REG(2) WD_DWLN_REG(3) WD_DWLN_REG(4) }
+#undef WD_DWLN_REG
+    return wd_launch_status();
+  }
   const int th = (h + DT_TH - 1) / DT_TH, tw = (w + DT_TW - 1) / DT_TW;
   const long long nblk = (long long)batch * th * tw;
   if (nblk > 0x7fffffffLL) return WD_ERR_BAD_ARG;
@@ -644,7 +902,6 @@ extern "C" int wd_dwconv7_ln(const float* x, const float* w7, const float* bias,
   int g = 8;
   while (g < 64 && g < nq) g <<= 1;
   const int nv = (nq + g - 1) / g;
-  hipStream_t st = static_cast<hipStream_t>(stream);
 #define WD_DWLN_CASE(NV)                                                                                               \
   case NV:                                                                                                             \
     if (split) hipLaunchKernelGGL((dwconv7_ln_kernel<NV, true>), dim3((unsigned)nblk), dim3(256), 0, st, x, w7, bias, y, \

@@ -78,7 +78,9 @@ class ImageTower:
         self.B, self.H, self.W = batch, height, width
         self.fuse_stem = os.environ.get("WEDETECT_FUSE_STEM", "1") == "1"      # stem as one fp32 kernel (bit-identical to the fp32 three-launch form)
         self.fuse_mlp = os.environ.get("WEDETECT_FUSE_MLP", "1") == "1"        # stage-1 block MLP as one kernel (bit-identical; profiles/r03_mlp_fused.txt)
-        self.fuse_dwln = os.environ.get("WEDETECT_FUSE_DWLN", "0") == "1"      # measured slower at every stage (profiles/r02_dwln_ab.txt): opt-in
+        # dwconv -> LayerNorm in one kernel: "auto" = the stages of <= 128 channels, where the pre-norm values stay in registers
+        # (profiles/r03_dwln_reg.txt); "1" = every stage (the wide ones through L2: slower, profiles/r02_dwln_ab.txt); "0" = never
+        self.fuse_dwln = os.environ.get("WEDETECT_FUSE_DWLN", "auto")
         self.overflowed = False
         # sticky range flag of the fp16x3 GEMMs (WdConvGemm.range_flag): set by a launch whose accumulators are inf / NaN
         self.range_flags = torch.zeros(2, dtype=torch.int32, device=torch.device(device))
@@ -328,7 +330,7 @@ class ImageTower:
             for j in range(a.depths[i]):
                 q = f"s{i}.{j}."
                 g_, b_ = self._ln_params(q + "ln_w", q + "ln_b", q + "ln" if pre else None)
-                if c % 32 == 0 and self.fuse_dwln:   # dwconv -> norm in one kernel (bit-identical to the pair; one HBM round trip less)
+                if c % 32 == 0 and (self.fuse_dwln == "1" or (self.fuse_dwln == "auto" and c <= 128)):   # bit-identical to the pair
                     L.dwconv7_ln(self.x[i], self.P[q + "dw_w"], self.P[q + "dw_b"], self.tmp, g_, b_, B, h, w, c, split=pre)
                 else:
                     L.dwconv7(self.x[i], self.P[q + "dw_w"], self.P[q + "dw_b"], self.tmp, B, h, w, c)
