@@ -115,6 +115,8 @@ def parse():
     ap.add_argument("--no-fp32-reference", action="store_true",
                     help="skip the short native-fp32 run that is reported beside an fp16x3 result (N = 1 only)")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the host-fed (PCIe-inclusive) leg (N = 1 only)")
+    ap.add_argument("--no-calibrate", action="store_true",
+                    help="skip the untimed range-calibration pass (an fp32 run of the tower): keeps it out of a rocprofv3 trace")
     ap.add_argument("--cpu-runs", type=int, default=5, help="timed CPU-oracle passes per leg (median reported; 3 warm-ups)")
     return ap.parse_args()
 
@@ -415,7 +417,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    tower.calibrate(images)                 # as the detectors do on a tower's first batch (untimed; all scales 1 here)
+    if not args.no_calibrate:
+        tower.calibrate(images)             # as the detectors do on a tower's first batch (untimed; all scales 1 here)
     timer.mode = "count"
     for _ in range(args.warmup):
         step()

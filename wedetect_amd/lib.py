@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("WEDETECT_LIB") or os.path.join(_HERE, "libwedetect_hi
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU = 0, 1, 2, 3
 OUT_ROWS, OUT_DECONV2X2 = 0, 1
 SPLIT_A, SPLIT_C = 1, 2
-ABI_VERSION = 9
+ABI_VERSION = 10
 NMS_VANILLA, NMS_TORCHVISION, NMS_MMCV = 0, 1, 2
 TV_TRICK_MAX_NUMEL = {"cpu": 4000, "cuda": 20000}   # torchvision/ops/boxes.py batched_nms: vanilla above this many box coordinates
 MMCV_SPLIT_THR = 10000                                 # mmcv/ops/nms.py batched_nms: per-class loop from this many candidates
