@@ -135,6 +135,7 @@ class GemmTimer:
         self.count = 0
         self.pool = []
         self._orig = lib.conv_gemm
+        self._orig_mlp = lib.mlp_fused
 
     @staticmethod
     def _pair():
@@ -178,6 +179,18 @@ class GemmTimer:
             nbytes = 4.0 * (a_elems + n * k + m * n * (2 if kw.get("res") is not None else 1))
             rec.setdefault(tag, []).append((s, e, 2.0 * m * n * k, nbytes))
         lib.conv_gemm = wrapped
+        orig_mlp = self._orig_mlp
+
+        def wrapped_mlp(a_split, rows, c, hidden, *args, **kw):     # the one-kernel block MLP: two GEMMs' worth of flops
+            if self.mode != "time":
+                self.count += self.mode == "count"
+                return orig_mlp(a_split, rows, c, hidden, *args, **kw)
+            s, e = self.pool.pop() if self.pool else self._pair()
+            lib.time_next_gemm(s, e)
+            orig_mlp(a_split, rows, c, hidden, *args, **kw)
+            nbytes = 4.0 * (3 * rows * c + 2 * c * hidden)           # LN rows in, x in and out, both weight matrices
+            rec.setdefault("fp16x3 fused block MLP 128x(128->512->128)/4w/dma", []).append((s, e, 4.0 * rows * c * hidden, nbytes))
+        lib.mlp_fused = wrapped_mlp
 
     def summary(self):
         out = {}
