@@ -17,9 +17,11 @@
 // Same halves, same K order per output (hidden columns ascending, 16 at a time), the same epilogue arithmetic as the two
 // kernels it replaces: BIT-IDENTICAL (tests/test_gpu_split.py::test_fused_mlp_*).
 //
-// Measured (MI355X, 819200 rows, profiles/r03_mlp_fused.txt): 750-760 us against 1190-1290 us for the two launches.  The
+// Measured (MI355X, 819200 rows, profiles/r03_mlp_fused.txt): 700-760 us against 1190-1290 us for the two launches.  The
 // road there: one workgroup per CU with 64-row waves and the hidden chunk through LDS (three barriers per chunk): 1157 us;
-// this wave-per-32-rows form without the in-wave pipelining: 843 us; pipelined: 760 us.  What bounds it now is VALU issue,
+// this wave-per-32-rows form without the in-wave pipelining: 843 us; pipelined: 760 us; epilogue operands requested before
+// the first output store (split_epi_oct.h): 720 us (requesting them two GEMM-2 passes earlier still: no change, 28 more
+// registers).  What bounds it now is VALU issue,
 // not MFMA (MFMA-busy 44 %, VALU-busy 50 %, and they do not overlap: dropping the GELU arithmetic gives 471 us): ~27 VALU
 // instructions per hidden value against 3 MFMAs.  Packed fp32 instructions (half the count) bought nothing — they
 // serialise with the matrix pipe — and neither did one wave per SIMD (942 us).
