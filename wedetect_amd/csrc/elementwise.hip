@@ -679,6 +679,7 @@ __global__ void __launch_bounds__(256) dwconv7_ln_reg_kernel(const float* __rest
 
 // The same on the 8 x 16 tile / 1 x 4-strip form of dwconv7_tiled_kernel: 16 NBLK accumulator registers instead of 32 NBLK
 // and 44 KB of LDS — three workgroups per CU where the 16 x 16 form, at 128 channels, is alone with one wave per SIMD.
+// (With the next block's halo requested ahead, as the 16 x 16 form does, it holds 198 registers: two workgroups, 331 us.)
 template <int NBLK, bool SPLIT>
 __global__ void __launch_bounds__(256) dwconv7_ln_reg4_kernel(const float* __restrict__ x, const float* __restrict__ w7,
                                                               const float* __restrict__ bias, float* __restrict__ y,
@@ -717,10 +718,11 @@ __global__ void __launch_bounds__(256) dwconv7_ln_reg4_kernel(const float* __res
     }
   };
   f32x4 acc[NBLK][4];
-  request(0);
 #pragma unroll
   for (int cb = 0; cb < NBLK; ++cb) {
-    if (cb > 0) __syncthreads();
+    request(cb);                                       // no request-ahead here: without the 40 staging registers held across the
+                                                       // taps three workgroups share a CU (311 vs 331 us at 160 x 160 x 128)
+    if (cb > 0) __syncthreads();                       // everyone is done reading the previous channel block's tile
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
       const int e = t + i * 256;
@@ -732,7 +734,6 @@ __global__ void __launch_bounds__(256) dwconv7_ln_reg4_kernel(const float* __res
       if (e < 49 * 8) *reinterpret_cast<f32x4*>(tw + (e >> 3) * DT_CB + (e & 7) * 4) = wst[i];
     }
     __syncthreads();
-    if (cb + 1 < NBLK) request(cb + 1);
     const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + cb * DT_CB + q * 4);
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[cb][j] = bv;
@@ -876,7 +877,7 @@ extern "C" int wd_dwconv7_ln(const float* x, const float* w7, const float* bias,
     else hipLaunchKernelGGL((dwconv7_ln_reg_kernel<NB_, false>), dim3((unsigned)nb16), dim3(256), 0, st, x, w7, bias, y,       \
                             gamma, beta, h, w, th16, tw16, eps);                                                                \
     break;
-    if (c == 4 * DT_CB) {                              // 128 channels: the 1 x 4-strip form (two workgroups per CU; 331 vs 400 us)
+    if (c == 4 * DT_CB) {                              // 128 channels: the 1 x 4-strip form (three workgroups per CU; 311 vs 400 us)
       const int th8 = (h + DT_TH - 1) / DT_TH;
       const long long nb8 = (long long)batch * th8 * tw16;
       if (nb8 > 0x7fffffffLL) return WD_ERR_BAD_ARG;
