@@ -67,8 +67,9 @@ class ImageTower:
                     if self.fixed_splitk else None)
         # 256 x 256 fp16x3 kernels for the big pre-split layers (split_gemm_p8.hip).  $WEDETECT_P8: "tile" (default) = one
         # workgroup per output tile, picked by the library; "persist" = additionally offer the park workspace, which
-        # selects the persistent work-unit form where it applies (faster per launch in isolation — profiles/r02_p8_ab.txt —
-        # equal inside the step; its flag words must start zero and it is never lent to split-K launches); "0" = neither
+        # selects the persistent work-unit form where it applies (faster per launch in isolation on some shapes — profiles/r02_p8_ab.txt —,
+        # equal inside the round-2 step and 3.5 % slower inside the round-3 one: 819 vs 790 images/s, profiles/r03_p8_tile_vs_persist.txt;
+        # its flag words must start zero and it is never lent to split-K launches); "0" = neither
         # (the round-1 128 x 128 / ping-pong kernels, for A/B runs).
         self.p8_mode = os.environ.get("WEDETECT_P8", "tile")
         self.s2d_down = os.environ.get("WEDETECT_S2D_DOWN", "1") != "0"     # downsample convs as plain GEMMs on space-to-depth LayerNorm rows
