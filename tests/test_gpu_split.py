@@ -375,7 +375,8 @@ def test_p4_kernel_bit_identical_to_the_128_tile_kernel(m, n, k, mode):
 
 
 @pytest.mark.parametrize("m,n,k,mode", [(51200, 512, 2048, "residual"), (51200, 2048, 512, "gelu_csplit"), (65536 + 8, 256, 96, "residual"),
-                                         (66000, 512, 32, "gelu_csplit"), (131064, 256, 64, "residual")])
+                                         (66000, 512, 32, "gelu_csplit"), (131064, 256, 64, "residual"),
+                                         (40008, 1024, 64, "gelu_csplit"), (70000, 768, 96, "residual")])   # round 4: gangs of 4 / of 1 with three column tiles
 def test_p8_persistent_kernel_bit_identical_and_repeatable(m, n, k, mode):
     """cfg 65: one workgroup per CU walks a contiguous range of (tile, K tile) units; tiles cut between two CUs are
     started by one, parked in the workspace, and finished by the other from the parked accumulators.  Same MFMA chain
@@ -572,6 +573,65 @@ def test_fused_mlp_bit_identical_to_the_two_kernel_chain(m, hid_scale):
     y = torch.nn.functional.layer_norm(x0.double(), (c,), g.double(), b.double(), 1e-6)
     ref = x0.double() + torch.nn.functional.gelu(y @ w1.double().T + b1.double()) @ w2.double().T + b2.double()
     assert float((got.double() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("c,m", [(512, 128), (512, 128 * 9), (512, 51200), (256, 128), (256, 128 * 37)])
+@pytest.mark.parametrize("hid_scale", [1.0, 0.25])
+def test_fused_mlp_wide_bit_identical_to_the_two_kernel_chain(c, m, hid_scale):
+    """wd_mlp_fused_wide (round 4: the block MLP of the 256 / 512-channel stages as one kernel — output tile in the four
+    waves' accumulators, hidden chunks of 128 columns through LDS, weights fragment-major straight from global memory) against
+    the two launches the engine otherwise runs (the 256 x 256 kernel twice).  Same halves, same K order per output, same
+    epilogue arithmetic: the same bits, with and without a range scale; repeated launches agree."""
+    from wedetect_amd import lib as L
+    h = 4 * c
+    x0, g, b = _rand((m, c), 311, 2.0), _rand((c,), 312), _rand((c,), 313, 0.1)
+    w1, b1 = _rand((h, c), 314, c ** -0.5), _rand((h,), 315, 0.1)
+    w2, b2 = _rand((c, h), 316, h ** -0.5), _rand((c,), 317, 0.1)
+    ws1, ws2 = L.split_weights(w1), L.split_weights(w2)
+    ws2s = (ws2[0], ws2[1] / hid_scale)
+    wf1 = (L.mlp_wide_pack(ws1[0], h, c), ws1[1])
+    wf2 = (L.mlp_wide_pack(ws2[0], c, h), ws2s[1])
+    xs = torch.empty(m, c, device="cuda")
+    L.layernorm_rows(x0, xs, g, b, m, c, split=True)
+    hid = torch.empty(m, h, device="cuda")
+    want = x0.clone()
+    L.conv_gemm(xs, None, b1, hid, w_split=ws1, batch=1, hin=1, win=m, cin=c, lda=c, n=h, ldc=h, act=L.ACT_GELU,
+                split_flags=L.SPLIT_A | L.SPLIT_C, c_split_scale=hid_scale)
+    L.conv_gemm(hid, None, b2, want, w_split=ws2s, batch=1, hin=1, win=m, cin=h, lda=h, n=c, ldc=c, res=want, ldres=c,
+                split_flags=L.SPLIT_A)
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for _ in range(3):
+        got = x0.clone()
+        L.mlp_fused_wide(xs, m, c, h, wf1, b1, wf2, b2, got, hid_scale=hid_scale, range_flag=flag)
+        torch.cuda.synchronize()
+        assert torch.equal(got.view(torch.int32), want.view(torch.int32)), f"max|d| {float((got - want).abs().max())}"
+    assert int(flag.item()) == 0
+    if m <= 128 * 37:                                             # and it is a real MLP: against float64
+        y = torch.nn.functional.layer_norm(x0.double(), (c,), g.double(), b.double(), 1e-6)
+        ref = x0.double() + torch.nn.functional.gelu(y @ w1.double().T + b1.double()) @ w2.double().T + b2.double()
+        assert float((got.double() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+
+
+def test_fused_mlp_wide_refuses_other_shapes_and_flags_overflow():
+    from wedetect_amd import lib as L
+    c, h, m = 256, 1024, 256
+    assert L.mlp_wide_supported(m, c, h) and L.mlp_wide_supported(m, 512, 2048)
+    assert not L.mlp_wide_supported(m + 8, c, h) and not L.mlp_wide_supported(m, 128, 512) and not L.mlp_wide_supported(m, 1024, 4096)
+    xs = torch.zeros(m, c, device="cuda")
+    ws1, ws2 = L.split_weights(_rand((h, c), 1, 0.1)), L.split_weights(_rand((c, h), 2, 0.1))
+    wf1, wf2 = (L.mlp_wide_pack(ws1[0], h, c), ws1[1]), (L.mlp_wide_pack(ws2[0], c, h), ws2[1])
+    b1, b2, x = torch.zeros(h, device="cuda"), torch.zeros(c, device="cuda"), torch.zeros(m, c, device="cuda")
+    with pytest.raises(L.WedetectHipError):
+        L.mlp_fused_wide(xs, m + 8, c, h, wf1, b1, wf2, b2, x)
+    with pytest.raises(L.WedetectHipError):
+        L.mlp_fused_wide(xs, m, 128, 512, wf1, b1, wf2, b2, x)
+    with pytest.raises(L.WedetectHipError):
+        L.mlp_wide_pack(ws1[0], h + 8, c)
+    b1big = torch.full((h,), 1e6, device="cuda")
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    L.mlp_fused_wide(xs, m, c, h, wf1, b1big, wf2, b2, x, range_flag=flag)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 1
 
 
 def test_fused_mlp_refuses_other_shapes_and_flags_overflow():

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwedetect_hip.so")
-SOURCES = ["abi.hip", "conv_gemm.hip", "split_gemm.hip", "split_gemm_pre.hip", "split_gemm_p8.hip", "split_gemm_p4.hip", "split_gemm_conv.hip", "split_gemm_mlp.hip", "probe.hip", "stem.hip", "elementwise.hip", "preprocess.hip", "text.hip", "bricks.hip", "evaluate.hip", "postprocess.hip"]
+SOURCES = ["abi.hip", "conv_gemm.hip", "split_gemm.hip", "split_gemm_pre.hip", "split_gemm_p8.hip", "split_gemm_p4.hip", "split_gemm_conv.hip", "split_gemm_mlp.hip", "split_gemm_mlpw.hip", "probe.hip", "stem.hip", "elementwise.hip", "preprocess.hip", "text.hip", "bricks.hip", "evaluate.hip", "postprocess.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-inline-asm",
          "-I", os.path.join(ROOT, "include"), "-I", CSRC]

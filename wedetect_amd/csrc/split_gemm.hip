@@ -102,6 +102,7 @@ static int pick_split_cfg(const WdConvGemm& p) {
 }
 
 long long wd_p8_workspace_floats();                                   // split_gemm_p8.hip
+bool wd_p8_persist_ok(int m, int n);
 // split_gemm_conv.hip: implicit-GEMM LDS-DMA kernel for pre-split activations (any geometry, every output form)
 bool wd_conv_pp_ok(const WdConvGemm& p, int flags);
 int wd_launch_conv_pp(const WdConvGemm& p, const void* w, float unscale, int flags, hipStream_t st, int ksplits, float* ws,
@@ -125,8 +126,7 @@ extern "C" int64_t wd_p8_workspace_bytes(void) { return 4 * wd_p8_workspace_floa
 static int pick_presplit_cfg(int m, int n, int k, bool park) {
   if (k % 32 == 0 && k >= 256 && m % 8 == 0 && n % 256 == 0) {
     const long long tiles = (long long)((m + 255) / 256) * (n / 256);
-    const long long wgs = wd_p8_workspace_floats() > 0 ? (wd_p8_workspace_floats() - 1024) / (128 * 512) : 256;
-    if (park && tiles >= wgs) return 65;
+    if (park && wd_p8_persist_ok(m, n)) return 65;
     if (tiles >= 128) return 64;
   }
   if (k % 16 == 0 && n % 256 == 0 && m % 16 == 0 && m >= 131072) return 66;   // short K, very long m (stage-1 pwconv1)

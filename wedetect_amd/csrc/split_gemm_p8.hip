@@ -77,22 +77,30 @@ __device__ __forceinline__ void p8_dma(unsigned lds_addr, unsigned voff, const u
 //
 // PERSIST (cfg 65): one workgroup per CU walks a contiguous range of (tile, K tile) work units instead of
 // owning whole output tiles, so 400 tiles on 256 CUs cost 1.5625 tile times, not 2 (and the epilogues of
-// different CUs stop happening in the same microseconds).  The tile list is cut into 8 chunks, one per XCD
-// (workgroup b runs on XCD b % 8: neighbouring tiles share operand panels through that XCD's L2), each chunk's
-// units are dealt evenly to the XCD's workgroups.  A workgroup's range therefore starts and / or ends inside
-// a tile.  The head of a tile [0, e) is computed FIRST, its raw accumulators are parked in the workspace and a
+// different CUs stop happening in the same microseconds).  Round 4: the units are dealt to GANGS of ngrp workgroups,
+// not to single workgroups.  The round-2/3 form gave every workgroup its own contiguous run of tiles: the column tiles
+// of one row panel, which the tile form runs on neighbouring CUs of an XCD at the same time (the activation panel is
+// fetched once and hits in L2 for the others), were then walked by ONE workgroup one after the other while its 31
+// neighbours walked 31 other panels — 32 panels live per 4 MB L2 instead of 4, and the PMC pass says what that costs
+// (profiles/r04_persist_pmc.txt, stage-3 pwconv1 / pwconv2: FETCH_SIZE 1.35 / 1.34 GB per launch against 0.33 / 0.58 GB
+// for the tile form, TCC misses 2.4 x) — hidden by the Infinity Cache in a one-kernel loop, 12 % slower inside the step.
+// A gang = ngrp workgroups with consecutive slots on one XCD; member j owns column tile j of every gang tile (= the ngrp
+// column tiles of a row panel, exactly the tiles the tile form runs side by side) and all members share the same unit
+// range, so the gang moves through K in step and the panel is fetched once.  The gang-tile list is cut into 8 chunks,
+// one per XCD (workgroup b runs on XCD b % 8), each chunk's units are dealt evenly to the XCD's gangs.  A gang's
+// range therefore starts and / or ends inside a tile.  The head of a tile [0, e) is computed FIRST, its raw accumulators are parked in the workspace and a
 // flag is published (agent-scope release); whole tiles follow; LAST comes the tail [o, nk) of the tile the
 // previous workgroup of the chain began: wait for that flag (set long before), acquire, reload the
 // accumulators and continue the K loop where it stopped — the same MFMA chain, only carried by two CUs, so the
-// result is bit-identical to the one-workgroup-per-tile kernels.  A workgroup waits only on its predecessor in
-// the XCD chain (block b - 8, dispatched earlier), and only at the very end of its own work; the first of a
-// chain never waits.  Needs tiles >= workgroups (every range is at least one whole tile long).
+// result is bit-identical to the one-workgroup-per-tile kernels.  A workgroup waits only on the same member of the
+// previous gang of its XCD chain (block b - 8 ngrp, dispatched earlier), and only at the very end of its own work; the
+// first gang of a chain never waits.  Needs at least one whole gang tile per gang on every XCD.
 constexpr long long P8_PARK_BYTES = 8ll * 32768;       // per workgroup: 8 accumulators x 512 lanes x 64 B
 struct P8Persist {
   float* acc;            // [workgroup][512 lanes][128 floats]: parked accumulators of the tile a workgroup shares with its successor
   unsigned* flag;        // [workgroup]: 1 = parked; reset to 0 by the consumer
   const float* zero;     // 512 bytes of zeros
-  int ntiles;
+  int ntiles;            // gang tiles: row panels x column groups
 };
 
 template <int VAR, int ABL = 0, bool PERSIST = false>
@@ -110,10 +118,11 @@ split_gemm_p8_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, 
   // ---- work assignment
   int seg_first_tile, seg_o, seg_last_tile, seg_e;   // units [first_tile * nk + o, last_tile * nk + e)
   if (PERSIST) {
-    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3, per = gridDim.x >> 3;
+    // gang = slot / ngrp, member = slot % ngrp; gang tile gt <-> tiles gt * ngrp + member of the tile form's list
+    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3, per = (gridDim.x >> 3) / ngrp, gang = slot / ngrp;
     const long long t0 = (long long)ps.ntiles * xcd / 8, t1 = (long long)ps.ntiles * (xcd + 1) / 8;
     const long long units = (t1 - t0) * nk;
-    const long long u0 = t0 * nk + units * slot / per, u1 = t0 * nk + units * (slot + 1) / per;
+    const long long u0 = t0 * nk + units * gang / per, u1 = t0 * nk + units * (gang + 1) / per;
     seg_first_tile = (int)(u0 / nk); seg_o = (int)(u0 - (long long)seg_first_tile * nk);
     seg_last_tile = (int)(u1 / nk); seg_e = (int)(u1 - (long long)seg_last_tile * nk);
   } else {
@@ -161,7 +170,8 @@ split_gemm_p8_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, 
     // which piece: head (park the accumulators), whole tile, or tail (resume from parked accumulators)
     const bool is_head = has_head && sg == 0;
     const bool is_tail = has_tail && sg == nseg - 1;
-    const int tile = is_head ? seg_last_tile : (is_tail ? seg_first_tile : full0 + sg - has_head);
+    int tile = is_head ? seg_last_tile : (is_tail ? seg_first_tile : full0 + sg - has_head);
+    if (PERSIST) tile = tile * ngrp + (int)(blockIdx.x >> 3) % ngrp;
     const int kb = is_tail ? seg_o : 0;
     const int nks = (is_head ? seg_e : nk) - kb;                  // K tiles of this piece (>= 1)
     const int grp = tile / gsz, rem = tile - grp * gsz;
@@ -208,7 +218,7 @@ split_gemm_p8_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, 
     // hipcc spill inside the K loop, accumulators that become live one pair per phase do not.
     const unsigned char* park_src = nullptr;
     if (PERSIST && is_tail) {
-      const int prev = blockIdx.x - 8;
+      const int prev = blockIdx.x - 8 * ngrp;
       if (t == 0) {
         while (__hip_atomic_load(ps.flag + prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) __builtin_amdgcn_s_sleep(8);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -345,7 +355,7 @@ split_gemm_p8_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, 
       if (PERSIST && resume) {                                     // every parked value is in registers: release the slot
         resume = false;
         __syncthreads();
-        if (t == 0) __hip_atomic_store(ps.flag + (blockIdx.x - 8), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == 0) __hip_atomic_store(ps.flag + (blockIdx.x - 8 * ngrp), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     };
 
@@ -426,16 +436,23 @@ split_gemm_p8_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, 
 
 constexpr long long P8_PARK_FLOATS = P8_PARK_BYTES / 4;
 
+// one workgroup per CU, the same number on every XCD — a fact of the CURRENT device (a process may drive several)
 int p8_workgroups() {
-  static int n = 0;
-  if (!n) {
-    int dev = 0;
+  static int n[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  int& slot = n[dev & 63];
+  if (!slot) {
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
-    n = prop.multiProcessorCount / 8 * 8;                          // one workgroup per CU, the same number on every XCD
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+    slot = prop.multiProcessorCount / 8 * 8;
   }
-  return n;
+  return slot;
 }
+
+// gang size of the persistent form for nbn column tiles: the largest of 8 / 4 / 2 / 1 that divides nbn (and the 32
+// workgroups of an XCD)
+int p8_gang(int nbn) { return nbn % 8 == 0 ? 8 : nbn % 4 == 0 ? 4 : nbn % 2 == 0 ? 2 : 1; }
 
 template <int VAR, int ABL = 0, bool PERSIST = false>
 int launch_p8(const WdConvGemm& p, const void* wsp, float unscale, hipStream_t st, float* ws = nullptr, long long ws_floats = 0) {
@@ -459,7 +476,11 @@ int launch_p8(const WdConvGemm& p, const void* wsp, float unscale, hipStream_t s
   if (PERSIST) {
     const int wgs = p8_workgroups();
     if (wgs <= 0) return WD_ERR_LAUNCH;
-    if (nblk < wgs) return WD_ERR_UNSUPPORTED;                     // ranges shorter than a tile would chain serially
+    ngrp = p8_gang(nbn);
+    const int per = wgs / 8;
+    if (per % ngrp) return WD_ERR_UNSUPPORTED;
+    ps.ntiles = (int)(nblk / ngrp);                                // gang tiles
+    if (ps.ntiles / 8 < per / ngrp) return WD_ERR_UNSUPPORTED;     // ranges shorter than a tile would chain serially
     if (!ws || ws_floats < wd_p8_workspace_floats()) return WD_ERR_WORKSPACE;
     ps.flag = reinterpret_cast<unsigned*>(ws);                     // first 4 KB: flags (zero between launches); [512, 516): zeros
     ps.zero = ws + 512;
@@ -475,6 +496,16 @@ int launch_p8(const WdConvGemm& p, const void* wsp, float unscale, hipStream_t s
 }
 
 }  // namespace
+
+// does the persistent form apply to an m x n problem on the current device?  (every gang of every XCD gets at least one
+// whole gang tile)
+bool wd_p8_persist_ok(int m, int n) {
+  const int wgs = p8_workgroups();
+  if (wgs <= 0 || n % 256) return false;
+  const int nbm = (m + 255) / 256, nbn = n / 256, g = p8_gang(nbn), per = wgs / 8;
+  if (per % g) return false;
+  return (long long)nbm * (nbn / g) / 8 >= per / g;
+}
 
 // workspace of the persistent form: 1024 flag words + one parked accumulator set per workgroup (fp32 elements)
 long long wd_p8_workspace_floats() {

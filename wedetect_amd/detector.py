@@ -121,6 +121,9 @@ class _TowerHolder:
         self.graph_max_batch = int(os.environ.get("WEDETECT_GRAPH_MAX_BATCH", "4"))
         # fp16x3 split scales are chosen from the first batch a tower sees (engine.ImageTower.calibrate); "0": never
         self.auto_calibrate = os.environ.get("WEDETECT_CALIBRATE", "1") != "0"
+        # ONE set of split scales per checkpoint, shared by every (B, H, W) tower: an image gets the same bits whatever batch
+        # shape it arrives in (per-tower first-batch calibration broke that for checkpoints with scales != 1)
+        self.sscale = None
         self.device = None
 
     def load(self, sd, strict: bool):
@@ -141,6 +144,7 @@ class _TowerHolder:
         self._packed = None
         self._towers.clear()
         self._graphs.clear()
+        self.sscale = None                                   # a new checkpoint calibrates anew
         return _IncompatibleKeys(missing, unexpected)
 
     def state(self) -> "OrderedDict[str, torch.Tensor]":
@@ -163,7 +167,21 @@ class _TowerHolder:
             self._towers[key] = ImageTower(self.arch, self._packed, batch, height, width, device=self.device,
                                            max_classes=self.max_classes, max_out=self.max_out, nms_pre=self.nms_pre,
                                            precision=self.precision)
+            if self.sscale is not None:
+                self._towers[key].adopt_scales(self.sscale)
         return self._towers[key]
+
+    def _share_scales(self, tower) -> None:
+        self.sscale = dict(tower.sscale)
+        for t in self._towers.values():
+            if t is not tower:
+                t.adopt_scales(self.sscale)
+
+    def recalibrate(self, tower, images_u8) -> None:
+        """The range guard tripped under scales taken from an earlier batch: derive them again from this one (scales only go
+        down) and hand them to every tower of the checkpoint."""
+        tower.calibrate(images_u8, merge=True)
+        self._share_scales(tower)
 
     def detect(self, tower, images_u8, text, meta, **kw):
         """``tower.detect`` for the detector classes.  Small batches (the reference runs batch 1 everywhere) are
@@ -172,9 +190,13 @@ class _TowerHolder:
         step, tests/test_gpu_detector.py).  A graph belongs to one (tower, arithmetic mode, bank size, thresholds); the
         range guard's switch to fp32 therefore captures anew."""
         if not tower.calibrated and self.auto_calibrate:
-            # first batch of this tower: one fp32 pass chooses the fp16x3 split scales for this checkpoint's activation
-            # ranges (engine.ImageTower.calibrate; scale 1 everywhere for ordinary checkpoints)
-            tower.calibrate(images_u8)
+            # first batch of this CHECKPOINT: one fp32 pass chooses the fp16x3 split scales for its activation ranges
+            # (engine.ImageTower.calibrate; scale 1 everywhere for ordinary checkpoints); towers of other shapes adopt them
+            if self.sscale is None:
+                tower.calibrate(images_u8)
+                self._share_scales(tower)
+            else:
+                tower.adopt_scales(self.sscale)
         if tower.B > self.graph_max_batch:
             return tower.detect(images_u8, text, meta, **kw)
         k = int(text.shape[0])
@@ -281,7 +303,13 @@ class SimpleYOLOWorldDetector(_DeviceModule):
         self._h = _TowerHolder(backbone_size, num_prompts, max(num_prompts, 1), num_proposals, precision)
         self._lb = None
         from .lib import TV_TRICK_MAX_NUMEL
-        self.tv_trick_max_numel = TV_TRICK_MAX_NUMEL[os.environ.get("WEDETECT_TV_NMS_DEVICE", "cpu")]
+        # which execution of the reference the torchvision NMS reproduces: "cpu" (default — the CPU path BASELINE.json's
+        # parity contract names: coordinate trick up to 4000 box coordinates, IoU compared with a C++ double threshold) or
+        # "cuda" (what the script's hard-coded .cuda() run takes: 20000, float threshold)
+        self.tv_nms_device = os.environ.get("WEDETECT_TV_NMS_DEVICE", "cpu")
+        if self.tv_nms_device not in TV_TRICK_MAX_NUMEL:
+            raise ValueError(f"WEDETECT_TV_NMS_DEVICE must be one of {sorted(TV_TRICK_MAX_NUMEL)}, not {self.tv_nms_device!r}")
+        self.tv_trick_max_numel = TV_TRICK_MAX_NUMEL[self.tv_nms_device]
 
     @torch.no_grad()
     def forward(self, image_paths: Sequence[Union[str, object]], rescale=True) -> List[Dict[str, torch.Tensor]]:
@@ -327,9 +355,10 @@ class SimpleYOLOWorldDetector(_DeviceModule):
         # branch threshold of the device the reference's tensors would live on ($WEDETECT_TV_NMS_DEVICE: "cpu" = the CPU
         # reference path the parity contract names, "cuda" = what the script's hard-coded .cuda() run takes)
         run = lambda: self._h.detect(tower, x, tower.P["prompts"], meta, normalize_text=False, score_thr=0.0, with_embed=True,
-                                     nms="torchvision", nms_param=self.tv_trick_max_numel)
+                                     nms="torchvision", nms_param=self.tv_trick_max_numel, nms_device=self.tv_nms_device)
         res = run()
-        counts = tower.checked_counts(res, run)             # one D2H sync per batch (+ the fp16x3 range guard)
+        recal = (lambda: self._h.recalibrate(tower, x)) if self._h.auto_calibrate else None
+        counts = tower.checked_counts(res, run, recal)      # one D2H sync per batch (+ the fp16x3 range guard)
         if tower.overflowed:
             self._h.precision = "fp32"                      # towers built later for other shapes start in fp32 too
         return res, counts, tower
@@ -708,7 +737,8 @@ class YOLOWorldDetector(_DeviceModule):
                                          # mmdet _bbox_post_process -> mmcv.ops.batched_nms(bboxes, scores, labels, cfg.nms)
                                          nms="mmcv", nms_param=int(self.test_cfg["nms"].get("split_thr", 10000)))
             res = run()
-            counts = tower.checked_counts(res, run)
+            recal = (lambda: self._h.recalibrate(tower, x)) if self._h.auto_calibrate else None
+            counts = tower.checked_counts(res, run, recal)
             if tower.overflowed:
                 self._h.precision = "fp32"
             for j, (i, n) in enumerate(zip(idxs, counts)):

@@ -79,6 +79,10 @@ class ImageTower:
         self.B, self.H, self.W = batch, height, width
         self.fuse_stem = os.environ.get("WEDETECT_FUSE_STEM", "1") == "1"      # stem as one fp32 kernel (bit-identical to the fp32 three-launch form)
         self.fuse_mlp = os.environ.get("WEDETECT_FUSE_MLP", "1") == "1"        # stage-1 block MLP as one kernel (bit-identical; profiles/r03_mlp_fused.txt)
+        # round 4: the block MLP of the 256 / 512-channel stages as one kernel too (wd_mlp_fused_wide, bit-identical):
+        # comma-separated widths, "" = none
+        self.fuse_mlp_wide = tuple(int(v) for v in os.environ.get("WEDETECT_FUSE_MLP_WIDE", "").split(",") if v.strip())
+        self.Wf: Dict[str, tuple] = {}           # fragment-major weight copies of those layers (lib.mlp_wide_pack)
         # dwconv -> LayerNorm in one kernel: "auto" = the stages of <= 128 channels, where the pre-norm values stay in registers
         # (profiles/r03_dwln_reg.txt); "1" = every stage (the wide ones through L2: slower, profiles/r02_dwln_ab.txt); "0" = never
         self.fuse_dwln = os.environ.get("WEDETECT_FUSE_DWLN", "auto")
@@ -154,6 +158,7 @@ class ImageTower:
         self._calib: Optional[Dict[str, torch.Tensor]] = None
         self._ln_scaled: Dict[tuple, tuple] = {}
         self.calibrated = False
+        self.calibration_runs = 0
         self._alloc_post(max_classes)
         self.nms_ws = torch.zeros(max(1, L.nms_workspace_bytes(B) // 4), dtype=torch.int32, device=self.dev)
         self.cand_idx = torch.empty(B, self.cap, dtype=torch.int32, device=self.dev)
@@ -249,10 +254,11 @@ class ImageTower:
                 else:
                     self._record(c_key, c[..., : n // 4] if kw.get("out_mode", 0) == L.OUT_DECONV2X2 else c[..., :n])
 
-    def _mlp_fused(self, q: str, i: int) -> None:
-        """One ConvNeXt block MLP on the narrow stage as a single launch (wd_mlp_fused_split): the 4c hidden activation stays in
-        LDS.  The range scales are applied exactly as the two-kernel path does (``_gemm``): LN scale divided out of W1's
-        unscale, the hidden scale applied before the split and divided out of W2's."""
+    def _mlp_fused(self, q: str, i: int, wide: bool = False) -> None:
+        """One ConvNeXt block MLP as a single launch: the 4c hidden activation never leaves the CU (wd_mlp_fused_split for the
+        128-channel stage, hidden chunk in registers; ``wide``: wd_mlp_fused_wide for 256 / 512 channels, hidden chunks through
+        LDS, weights fragment-major).  The range scales are applied exactly as the two-kernel path does (``_gemm``): LN scale
+        divided out of W1's unscale, the hidden scale applied before the split and divided out of W2's."""
         c = self.a.dims[i]
         ws = []
         for name in (q + "w1", q + "w2"):
@@ -260,10 +266,17 @@ class ImageTower:
             if s_ is None:
                 wt = self.P[name]
                 s_ = self.Ws[name] = L.split_weights(wt.view(wt.shape[0], -1))
+            if wide:
+                f_ = self.Wf.get(name)
+                if f_ is None:
+                    n_, k_ = (4 * c, c) if name.endswith("w1") else (c, 4 * c)
+                    f_ = self.Wf[name] = (L.mlp_wide_pack(s_[0], n_, k_), s_[1])
+                s_ = f_
             ws.append(s_)
         sa, sh = self.sscale.get(q + "ln", 1.0), self.sscale.get(q + "hid", 1.0)
-        L.mlp_fused(self.tmp, self.M[i], c, 4 * c, (ws[0][0], ws[0][1] / sa), self.P[q + "b1"], (ws[1][0], ws[1][1] / sh),
-                    self.P[q + "b2"], self.x[i], hid_scale=sh, range_flag=self.range_flag)
+        fn = L.mlp_fused_wide if wide else L.mlp_fused
+        fn(self.tmp, self.M[i], c, 4 * c, (ws[0][0], ws[0][1] / sa), self.P[q + "b1"], (ws[1][0], ws[1][1] / sh),
+           self.P[q + "b2"], self.x[i], hid_scale=sh, range_flag=self.range_flag)
 
     def _neck_split(self) -> bool:
         """Is the neck / head running on pre-split activations in this step?  Not when the tower fell back to fp32 kernels,
@@ -271,17 +284,21 @@ class ImageTower:
         return self.presplit_neck and self.precision == "fp16x3" and not self.neck_pin
 
     @staticmethod
-    def unsplit(t: torch.Tensor) -> torch.Tensor:
+    def unsplit(t: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
         """fp32 view of a tensor stored as fp16 hi/lo groups ([hi x8 | lo x8] per 8 channels): hi + lo, i.e. the producer's
-        fp32 value to 2^-22 relative.  Diagnostics / tests only — the hot path never converts back."""
+        fp32 value to 2^-22 relative.  ``scale``: the split scale the producer multiplied by (calibrate(); a power of two,
+        divided out exactly).  Diagnostics / tests only — the hot path never converts back."""
         rows, c = t.shape
         h = t.contiguous().view(torch.float16).view(rows, c // 8, 2, 8)
-        return (h[:, :, 0].float() + h[:, :, 1].float()).reshape(rows, c)
+        v = (h[:, :, 0].float() + h[:, :, 1].float()).reshape(rows, c)
+        return v if scale == 1.0 else v / scale
 
     def pyramid(self) -> List[torch.Tensor]:
-        """P3, P4, P5 as fp32 rows whatever format the neck wrote them in."""
+        """P3, P4, P5 as fp32 rows whatever format the neck wrote them in (split scales divided out)."""
         ps = [self.p3, self.p4, self.p5]
-        return [self.unsplit(p) for p in ps] if self._neck_split() else ps
+        if not self._neck_split():
+            return ps
+        return [self.unsplit(p, self.sscale.get(k, 1.0)) for p, k in zip(ps, ("p3", "p4", "p5"))]
 
     def _conv(self, a, w, b, c, *, hin, win, cin, lda, n, ldc, k=1, stride=1, act=L.ACT_NONE, res=None, ldres=0,
               res_alpha=1.0, **kw):
@@ -339,6 +356,9 @@ class ImageTower:
                 self._record(q + "ln", self.tmp[: self.M[i] * c])
                 if pre and self.fuse_mlp and L.mlp_fused_supported(self.M[i], c, 4 * c):
                     self._mlp_fused(q, i)       # pwconv1 -> GELU -> pwconv2 -> residual in one kernel: same bits
+                    continue
+                if pre and c in self.fuse_mlp_wide and L.mlp_wide_supported(self.M[i], c, 4 * c):
+                    self._mlp_fused(q, i, wide=True)
                     continue
                 self._conv(self.tmp, q + "w1", q + "b1", self.hid, hin=h, win=w, cin=c, lda=c, n=4 * c, ldc=4 * c,
                            act=L.ACT_GELU, split_flags=(L.SPLIT_A | L.SPLIT_C) if pre else 0,
@@ -486,20 +506,23 @@ class ImageTower:
     NMS_MODES = {"vanilla": L.NMS_VANILLA, "torchvision": L.NMS_TORCHVISION, "mmcv": L.NMS_MMCV}
 
     def postprocess(self, scores: torch.Tensor, score_thr: float, meta: torch.Tensor, iou_thr: float = 0.7,
-                    with_embed: bool = True, nms: str = "vanilla", nms_param: Optional[int] = None) -> Dict[str, torch.Tensor]:
+                    with_embed: bool = True, nms: str = "vanilla", nms_param: Optional[int] = None,
+                    nms_device: str = "cpu") -> Dict[str, torch.Tensor]:
         """scores [B, N, K] -> candidates (score desc, index asc, <= nms_pre) -> class-aware NMS
         -> <= max_out rows per image.  ``meta`` [B, 8] fp32 device tensor, see wd_nms_gather.
         ``nms``: which library's batched NMS is reproduced — "torchvision" (generate_proposal.py:1210; ``nms_param`` =
         the box-coordinate count above which it runs per class, 4000 for CPU tensors), "mmcv" (mmdet's
-        _bbox_post_process, yolo_world_head.py:740-744; ``nms_param`` = split_thr, 10000) or "vanilla" (label test)."""
+        _bbox_post_process, yolo_world_head.py:740-744; ``nms_param`` = split_thr, 10000) or "vanilla" (label test).
+        ``nms_device``: the device kind the reference's tensors would be on — decides torchvision's branch limit default
+        (4000 / 20000 box coordinates) and whether its kernel compares the IoU with a double ("cpu") or a float ("cuda")."""
         B, n, k = scores.shape
         mode = self.NMS_MODES[nms]
         if nms_param is None:
-            nms_param = {L.NMS_VANILLA: 0, L.NMS_TORCHVISION: L.TV_TRICK_MAX_NUMEL["cpu"], L.NMS_MMCV: L.MMCV_SPLIT_THR}[mode]
+            nms_param = {L.NMS_VANILLA: 0, L.NMS_TORCHVISION: L.TV_TRICK_MAX_NUMEL[nms_device], L.NMS_MMCV: L.MMCV_SPLIT_THR}[mode]
         L.topk_candidates(scores, B, n * k, float(np.float32(score_thr)), self.nms_pre, self.cand_idx,
                           self.cand_score, self.cand_count, self.topk_ws)
         L.nms_gather(self.cand_idx, self.cand_score, self.cand_count, self.cap, self.boxes, n, k, meta,
-                     L.nms_threshold(iou_thr, mode), self.max_out, self.embed if with_embed else None, EMBED_DIM,
+                     L.nms_threshold(iou_thr, mode, nms_device), self.max_out, self.embed if with_embed else None, EMBED_DIM,
                      self.out_boxes, self.out_scores, self.out_labels, self.out_anchors, self.out_count,
                      self.out_embed if with_embed else None, B, nms_mode=mode, mode_param=int(nms_param),
                      workspace=self.nms_ws)
@@ -512,7 +535,7 @@ class ImageTower:
     # ------------------------------------------------------------------ fp16x3 range calibration
     SCALE_TARGET_LOG2 = 10       # calibrate() places max |x| of every split tensor at 2^10: 2^6 of headroom below the fp16 maximum
 
-    def calibrate(self, images_u8: torch.Tensor) -> Dict[str, float]:
+    def calibrate(self, images_u8: torch.Tensor, merge: bool = False) -> Dict[str, float]:
         """Choose the power-of-two split scales for this checkpoint's activation ranges from ONE batch.
 
         An fp32 value travels through the fp16x3 GEMMs as hi = fp16(x), lo = fp16(x - hi).  That pair reproduces x to 2^-22
@@ -534,6 +557,7 @@ class ImageTower:
         self.calibrated = True
         if self.precision != "fp16x3":
             return {}
+        self.calibration_runs += 1
         saved = self.precision
         self.precision, self._calib = "fp32", {}
         try:
@@ -549,11 +573,23 @@ class ImageTower:
                 sc = 2.0 ** (self.SCALE_TARGET_LOG2 - math.floor(math.log2(m)) - 1)      # max lands in [2^9, 2^10)
                 if sc != 1.0:
                     new[k] = sc
-        if new != self.sscale:
-            self.sscale = new
+        if merge:
+            # re-calibration after the range guard tripped: never RAISE a scale the earlier batch chose (both batches must
+            # stay below the fp16 maximum) — per tensor the smaller of the two
+            keys = set(new) | set(self.sscale)
+            new = {k: min(new.get(k, 1.0), self.sscale.get(k, 1.0)) for k in keys}
+            new = {k: v for k, v in new.items() if v != 1.0}
+        self.adopt_scales(new)
+        return amax
+
+    def adopt_scales(self, sscale: Dict[str, float]) -> None:
+        """Take split scales chosen elsewhere (another tower of the same checkpoint: detector._TowerHolder calibrates ONCE per
+        checkpoint so that an image gets the same bits whatever batch shape it arrives in)."""
+        self.calibrated = True
+        if dict(sscale) != self.sscale:
+            self.sscale = dict(sscale)
             self._ln_scaled.clear()
             self.generation += 1               # scales are kernel arguments baked into captured graphs
-        return amax
 
     def identity_meta(self) -> torch.Tensor:
         """Letterbox metadata of a network-sized image: pad 0, scale 1, clamp to H x W."""
@@ -571,23 +607,26 @@ class ImageTower:
         return self.head()
 
     def detect(self, images_u8, text, meta, *, normalize_text: bool, score_thr: float, iou_thr: float = 0.7,
-               with_embed: bool = False, nms: Optional[str] = None, nms_param: Optional[int] = None):
+               with_embed: bool = False, nms: Optional[str] = None, nms_param: Optional[int] = None, nms_device: str = "cpu"):
         """The whole step.  ``nms`` None picks the library the reference's path of this text handling uses: normalised
         text = BNContrastiveHead of the mmdet path -> "mmcv"; prompts as stored = the Uni scripts -> "torchvision"."""
         if nms is None:
             nms = "mmcv" if normalize_text else "torchvision"
         self.features(images_u8)
         scores = self.similarity(text, normalize=normalize_text)
-        return self.postprocess(scores, score_thr, meta, iou_thr, with_embed, nms, nms_param)
+        return self.postprocess(scores, score_thr, meta, iou_thr, with_embed, nms, nms_param, nms_device)
 
-    def checked_counts(self, res: Dict[str, torch.Tensor], rerun) -> List[int]:
+    def checked_counts(self, res: Dict[str, torch.Tensor], rerun, recalibrate=None) -> List[int]:
         """Kept-row counts of a step on the host (the one D2H sync a caller needs anyway) with the fp16x3 range guard:
         the fp16x3 GEMMs carry fp32 operands as fp16 (hi, lo) pairs, so an activation beyond 65504 becomes inf.  Every
         fp16x3 launch checks its accumulators in the epilogue and raises the tower's sticky ``range_flag`` on inf / NaN
         (a later ReLU would otherwise turn the NaN into a plausible 0), and the top-k kernel reports non-finite score
         rows as count -1.  When either happens this tower switches to the fp32 MFMA kernels — for good: a checkpoint
         that overflows once will again — and ``rerun()`` (the caller's closure that repeats the step) is executed once
-        more.  Raises if fp32 produces non-finite scores too."""
+        more.  Raises if fp32 produces non-finite scores too.  ``recalibrate``: the caller's closure that re-derives the split
+        scales from THIS batch (detector._TowerHolder.recalibrate: scales only ever go down, every tower of the checkpoint
+        adopts them); it is tried once per trip before the fp32 fallback — a first batch of blank images may have chosen
+        scales under which an ordinary image overflows, which is a calibration problem, not a checkpoint that needs fp32."""
         counts = res["count"].tolist()
         flags = self.range_flags.tolist() if self.precision == "fp16x3" else [0, 0]
         if flags[1] and not self.neck_pin:
@@ -598,11 +637,19 @@ class ImageTower:
                           "run the fp32 MFMA kernel")
             self.neck_pin = True
             self.range_flags.zero_()
-            return self.checked_counts(rerun(), rerun)
+            return self.checked_counts(rerun(), rerun, recalibrate)
         tripped = flags[0] != 0
         if min(counts, default=0) >= 0 and not tripped:
             return counts
         self.range_flags.zero_()
+        if self.precision == "fp16x3" and recalibrate is not None and self.sscale:
+            before = dict(self.sscale)
+            recalibrate()
+            if self.sscale != before:                       # new scales: one more fp16x3 attempt, fp32 only if that trips too
+                import warnings
+                warnings.warn("wedetect_amd: an activation left the fp16 range under the split scales of an earlier batch; "
+                              "re-calibrated on this batch")
+                return self.checked_counts(rerun(), rerun, None)
         if self.precision == "fp32":
             raise L.WedetectHipError("non-finite scores in fp32 mode: the checkpoint or the inputs produce inf / NaN")
         import warnings
@@ -629,7 +676,7 @@ class GraphedDetect:
 
     def __init__(self, tower: ImageTower, num_classes: int, *, normalize_text: bool, score_thr: float,
                  iou_thr: float = 0.7, with_embed: bool = True, warmup: int = 2, nms: Optional[str] = None,
-                 nms_param: Optional[int] = None):
+                 nms_param: Optional[int] = None, nms_device: str = "cpu"):
         self.tower = tower
         dev = tower.dev
         self.images = torch.zeros(tower.B, tower.H, tower.W, 3, dtype=torch.uint8, device=dev)
@@ -637,7 +684,7 @@ class GraphedDetect:
         self.text[:, 0] = 1.0
         self.meta = tower.identity_meta()
         kw = dict(normalize_text=normalize_text, score_thr=score_thr, iou_thr=iou_thr, with_embed=with_embed, nms=nms,
-                  nms_param=nms_param)
+                  nms_param=nms_param, nms_device=nms_device)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # one-time kernel attribute setup + buffer growth

@@ -20,9 +20,12 @@ LIB_PATH = os.environ.get("WEDETECT_LIB") or os.path.join(_HERE, "libwedetect_hi
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU = 0, 1, 2, 3
 OUT_ROWS, OUT_DECONV2X2 = 0, 1
 SPLIT_A, SPLIT_C = 1, 2
-ABI_VERSION = 10
+ABI_VERSION = 11
 NMS_VANILLA, NMS_TORCHVISION, NMS_MMCV = 0, 1, 2
-TV_TRICK_MAX_NUMEL = {"cpu": 4000, "cuda": 20000}   # torchvision/ops/boxes.py batched_nms: vanilla above this many box coordinates
+# torchvision/ops/boxes.py batched_nms: the per-class loop (_batched_nms_vanilla) above this many box coordinates
+# (boxes.numel()).  4000 / 20000 are the values of torchvision 0.15 ... 0.21 (the releases contemporary with the
+# reference's torch 2.x pins; newer releases raised the GPU limit to 100000 — set nms_param explicitly to reproduce those).
+TV_TRICK_MAX_NUMEL = {"cpu": 4000, "cuda": 20000}
 MMCV_SPLIT_THR = 10000                                 # mmcv/ops/nms.py batched_nms: per-class loop from this many candidates
 
 EXPORTS = (
@@ -31,7 +34,7 @@ EXPORTS = (
     "wd_topk_candidates", "wd_nms_workspace_bytes", "wd_nms_gather", "wd_retrieval_max",
     "wd_split_weights_bytes", "wd_split_weights", "wd_conv_gemm_split", "wd_conv_gemm_split_ws", "wd_conv_gemm_split_config", "wd_layernorm_rows_split", "wd_layernorm_rows_split_s2d", "wd_letterbox_u8", "wd_retrieval_max_split", "wd_text_embed", "wd_attention_small", "wd_recall_scratch_floats", "wd_recall_match",
     "wd_max_sigmoid_attn", "wd_adaptive_maxpool_nhwc", "wd_cross_attention_small", "wd_time_next_gemm",
-    "wd_cv_resize_paste_u8", "wd_chw_to_hwc_u8", "wd_p8_workspace_bytes", "wd_dwconv7_ln", "wd_probe_lds_dma", "wd_probe_issue", "wd_mlp_fused_split", "wd_stem_fused",
+    "wd_cv_resize_paste_u8", "wd_chw_to_hwc_u8", "wd_p8_workspace_bytes", "wd_dwconv7_ln", "wd_probe_lds_dma", "wd_probe_issue", "wd_mlp_fused_split", "wd_mlp_fused_wide", "wd_stem_fused",
 )
 
 
@@ -117,6 +120,7 @@ def _load():
     lib.wd_chw_to_hwc_u8.argtypes = [vp, i32, vp, i32, i32, i32, vp]
     lib.wd_dwconv7_ln.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]
     lib.wd_mlp_fused_split.argtypes = [vp, i64, i32, i32, vp, f32, vp, vp, f32, vp, vp, f32, vp, vp]
+    lib.wd_mlp_fused_wide.argtypes = [vp, i64, i32, i32, vp, f32, vp, vp, f32, vp, vp, f32, vp, vp]
     lib.wd_stem_fused.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, i32, f32, vp, vp]
     lib.wd_probe_issue.argtypes = [i32, i32, i32, i32, i32, vp, vp, vp]
     lib.wd_probe_lds_dma.argtypes = [vp, i64, i32, i32, i32, i32, vp, vp]
@@ -193,6 +197,31 @@ def conv_gemm(a, w, bias, c, *, batch, hin, win, cin, lda, kh=1, kw=1, stride=1,
 
 def mlp_fused_supported(rows: int, c: int, hidden: int) -> bool:
     return c == 128 and hidden == 512 and rows > 0 and rows % 128 == 0
+
+
+MLP_WIDE_WIDTHS = (256, 512)
+
+
+def mlp_wide_supported(rows: int, c: int, hidden: int) -> bool:
+    return c in MLP_WIDE_WIDTHS and hidden == 4 * c and rows > 0 and rows % 128 == 0
+
+
+def mlp_wide_pack(w_split: torch.Tensor, n: int, k: int) -> torch.Tensor:
+    """wd_split_weights buffer of an [n][k] matrix ([n][k / 8][hi x8 | lo x8] 32-byte groups) -> FRAGMENT-MAJOR order for
+    wd_mlp_fused_wide: [n / 32][k / 16][2 (hi, lo)][64 lanes = (k half) * 32 + (row in block)][16 B] — one MFMA operand of a
+    wave is one contiguous 1 KB.  Pack time only."""
+    if n % 32 or k % 16 or w_split.numel() != n * k * 4:
+        raise WedetectHipError(f"mlp_wide_pack: [{n}][{k}] is not a whole number of 32 x 16 fragments")
+    v = w_split.view(n // 32, 32, k // 16, 2, 2, 16)               # [block, row, k16 step, k half, part, bytes]
+    return v.permute(0, 2, 4, 3, 1, 5).contiguous().view(-1)
+
+
+def mlp_fused_wide(a_split, rows, c, hidden, w1_frag, b1, w2_frag, b2, x, hid_scale=1.0, range_flag=None) -> None:
+    """x <- x + W2 GELU(W1 a + b1) + b2 in one kernel for c = 256 / 512 (wd_mlp_fused_wide); ``w*_frag`` = (fragment-major
+    buffer from mlp_wide_pack, unscale) pairs."""
+    check(LIB.wd_mlp_fused_wide(_p(a_split), rows, c, hidden, _p(w1_frag[0]), float(w1_frag[1]), _p(b1), _p(w2_frag[0]),
+                                float(w2_frag[1]), _p(b2), _p(x), float(hid_scale), _p(range_flag), stream_ptr()),
+          "wd_mlp_fused_wide")
 
 
 def mlp_fused(a_split, rows, c, hidden, w1_split, b1, w2_split, b2, x, hid_scale=1.0, range_flag=None) -> None:
@@ -328,13 +357,16 @@ def nms_workspace_bytes(batch: int) -> int:
     return LIB.wd_nms_workspace_bytes(batch)
 
 
-def nms_threshold(iou_thr: float, nms_mode: int) -> float:
+def nms_threshold(iou_thr: float, nms_mode: int, device_kind: str = "cpu") -> float:
     """The fp32 value whose ``ovr > value`` decides like the library's own comparison: mmcv's nms_cpu takes a C++
-    ``float`` (nearest); torchvision's nms_kernel_impl compares the fp32 IoU with a C++ ``double``, i.e. like the
-    largest fp32 <= the Python value (include/wedetect_hip.h, wd_nms_gather)."""
+    ``float`` (nearest); torchvision's CPU nms_kernel_impl compares the fp32 IoU with a C++ ``double``, i.e. like the
+    largest fp32 <= the Python value (include/wedetect_hip.h, wd_nms_gather); torchvision's GPU kernel (nms_kernel.cu)
+    takes the threshold as a ``float`` (``device_kind`` "cuda": nearest, like mmcv)."""
     import numpy as np
+    if device_kind not in TV_TRICK_MAX_NUMEL:
+        raise ValueError(f"device_kind must be one of {sorted(TV_TRICK_MAX_NUMEL)}, not {device_kind!r}")
     t = np.float32(iou_thr)
-    if nms_mode == NMS_TORCHVISION and float(t) > float(iou_thr):
+    if nms_mode == NMS_TORCHVISION and device_kind == "cpu" and float(t) > float(iou_thr):
         t = np.nextafter(t, np.float32(-np.inf), dtype=np.float32)
     return float(t)
 
