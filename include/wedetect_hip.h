@@ -171,10 +171,14 @@ int wd_mlp_fused_split(const void* a_split, int64_t rows, int32_t c, int32_t hid
  * chunks of 128 columns that pass through LDS only.  rows % 128 == 0.  w1_frag / w2_frag: the wd_split_weights buffers of
  * W1 [hidden][c] / W2 [c][hidden] re-ordered FRAGMENT-MAJOR at pack time — [n / 32][k / 16][2 (hi, lo)][64][16 B], lane
  * (k half) * 32 + (row in block) — so that a wave's MFMA operand is one contiguous 1 KB load from global memory (the
- * weights never touch LDS).  Same halves, same K order, same epilogue arithmetic: bit-identical to the two-launch chain. */
+ * weights never touch LDS).  Same halves, same K order, same epilogue arithmetic: bit-identical to the two-launch chain.
+ * workspace (optional, 16-byte aligned, wd_p8_workspace_bytes() bytes, zero-filled once before its first use — the park
+ * workspace of the persistent 256 x 256 kernel serves): with more row blocks than CUs the kernel then runs one workgroup per
+ * CU over contiguous ranges of (row block, hidden chunk) units, a row block cut between two CUs is handed over through
+ * parked accumulators (same MFMA chain: still bit-identical). */
 int wd_mlp_fused_wide(const void* a_split, int64_t rows, int32_t c, int32_t hidden, const void* w1_frag, float w1_unscale,
                       const float* b1, const void* w2_frag, float w2_unscale, const float* b2, float* x, float hid_scale,
-                      uint32_t* range_flag, void* stream);
+                      uint32_t* range_flag, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Name of the tile wd_conv_gemm_split picks with cfg < 0 for an (m, n, k) problem; is_conv != 0:
  * not a 1x1 / stride 1 / pad 0 layer (diagnostic). */

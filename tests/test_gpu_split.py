@@ -575,7 +575,7 @@ def test_fused_mlp_bit_identical_to_the_two_kernel_chain(m, hid_scale):
     assert float((got.double() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
 
 
-@pytest.mark.parametrize("c,m", [(512, 128), (512, 128 * 9), (512, 51200), (256, 128), (256, 128 * 37)])
+@pytest.mark.parametrize("c,m", [(512, 128), (512, 128 * 9), (512, 51200), (512, 128 * 257), (256, 128), (256, 128 * 37), (256, 128 * 300)])
 @pytest.mark.parametrize("hid_scale", [1.0, 0.25])
 def test_fused_mlp_wide_bit_identical_to_the_two_kernel_chain(c, m, hid_scale):
     """wd_mlp_fused_wide (round 4: the block MLP of the 256 / 512-channel stages as one kernel — output tile in the four
@@ -600,11 +600,15 @@ def test_fused_mlp_wide_bit_identical_to_the_two_kernel_chain(c, m, hid_scale):
     L.conv_gemm(hid, None, b2, want, w_split=ws2s, batch=1, hin=1, win=m, cin=h, lda=h, n=c, ldc=c, res=want, ldres=c,
                 split_flags=L.SPLIT_A)
     flag = torch.zeros(1, dtype=torch.int32, device="cuda")
-    for _ in range(3):
-        got = x0.clone()
-        L.mlp_fused_wide(xs, m, c, h, wf1, b1, wf2, b2, got, hid_scale=hid_scale, range_flag=flag)
-        torch.cuda.synchronize()
-        assert torch.equal(got.view(torch.int32), want.view(torch.int32)), f"max|d| {float((got - want).abs().max())}"
+    # with the park workspace and more row blocks than CUs: the persistent form (a row block cut between two CUs)
+    park = torch.zeros(L.p8_workspace_bytes() // 4, dtype=torch.float32, device="cuda")
+    for ws in (None, park):
+        for _ in range(3):
+            got = x0.clone()
+            L.mlp_fused_wide(xs, m, c, h, wf1, b1, wf2, b2, got, hid_scale=hid_scale, range_flag=flag, workspace=ws)
+            torch.cuda.synchronize()
+            assert torch.equal(got.view(torch.int32), want.view(torch.int32)), f"workspace {ws is not None}: max|d| {float((got - want).abs().max())}"
+            assert int(park[:1024].view(torch.int32).abs().max()) == 0, "flag words must be zero again after a launch"
     assert int(flag.item()) == 0
     if m <= 128 * 37:                                             # and it is a real MLP: against float64
         y = torch.nn.functional.layer_norm(x0.double(), (c,), g.double(), b.double(), 1e-6)

@@ -76,12 +76,16 @@ class ImageTower:
         self.park = None
         if precision == "fp16x3" and self.p8_mode == "persist" and L.p8_workspace_bytes() > 0:
             self.park = torch.zeros(L.p8_workspace_bytes() // 4, dtype=torch.float32, device=torch.device(device))
+        self._park_mlp = None                    # park workspace of the persistent wide fused MLP (the same layout; shared with self.park)
         self.B, self.H, self.W = batch, height, width
         self.fuse_stem = os.environ.get("WEDETECT_FUSE_STEM", "1") == "1"      # stem as one fp32 kernel (bit-identical to the fp32 three-launch form)
         self.fuse_mlp = os.environ.get("WEDETECT_FUSE_MLP", "1") == "1"        # stage-1 block MLP as one kernel (bit-identical; profiles/r03_mlp_fused.txt)
         # round 4: the block MLP of the 256 / 512-channel stages as one kernel too (wd_mlp_fused_wide, bit-identical):
         # comma-separated widths, "" = none
-        self.fuse_mlp_wide = tuple(int(v) for v in os.environ.get("WEDETECT_FUSE_MLP_WIDE", "").split(",") if v.strip())
+        # comma-separated widths, "" = none.  Default "256": on the stage-2 shape the fused persistent kernel is 7 % faster than
+        # the two launches (750 vs 804 us per block), on the stage-3 shape (512 channels) still 2-3 % slower (670 vs 654 us) —
+        # profiles/r04_mlp_wide.txt
+        self.fuse_mlp_wide = tuple(int(v) for v in os.environ.get("WEDETECT_FUSE_MLP_WIDE", "256").split(",") if v.strip())
         self.Wf: Dict[str, tuple] = {}           # fragment-major weight copies of those layers (lib.mlp_wide_pack)
         # dwconv -> LayerNorm in one kernel: "auto" = the stages of <= 128 channels, where the pre-norm values stay in registers
         # (profiles/r03_dwln_reg.txt); "1" = every stage (the wide ones through L2: slower, profiles/r02_dwln_ab.txt); "0" = never
@@ -274,9 +278,15 @@ class ImageTower:
                 s_ = f_
             ws.append(s_)
         sa, sh = self.sscale.get(q + "ln", 1.0), self.sscale.get(q + "hid", 1.0)
+        kw = {}
+        if wide:
+            if self._park_mlp is None:
+                self._park_mlp = self.park if self.park is not None else torch.zeros(
+                    max(1, L.p8_workspace_bytes() // 4), dtype=torch.float32, device=self.dev)
+            kw["workspace"] = self._park_mlp
         fn = L.mlp_fused_wide if wide else L.mlp_fused
         fn(self.tmp, self.M[i], c, 4 * c, (ws[0][0], ws[0][1] / sa), self.P[q + "b1"], (ws[1][0], ws[1][1] / sh),
-           self.P[q + "b2"], self.x[i], hid_scale=sh, range_flag=self.range_flag)
+           self.P[q + "b2"], self.x[i], hid_scale=sh, range_flag=self.range_flag, **kw)
 
     def _neck_split(self) -> bool:
         """Is the neck / head running on pre-split activations in this step?  Not when the tower fell back to fp32 kernels,

@@ -120,7 +120,7 @@ def _load():
     lib.wd_chw_to_hwc_u8.argtypes = [vp, i32, vp, i32, i32, i32, vp]
     lib.wd_dwconv7_ln.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]
     lib.wd_mlp_fused_split.argtypes = [vp, i64, i32, i32, vp, f32, vp, vp, f32, vp, vp, f32, vp, vp]
-    lib.wd_mlp_fused_wide.argtypes = [vp, i64, i32, i32, vp, f32, vp, vp, f32, vp, vp, f32, vp, vp]
+    lib.wd_mlp_fused_wide.argtypes = [vp, i64, i32, i32, vp, f32, vp, vp, f32, vp, vp, f32, vp, vp, i64, vp]
     lib.wd_stem_fused.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, i32, f32, vp, vp]
     lib.wd_probe_issue.argtypes = [i32, i32, i32, i32, i32, vp, vp, vp]
     lib.wd_probe_lds_dma.argtypes = [vp, i64, i32, i32, i32, i32, vp, vp]
@@ -216,11 +216,14 @@ def mlp_wide_pack(w_split: torch.Tensor, n: int, k: int) -> torch.Tensor:
     return v.permute(0, 2, 4, 3, 1, 5).contiguous().view(-1)
 
 
-def mlp_fused_wide(a_split, rows, c, hidden, w1_frag, b1, w2_frag, b2, x, hid_scale=1.0, range_flag=None) -> None:
+def mlp_fused_wide(a_split, rows, c, hidden, w1_frag, b1, w2_frag, b2, x, hid_scale=1.0, range_flag=None, workspace=None) -> None:
     """x <- x + W2 GELU(W1 a + b1) + b2 in one kernel for c = 256 / 512 (wd_mlp_fused_wide); ``w*_frag`` = (fragment-major
-    buffer from mlp_wide_pack, unscale) pairs."""
+    buffer from mlp_wide_pack, unscale) pairs.  ``workspace``: a zero-initialised fp32 tensor of p8_workspace_bytes() bytes
+    selects the persistent form when there are more row blocks than CUs."""
+    ws_bytes = 0 if workspace is None else workspace.numel() * workspace.element_size()
     check(LIB.wd_mlp_fused_wide(_p(a_split), rows, c, hidden, _p(w1_frag[0]), float(w1_frag[1]), _p(b1), _p(w2_frag[0]),
-                                float(w2_frag[1]), _p(b2), _p(x), float(hid_scale), _p(range_flag), stream_ptr()),
+                                float(w2_frag[1]), _p(b2), _p(x), float(hid_scale), _p(range_flag), _p(workspace), ws_bytes,
+                                stream_ptr()),
           "wd_mlp_fused_wide")
 
 
