@@ -44,6 +44,7 @@ sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 F16_MFMA_PEAK_TFLOPS = 2516.6    # MI355X_MICROARCH.md: fp16/bf16 dense (v_mfma_f32_32x32x16_f16)
+PEAK_CLOCK_MHZ = 2400.0          # the clock those peaks are quoted at
 SPLIT_PASSES = 3                 # fp16x3: hi*hi + hi*lo + lo*hi per fp32-accurate product
 # bench tag -> kernel symbol in the rocprofv3 traces / profiles/r01_traffic.json
 KERNEL_SYMBOL = {
@@ -207,12 +208,70 @@ class GemmTimer:
 
     def summary(self):
         out = {}
+        merged = {}
         for tag, lst in self.rec.items():
+            # the tile form and the persistent (gang-scheduled) form of the 256 x 256 kernel are one family: same tiles, same
+            # MFMA chain, chosen per layer (K >= 512 and enough tiles -> persistent)
+            merged.setdefault(tag.replace("/p8s/", "/p8/"), []).extend(lst)
+        for tag, lst in merged.items():
             ms = sum(r[0].elapsed_time(r[1]) for r in lst)
             fl = sum(r[2] for r in lst)
             out[tag] = dict(launches=len(lst), ms_total=ms, flops_total=fl, bytes_total=sum(r[3] for r in lst),
                             avg_us=1e3 * ms / len(lst), tflops=fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0)
         return out
+
+
+class ClockSampler:
+    """Shader clock of the benchmarked device during the timed region, from the driver's own sysfs node
+    (/sys/class/drm/card*/device/pp_dpm_sclk: the starred line is the current GFX clock), sampled every 10 ms by a host
+    thread.  The dominant kernels run power-limited (1.8 - 2.0 GHz against the 2.4 GHz the MFMA peaks are quoted at); this
+    puts that figure into the bench line itself instead of deriving it from GRBM_GUI_ACTIVE in a separate profile."""
+
+    def __init__(self, device_index: int):
+        import glob
+        self.path, self.samples, self._stop, self._th = None, [], False, None
+        try:
+            p = torch.cuda.get_device_properties(device_index)
+            want = f"{int(getattr(p, 'pci_domain_id', 0)):04x}:{int(p.pci_bus_id):02x}:{int(p.pci_device_id):02x}."
+            for node in sorted(glob.glob("/sys/class/drm/card*/device")):
+                if os.path.basename(os.path.realpath(node)).startswith(want) and os.path.exists(node + "/pp_dpm_sclk"):
+                    self.path = node + "/pp_dpm_sclk"
+                    break
+        except Exception:
+            self.path = None
+
+    def _read(self):
+        try:
+            for line in open(self.path).read().splitlines():
+                if line.rstrip().endswith("*"):
+                    return float(line.split(":")[1].strip().split("M")[0])
+        except Exception:
+            pass
+        return None
+
+    def start(self):
+        import threading
+        if self.path is None:
+            return
+
+        def loop():
+            while not self._stop:
+                v = self._read()
+                if v is not None:
+                    self.samples.append(v)
+                time.sleep(0.01)
+        self._th = threading.Thread(target=loop, daemon=True)
+        self._th.start()
+
+    def stop(self):
+        self._stop = True
+        if self._th is not None:
+            self._th.join(timeout=1.0)
+        busy = [v for v in self.samples if v > 600.0]            # drop the idle / sleep states around the region
+        if not busy:
+            return None
+        return {"mean_mhz": round(sum(busy) / len(busy), 1), "min_mhz": min(busy), "max_mhz": max(busy), "samples": len(busy),
+                "source": self.path}
 
 
 def usable_cores() -> int:
@@ -454,6 +513,8 @@ def main():
     n_inst = min(args.steps, 1 if args.steps < 4 else 2)
     timer.prepare(timer.count // max(1, args.warmup) * n_inst)
     timer.mode = "off"
+    clock = ClockSampler(local)
+    clock.start()
     t0 = time.perf_counter()
     for i in range(args.steps):
         if i == args.steps - n_inst:
@@ -461,8 +522,10 @@ def main():
         res = step(measure_stall=world > 1)
     sync()
     dt = time.perf_counter() - t0
+    clk = clock.stop()
     timer.mode = "off"
     per_rank = None
+    ranks_seen, backend_name = 1, None
     if dist is not None:
         own = dict(rank=rank, ms_per_step=round(1e3 * dt / args.steps, 3),
                    gather_handover_ms_per_step=round(sum(a.elapsed_time(b) for a, b in stall) / max(1, len(stall)), 3))
@@ -471,6 +534,9 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        one = torch.ones(1, dtype=torch.int32, device="cuda")    # how many ranks the collective library actually joined
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        ranks_seen, backend_name = int(one.item()), str(dist.get_backend())
     kept = int(res["count"].sum().item())
     overflow = bool((res["count"] < 0).any().item()) or bool(tower.range_flags.any().item())     # fp16x3 range guards
 
@@ -519,6 +585,12 @@ def main():
             "roofline": {"kernel": dom_kernel, "bound": "mfma",
                          "achieved": round(dom["tflops"], 2), "peak": dom_peak, "unit": "TFLOP/s",
                          "frac": round(dom["tflops"] / dom_peak, 4),
+                         **({"effective_mhz": clk["mean_mhz"], "effective_mhz_min_max": [clk["min_mhz"], clk["max_mhz"]],
+                             "clock_samples": clk["samples"], "clock_source": clk["source"], "peak_quoted_at_mhz": PEAK_CLOCK_MHZ,
+                             "frac_at_effective_clock": round(dom["tflops"] / dom_peak * PEAK_CLOCK_MHZ / clk["mean_mhz"], 4),
+                             "clock_note": "shader clock sampled every 10 ms from sysfs during the timed steps: the chip is "
+                                           "power-limited in this step; frac stays against the spec peak"} if clk else
+                            {"effective_mhz": None}),
                          **({"peak_note": f"fp16 dense MFMA peak {F16_MFMA_PEAK_TFLOPS} / {SPLIT_PASSES} passes per product",
                              "mfma_issued_tflops": round(SPLIT_PASSES * dom["tflops"], 1),
                              "frac_of_fp16_peak": round(SPLIT_PASSES * dom["tflops"] / F16_MFMA_PEAK_TFLOPS, 4)} if dom_split else {}),
@@ -544,6 +616,8 @@ def main():
             out["host_fed"] = host_fed_run(tower, images, text, meta, uni, min(args.steps, 20))
         if per_rank is not None:
             out["per_rank"] = per_rank
+            out["ranks_seen"] = ranks_seen          # all_reduce(1) over the job's process group: the collective library saw this many
+            out["collective_backend"] = backend_name
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.arch, S, K, args.cpu_runs)
         print(json.dumps(out), flush=True)

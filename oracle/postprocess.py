@@ -114,12 +114,13 @@ def batched_nms(boxes: np.ndarray, scores: np.ndarray, labels: np.ndarray, thr: 
                 sup = _iou_f32(boxes[i], boxes[rest]).astype(np.float64) > float(thr)
             suppressed[rest[sup]] = True
             if stats is not None:
-                ovr = _iou_f32(boxes[i], boxes[rest]).astype(np.float64)
+                rel = rest <= stats.get("rmax", n)           # effective margins: only candidates that can reach the output
+                ovr = _iou_f32(boxes[i], boxes[rest[rel]]).astype(np.float64)
                 ovr = ovr[np.isfinite(ovr)]
                 if ovr.size:
                     iou_margin = min(iou_margin, float(np.min(np.abs(ovr - float(f32(thr))))))
-                if np.any(sup):
-                    pair_gap = min(pair_gap, float(np.min(scores[i].astype(np.float64) - scores[rest[sup]].astype(np.float64))))
+                if np.any(sup & rel):
+                    pair_gap = min(pair_gap, float(np.min(scores[i].astype(np.float64) - scores[rest[sup & rel]].astype(np.float64))))
     if stats is not None:
         ks = scores[np.asarray(keep, dtype=np.int64)].astype(np.float64) if keep else np.zeros(0)
         stats["iou_margin"] = iou_margin if np.isfinite(iou_margin) else 1.0
@@ -178,13 +179,14 @@ def nms_greedy(boxes: np.ndarray, scores: np.ndarray, thr: float, compare: str =
         sup = (ovr.astype(np.float64) > t64) if compare == "double" else (ovr > t32)
         suppressed[rest[sup]] = True
         if stats is not None:
-            o64 = ovr.astype(np.float64)
+            rel = rest <= stats.get("rmax", n)               # effective margins (sorted input: position = candidate rank)
+            o64 = ovr.astype(np.float64)[rel]
             o64 = o64[np.isfinite(o64)]
             if o64.size:
                 iou_margin = min(iou_margin, float(np.min(np.abs(o64 - (t64 if compare == "double" else float(t32))))))
-            if np.any(sup):
+            if np.any(sup & rel):
                 ss = scores[order]
-                pair_gap = min(pair_gap, float(np.min(ss[_i].astype(np.float64) - ss[rest[sup]].astype(np.float64))))
+                pair_gap = min(pair_gap, float(np.min(ss[_i].astype(np.float64) - ss[rest[sup & rel]].astype(np.float64))))
     _merge_stats(stats, iou_margin, pair_gap)
     return order[np.asarray(keep, dtype=np.int64)]
 
@@ -281,6 +283,25 @@ def cut_gap(scores: np.ndarray, score_thr: float, topk: int) -> float:
     return float(part[valid.shape[0] - topk:].min().astype(np.float64) - part[valid.shape[0] - topk - 1].astype(np.float64))
 
 
+def effective_margins(nms_fn, s: np.ndarray, n_keep: int, cut: float) -> np.ndarray:
+    """Decision margins restricted to what can change the FIRST ``n_keep`` output rows — [iou, pair, kept, cut] like the
+    ``margins`` of the predict functions, which take every decision of the whole candidate list (30 000 candidates, millions
+    of IoU tests: some decision always sits inside fp32 noise although it can never reach the output).  ``nms_fn(stats,
+    max_keep)`` runs the image's batched NMS on its (sorted) candidates.  A decision matters only if it involves a candidate
+    ranked at or before the (n_keep + 1)-th keeper — the first row that is NOT output: later candidates cannot enter the
+    first n_keep rows whatever happens to them.  iou / pair: over the IoU tests of the first n_keep + 1 keepers against
+    candidates up to that rank; kept: the gaps between consecutive keepers including the one to the first row left out
+    (a swap there changes membership); cut: the nms_pre gap only if NMS ran out of candidates before n_keep + 1 keepers."""
+    keep = nms_fn(None, n_keep + 1)
+    exhausted = keep.shape[0] <= n_keep
+    stats = {"rmax": int(s.shape[0]) if exhausted else int(keep[n_keep])}
+    keep2 = nms_fn(stats, n_keep + 1)
+    assert np.array_equal(keep, keep2)
+    ks = s[keep].astype(np.float64)
+    kept = float(np.min(-np.diff(ks))) if ks.size > 1 else 1.0
+    return np.asarray([stats.get("iou_margin", 1.0), stats.get("pair_gap", 1.0), kept, cut if exhausted else 1.0], dtype=np.float64)
+
+
 def unletterbox(boxes: np.ndarray, pad_xy: Tuple[float, float], ratio: float,
                 ori_hw: Tuple[int, int], rescale: bool = True) -> np.ndarray:
     """generate_proposal.py:1106-1115: subtract (dw, dh), divide by ratio, clamp."""
@@ -296,7 +317,7 @@ def unletterbox(boxes: np.ndarray, pad_xy: Tuple[float, float], ratio: float,
 def uni_predict_image(boxes: np.ndarray, embed: np.ndarray, scores: np.ndarray,
                       level_of: np.ndarray, logit_scale: np.ndarray, contrast_bias: np.ndarray,
                       num_proposals: int = 300, nms_pre: int = 30000, iou_thr: float = 0.7,
-                      score_thr: float = 0.0, device_type: str = "cpu") -> Dict[str, np.ndarray]:
+                      score_thr: float = 0.0, device_type: str = "cpu", effective: bool = False) -> Dict[str, np.ndarray]:
     """One image of SimpleYOLOWorldDetector.head_predict (generate_proposal.py:1197-1217,
     with the extra outputs of extract_embedding.py:1247-1259).  Boxes stay in
     letterboxed network coordinates (NMS runs before the un-letterbox there);
@@ -309,9 +330,14 @@ def uni_predict_image(boxes: np.ndarray, embed: np.ndarray, scores: np.ndarray,
     stats["cut_gap"] = cut_gap(scores, score_thr, nms_pre)
     a = anchors[keep]
     lv = level_of[a]
-    return dict(bboxes=cand_boxes[keep], embeddings=embed[a], scores=s[keep], labels=labels[keep],
-                anchors=a, scales=logit_scale[lv].astype(f32), bias=contrast_bias[lv].astype(f32),
-                num_candidates=np.int64(s.shape[0]), keep=keep, margins=stats)
+    out = dict(bboxes=cand_boxes[keep], embeddings=embed[a], scores=s[keep], labels=labels[keep],
+               anchors=a, scales=logit_scale[lv].astype(f32), bias=contrast_bias[lv].astype(f32),
+               num_candidates=np.int64(s.shape[0]), keep=keep, margins=stats)
+    if effective:
+        out["eff_margins"] = effective_margins(
+            lambda st, mk: torchvision_batched_nms(cand_boxes, s, labels, iou_thr, device_type, st, max_keep=mk),
+            s, num_proposals, stats["cut_gap"])
+    return out
 
 
 def rescale_boxes(b: np.ndarray, pad_xy, scale_xy) -> np.ndarray:
@@ -346,7 +372,8 @@ def mmdet_predict_image_from_candidates(cand_boxes, s, labels, pad_param, scale_
 
 def mmdet_predict_image(boxes: np.ndarray, scores: np.ndarray, pad_param, scale_factor,
                         ori_hw: Tuple[int, int], score_thr: float = 0.001, nms_pre: int = 30000,
-                        iou_thr: float = 0.7, max_per_img: int = 300, nms_cfg: Optional[dict] = None) -> Dict[str, np.ndarray]:
+                        iou_thr: float = 0.7, max_per_img: int = 300, nms_cfg: Optional[dict] = None,
+                        effective: bool = False) -> Dict[str, np.ndarray]:
     """One image of YOLOWorldHead.predict_by_feat, multi_label=True
     (yolo_world_head.py:680-748): filter/top-k, rescale to original pixels, THEN NMS,
     [:max_per_img], clamp."""
@@ -357,7 +384,14 @@ def mmdet_predict_image(boxes: np.ndarray, scores: np.ndarray, pad_param, scale_
                                             iou_thr, max_per_img, nms_cfg)
     keep = r["keep"]
     r["margins"]["cut_gap"] = cut_gap(scores, score_thr, nms_pre)
-    return dict(bboxes=r["bboxes"], scores=s[keep], labels=labels[keep], anchors=anchors[keep], margins=r["margins"])
+    out = dict(bboxes=r["bboxes"], scores=s[keep], labels=labels[keep], anchors=anchors[keep], margins=r["margins"])
+    if effective:
+        pad = (0.0, 0.0) if pad_param is None else (pad_param[2], pad_param[0])
+        b = rescale_boxes(boxes[anchors].astype(f32), pad, scale_factor)
+        cfg = dict(type="nms", iou_threshold=iou_thr) if nms_cfg is None else nms_cfg
+        out["eff_margins"] = effective_margins(lambda st, mk: mmcv_batched_nms(b, s, labels, cfg, st, max_keep=mk),
+                                               s, max_per_img, r["margins"]["cut_gap"])
+    return out
 
 
 def retrieval_scores(embedding: np.ndarray, text: np.ndarray, scale: np.ndarray,

@@ -291,10 +291,55 @@ def _margins(o) -> np.ndarray:
     return np.asarray([m["iou_margin"], m["pair_gap"], m["kept_gap"], m["cut_gap"]], dtype=np.float64)
 
 
+# ------------------------------------------------------------------ margin-robust cases (round 4)
+# B = 1 @ 640 images whose post-process decisions are far from flipping, found by a seed search with the ORACLE's network
+# (bit-identical to the reference, asserted again on the chosen seed by case_network): for each path (mmdet K-class /
+# Uni 256 prompts) the seed with the largest kept-row gap among those whose EFFECTIVE iou / pair / cut margins exceed
+# ROBUST_MIN (oracle.postprocess.effective_margins: only decisions that can reach the first 300 output rows count — over
+# all 30 000 candidates and millions of IoU tests some decision always sits inside fp32 noise, which is why the round-3
+# margins were "within noise" for 29 of 33 cases although nothing ever flipped).  The kept-row gap itself cannot reach
+# ROBUST_MIN: 300 sigmoid scores of one image are nearly continuous (best of 120 seeds: 8e-6, about 6 x the measured
+# score noise); a swap there permutes two output rows and is the counted tie-run relaxation of tests/util.py.
+ROBUST_MIN = 2e-5
+# (seed_img_mm, seed_img_uni) per arch: output of `make_golden.py --search-robust ARCH K` (kept in the file so that the
+# fixtures regenerate without repeating the search)
+ROBUST_SEEDS = {"base": (5008, 5020), "large": (5027, 5055)}
+
+
+def search_robust(arch, k_text, start=5000, trials=120):
+    sd_np = W.make_state_dict(arch, seed=2026, num_prompts=256)
+    sd = orc.to_torch(sd_np)
+    a = get_arch(arch)
+    text = torch.from_numpy(W.make_text_bank(k_text) * np.float32(1.7))
+    ls = np.asarray([sd[HD + f"cls_contrasts.{l}.logit_scale"].item() for l in range(3)], dtype=np.float32)
+    cb = np.asarray([sd[HD + f"cls_contrasts.{l}.bias"].item() for l in range(3)], dtype=np.float32)
+    pad, sf, ori = (8.0, 8.0, 0.0, 0.0), (0.5, 0.5), (int((640 - 16) / 0.5), int(640 / 0.5))
+    best = {"mm": (-1.0, None), "uni": (-1.0, None)}
+    for seed in range(start, start + trials):
+        imgs = W.make_images(1, 640, 640, seed=seed)
+        _, p = orc.forward_features(sd, a, imgs)
+        fm = orc.head_flat(sd, p, text[None], normalize_text=True)
+        em = opp.mmdet_predict_image(fm["boxes"][0].numpy(), fm["scores"][0].numpy(), pad, sf, ori, effective=True)["eff_margins"]
+        fu = orc.head_flat(sd, p, sd["embeddings"], normalize_text=False)
+        eu = opp.uni_predict_image(fu["boxes"][0].numpy(), fu["embed"][0].numpy(), fu["scores"][0].numpy(), fu["level_of"].numpy(),
+                                   ls, cb, effective=True)["eff_margins"]
+        for key, e in (("mm", em), ("uni", eu)):
+            if min(e[0], e[1], e[3]) > ROBUST_MIN and e[2] > best[key][0]:
+                best[key] = (float(e[2]), seed)
+        print(f"seed {seed}: mm eff {em}  uni eff {eu}   best so far {best}", flush=True)
+    return best
+
+
+def case_robust(gp, arch, k_text):
+    s_mm, s_uni = ROBUST_SEEDS[arch]
+    case_network(gp, arch, 1, 640, seed_img=s_mm, k_text=k_text, out_tag=f"{arch}_b1_640_robust_mm")
+    case_network(gp, arch, 1, 640, seed_img=s_uni, k_text=k_text, out_tag=f"{arch}_b1_640_robust_uni")
+
+
 # ------------------------------------------------------------------ cases
-def case_network(gp, arch, b, hw, seed_w=2026, seed_img=1234, num_prompts=256, full_predict=True, k_text=80):
+def case_network(gp, arch, b, hw, seed_w=2026, seed_img=1234, num_prompts=256, full_predict=True, k_text=80, out_tag=None):
     """Reference pure-torch copy vs oracle on (arch, b, hw)."""
-    tag = f"{arch}_b{b}_{hw}"
+    tag = out_tag or f"{arch}_b{b}_{hw}"
     print(f"== network case {tag}")
     model, sd_np = load_uni_model(gp, arch, num_prompts, seed_w)
     sd = orc.to_torch(sd_np)
@@ -344,7 +389,10 @@ def case_network(gp, arch, b, hw, seed_w=2026, seed_img=1234, num_prompts=256, f
             pad = (8.0, 8.0, 0.0, 0.0) if i % 2 == 0 else (0.0, 0.0, 12.0, 12.0)
             sf = (0.5, 0.5) if i % 2 == 0 else (0.8, 0.8)
             ori = (int((hw - 16) / 0.5), int(hw / 0.5)) if i % 2 == 0 else (int(hw / 0.8), int((hw - 24) / 0.8))
-            o = opp.mmdet_predict_image(flat_mm["boxes"][i].numpy(), flat_mm["scores"][i].numpy(), pad, sf, ori)
+            o = opp.mmdet_predict_image(flat_mm["boxes"][i].numpy(), flat_mm["scores"][i].numpy(), pad, sf, ori, effective=out_tag is not None)
+            if out_tag is not None:
+                fx[f"mm.img{i}.eff_margins"] = o["eff_margins"]
+                print(f"  mm img{i}: EFFECTIVE margins (iou, pair, kept, cut) {o['eff_margins']}")
             fx[f"mm.img{i}.pad"], fx[f"mm.img{i}.sf"], fx[f"mm.img{i}.ori"] = np.asarray(pad), np.asarray(sf), np.asarray(ori)
             for key in ("bboxes", "scores", "labels", "anchors"):
                 fx[f"mm.img{i}.{key}"] = o[key]
@@ -358,7 +406,10 @@ def case_network(gp, arch, b, hw, seed_w=2026, seed_img=1234, num_prompts=256, f
         cb = np.asarray([sd[HD + f"cls_contrasts.{l}.bias"].item() for l in range(3)], dtype=np.float32)
         for i in range(b):
             o = opp.uni_predict_image(flat["boxes"][i].numpy(), flat["embed"][i].numpy(), flat["scores"][i].numpy(),
-                                      flat["level_of"].numpy(), ls, cb)
+                                      flat["level_of"].numpy(), ls, cb, effective=out_tag is not None)
+            if out_tag is not None:
+                fx[f"img{i}.eff_margins"] = o["eff_margins"]
+                print(f"  img{i}: EFFECTIVE margins (iou, pair, kept, cut) {o['eff_margins']}")
             must_equal(f"{tag}.img{i}.bboxes", res[i]["bboxes"], torch.from_numpy(o["bboxes"]))
             must_equal(f"{tag}.img{i}.scores", res[i]["scores"], torch.from_numpy(o["scores"]))
             must_equal(f"{tag}.img{i}.embeddings", res[i]["embeddings"], torch.from_numpy(o["embeddings"]))
@@ -784,6 +835,16 @@ if __name__ == "__main__":
         case_network(gp, "base", 1, 640)
         case_network(gp, "large", 1, 640, k_text=1203)
         sys.exit(0)
+    if "--search-robust" in sys.argv:
+        i = sys.argv.index("--search-robust")
+        print(search_robust(sys.argv[i + 1], int(sys.argv[i + 2])))
+        sys.exit(0)
+    if "--only-robust" in sys.argv:
+        gp = import_generate_proposal()
+        i = sys.argv.index("--only-robust")
+        for arch in sys.argv[i + 1:] or ["base", "large"]:
+            case_robust(gp, arch, 80 if arch == "base" else 1203)
+        sys.exit(0)
     if "--only-nms" in sys.argv:
         case_nms()
         sys.exit(0)
@@ -805,6 +866,8 @@ if __name__ == "__main__":
     case_network(gp, "base", 1, 640)
     case_network(gp, "large", 1, 64, full_predict=False)
     case_network(gp, "large", 1, 640, k_text=1203)
+    case_robust(gp, "base", 80)
+    case_robust(gp, "large", 1203)
     case_letterbox(gp)
     case_recall()
     case_retrieval_metric()

@@ -138,6 +138,14 @@ def test_detector_options_are_honoured_or_refused():
         YOLOWorldDetector("nano", test_cfg=dict(nms=dict(type="soft_nms", iou_threshold=0.5)))
     with pytest.raises(NotImplementedError):
         YOLOWorldDetector("nano", test_cfg=dict(nms=dict(type="nms", iou_threshold=0.5, class_agnostic=True)))
+    with pytest.raises(NotImplementedError, match="class_agnostic"):            # the refusal names the option
+        YOLOWorldDetector("nano", test_cfg=dict(nms=dict(type="nms", iou_threshold=0.5, class_agnostic=True)))
+    # round 4: mmcv's max_num / score_threshold fold into max_per_img / score_thr (keep[:max_num] then results[:max_per_img];
+    # two strict score filters around a top-k are one filter with the larger threshold)
+    d = YOLOWorldDetector("nano", test_cfg=dict(max_per_img=300, nms=dict(type="nms", iou_threshold=0.5, max_num=120, score_threshold=0.05)))
+    assert d._h.max_out == 120 and d.test_cfg["score_thr"] == 0.05
+    d = YOLOWorldDetector("nano", test_cfg=dict(max_per_img=100, score_thr=0.1, nms=dict(type="nms", iou_threshold=0.5, max_num=500, score_threshold=0.05)))
+    assert d._h.max_out == 100 and d.test_cfg["score_thr"] == 0.1
     # split_thr is mmcv.ops.batched_nms' own option and reaches wd_nms_gather as mode_param
     d = YOLOWorldDetector("nano", test_cfg=dict(nms=dict(type="nms", iou_threshold=0.5, split_thr=100)))
     assert d.test_cfg["nms"]["split_thr"] == 100

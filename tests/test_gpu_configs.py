@@ -5,12 +5,17 @@
   configs[4]  WeDetect-Large retrieval against a 1 000 000-class text bank (per-GPU form; the 8-shard identity)
 (configs[0] is tests/test_gpu_entry.py; configs[3]'s exchange is covered by the gloo tests and the one-rank RCCL run there.)
 
-Each full batch is checked four ways: image 0 IS the image of the reference-generated B = 1 golden (tests/golden/
-net_*_b1_640.npz) and must reproduce its checksums and kept lists ORDER-EXACT (zero tie-run relaxations, asserted); one
-image from the middle of the batch goes through the CPU oracle's whole network on the box (the oracle is bit-identical
-to the reference on the golden cases) and must agree on embeddings / scores / boxes and, exactly, on both kept lists;
-the post-process of EVERY image must equal the oracle's post-process run on the device's own score / box tensors bit
-for bit (candidate order, NMS keeps, boxes); and two other images must come out bit-identical when run alone."""
+Each full batch is checked five ways.  Image 0 IS the image of the round-1 reference-generated B = 1 golden (tests/golden/
+net_*_b1_640.npz): its network checksums are asserted; its kept lists are compared and RECORDED, not asserted exact — the
+reference's own decisions on that image sit inside fp32 summation noise (round-3 review: exact "only because every kernel
+change so far kept the K order bit-identical").  Images 1 and 2 are the MARGIN-ROBUST goldens of round 4
+(net_*_b1_640_robust_{mm,uni}.npz: seeds searched for decision margins >= 2e-5 on everything that can reach the output,
+make_golden.py: search_robust): the mmdet-path list of image 1 and the Uni-path list of image 2 must equal the
+reference's position by position with ZERO relaxations — under any K order (the test is also run with WEDETECT_P8=0 /
+WEDETECT_FUSE_MLP_WIDE toggled, profiles/r04_parity.jsonl).  One image from the middle of the batch goes through the CPU
+oracle's whole network on the box and must agree on embeddings / scores / boxes, and exactly on both kept lists whenever
+its own effective margins exceed 2e-5 (recorded otherwise); the post-process of EVERY image must equal the oracle's
+post-process run on the device's own score / box tensors bit for bit; two other images must come out bit-identical alone."""
 import numpy as np
 import pytest
 import torch
@@ -20,11 +25,14 @@ from tests.util import assert_close, assert_no_relaxations, check_checksum, comp
 pytestmark = pytest.mark.gpu
 
 
-def _batch_with_golden_first(b, seed_rest=77):
+ROBUST_MIN = 2e-5
+
+
+def _batch_with_goldens_first(b, seeds, seed_rest=77):
     from wedetect_amd import weights as W
-    first = W.make_images(1, 640, 640, seed=1234)                      # the golden's image
-    rest = W.make_images(b - 1, 640, 640, seed=seed_rest)
-    return np.concatenate([first, rest], axis=0)
+    first = [W.make_images(1, 640, 640, seed=int(sd)) for sd in seeds]   # the goldens' images
+    rest = W.make_images(b - len(first), 640, 640, seed=seed_rest)
+    return np.concatenate(first + [rest], axis=0)
 
 
 def _run_config(arch, b, k, fixture, precision):
@@ -33,11 +41,13 @@ def _run_config(arch, b, k, fixture, precision):
     from wedetect_amd.engine import ImageTower
     from wedetect_amd.pack import pack
     fx = golden(fixture)
-    assert int(fx["k_text"]) == k and int(fx["hw"]) == 640
+    fx_mm = golden(fixture.replace(".npz", "_robust_mm.npz"))
+    fx_un = golden(fixture.replace(".npz", "_robust_uni.npz"))
+    assert int(fx["k_text"]) == k and int(fx["hw"]) == 640 and int(fx_mm["k_text"]) == k and int(fx_un["k_text"]) == k
     sd = W.make_state_dict(arch, seed=int(fx["seed_w"]), num_prompts=int(fx["num_prompts"]))
     packed = pack(sd, arch)
     tower = ImageTower(arch, packed, b, 640, 640, max_classes=max(k, 256), precision=precision)
-    imgs = _batch_with_golden_first(b)
+    imgs = _batch_with_goldens_first(b, [fx["seed_img"], fx_mm["seed_img"], fx_un["seed_img"]])
     x = torch.from_numpy(imgs).cuda()
     tag = f"{arch} B={b} K={k} [{precision}]"
     # ---- network: image 0 against the reference's checksums (rows of image 0 come first in every NHWC buffer)
@@ -60,9 +70,15 @@ def _run_config(arch, b, k, fixture, precision):
     res = {kk: v.clone() for kk, v in tower.postprocess(scores, 0.001, meta, with_embed=False, nms="mmcv").items()}
     torch.cuda.synchronize()
     n0 = int(res["count"][0])
-    compare_kept_lists(f"{tag} mmdet img0 vs reference golden", res["anchors"][0, :n0], res["labels"][0, :n0], res["scores"][0, :n0],
-                       fx["mm.img0.anchors"], fx["mm.img0.labels"], fx["mm.img0.scores"], fx["mm.img0.margins"],
-                       got_boxes=res["bboxes"][0, :n0], ref_boxes=fx["mm.img0.bboxes"])
+    compare_kept_lists(f"{tag} mmdet img0 vs round-1 reference golden (recorded)", res["anchors"][0, :n0], res["labels"][0, :n0],
+                       res["scores"][0, :n0], fx["mm.img0.anchors"], fx["mm.img0.labels"], fx["mm.img0.scores"], fx["mm.img0.margins"],
+                       got_boxes=res["bboxes"][0, :n0], ref_boxes=fx["mm.img0.bboxes"], assert_exact=False)
+    assert min(fx_mm["mm.img0.eff_margins"][[0, 1, 3]]) > ROBUST_MIN and min(fx_un["img0.eff_margins"][[0, 1, 3]]) > ROBUST_MIN
+    n1 = int(res["count"][1])
+    compare_kept_lists(f"{tag} mmdet img1 vs margin-robust reference golden", res["anchors"][1, :n1], res["labels"][1, :n1],
+                       res["scores"][1, :n1], fx_mm["mm.img0.anchors"], fx_mm["mm.img0.labels"], fx_mm["mm.img0.scores"],
+                       fx_mm["mm.img0.margins"], got_boxes=res["bboxes"][1, :n1], ref_boxes=fx_mm["mm.img0.bboxes"],
+                       eff_margins=fx_mm["mm.img0.eff_margins"])
     sc_np, bx_np = to_np(scores), to_np(boxes)
     for i in range(b):                                                  # every image: exact post-process on equal inputs
         o = opp.mmdet_predict_image(bx_np[i], sc_np[i], tuple(float(v) for v in pad), tuple(float(v) for v in sf),
@@ -78,11 +94,19 @@ def _run_config(arch, b, k, fixture, precision):
     torch.cuda.synchronize()
     n0 = int(res_u["count"][0])
     ref_boxes = opp.unletterbox(fx["img0.bboxes"], (0.0, 0.0), 1.0, (640, 640))
-    jj, gg = compare_kept_lists(f"{tag} uni img0 vs reference golden", res_u["anchors"][0, :n0], res_u["labels"][0, :n0],
+    jj, gg = compare_kept_lists(f"{tag} uni img0 vs round-1 reference golden (recorded)", res_u["anchors"][0, :n0], res_u["labels"][0, :n0],
                                 res_u["scores"][0, :n0], fx["img0.anchors"], fx["img0.labels"], fx["img0.scores"], fx["img0.margins"],
-                                got_boxes=res_u["bboxes"][0, :n0], ref_boxes=ref_boxes)
+                                got_boxes=res_u["bboxes"][0, :n0], ref_boxes=ref_boxes, assert_exact=False)
     assert_close(f"{tag} uni img0 embeddings[:, :16]", to_np(res_u["embeddings"][0])[jj][:, :16], fx["img0.embed16"][gg], 1e-3, 1e-3)
     assert_close(f"{tag} uni img0 boxes", to_np(res_u["bboxes"][0])[jj], ref_boxes[gg], 2e-2, 1e-5)
+    n2 = int(res_u["count"][2])
+    ref_boxes2 = opp.unletterbox(fx_un["img0.bboxes"], (0.0, 0.0), 1.0, (640, 640))
+    jj, gg = compare_kept_lists(f"{tag} uni img2 vs margin-robust reference golden", res_u["anchors"][2, :n2], res_u["labels"][2, :n2],
+                                res_u["scores"][2, :n2], fx_un["img0.anchors"], fx_un["img0.labels"], fx_un["img0.scores"],
+                                fx_un["img0.margins"], got_boxes=res_u["bboxes"][2, :n2], ref_boxes=ref_boxes2,
+                                eff_margins=fx_un["img0.eff_margins"])
+    assert_close(f"{tag} uni img2 embeddings[:, :16]", to_np(res_u["embeddings"][2])[jj][:, :16], fx_un["img0.embed16"][gg], 1e-3, 1e-3)
+    assert_close(f"{tag} uni img2 boxes", to_np(res_u["bboxes"][2])[jj], ref_boxes2[gg], 2e-2, 1e-5)
     # ---- a mid-batch image against the CPU oracle's own network run (batch-position bugs of the GEMM tilings)
     from oracle import ref_cpu as orc
     from wedetect_amd.arch import get_arch
@@ -96,22 +120,24 @@ def _run_config(arch, b, k, fixture, precision):
     assert_close(f"{tag} img{im} scores vs CPU oracle", scores[im], flat_mm["scores"][0], 1e-3)
     assert_close(f"{tag} img{im} boxes vs CPU oracle", boxes[im], flat_mm["boxes"][0], 1e-2)
     o = opp.mmdet_predict_image(flat_mm["boxes"][0].numpy(), flat_mm["scores"][0].numpy(), tuple(float(v) for v in pad),
-                                tuple(float(v) for v in sf), tuple(int(v) for v in ori))
+                                tuple(float(v) for v in sf), tuple(int(v) for v in ori), effective=True)
     n = int(res["count"][im])
     mg = o["margins"]
+    robust = bool(min(o["eff_margins"][[0, 1, 3]]) > ROBUST_MIN)      # exactness is demanded where the oracle's own decisions are far from flipping
     compare_kept_lists(f"{tag} mmdet img{im} vs CPU oracle network", res["anchors"][im, :n], res["labels"][im, :n], res["scores"][im, :n],
                        o["anchors"], o["labels"], o["scores"], [mg["iou_margin"], mg["pair_gap"], mg["kept_gap"], mg["cut_gap"]],
-                       got_boxes=res["bboxes"][im, :n], ref_boxes=o["bboxes"])
+                       got_boxes=res["bboxes"][im, :n], ref_boxes=o["bboxes"], assert_exact=robust, eff_margins=o["eff_margins"])
     ls = np.asarray(tower.lvl_logit_scale, np.float32)
     cb = np.asarray(tower.lvl_bias, np.float32)
     o = opp.uni_predict_image(flat_u["boxes"][0].numpy(), flat_u["embed"][0].numpy(), flat_u["scores"][0].numpy(),
-                              flat_u["level_of"].numpy(), ls, cb)
+                              flat_u["level_of"].numpy(), ls, cb, effective=True)
     n = int(res_u["count"][im])
     mg = o["margins"]
+    robust = bool(min(o["eff_margins"][[0, 1, 3]]) > ROBUST_MIN)
     compare_kept_lists(f"{tag} uni img{im} vs CPU oracle network", res_u["anchors"][im, :n], res_u["labels"][im, :n], res_u["scores"][im, :n],
                        o["anchors"], o["labels"], o["scores"], [mg["iou_margin"], mg["pair_gap"], mg["kept_gap"], mg["cut_gap"]],
-                       got_boxes=res_u["bboxes"][im, :n], ref_boxes=o["bboxes"])
-    assert_no_relaxations(tag)          # the BASELINE configurations reproduce the reference's lists with no tie-run allowance
+                       got_boxes=res_u["bboxes"][im, :n], ref_boxes=o["bboxes"], assert_exact=robust, eff_margins=o["eff_margins"])
+    assert_no_relaxations(tag, allow_tie_runs=True)          # the asserted comparisons reproduce the reference's lists with no tie-run / cut-swap allowance
     # ---- batch independence: two images alone, bit for bit
     t1 = ImageTower(arch, packed, 1, 640, 640, max_classes=max(k, 256), precision=precision)
     for i in (b // 2, b - 1):

@@ -25,14 +25,14 @@ def precision(request):
     yield request.param
 
 
-def build(arch, b, hw, num_prompts=256, seed=2026, **kw):
+def build(arch, b, hw, num_prompts=256, seed=2026, seed_img=1234, **kw):
     kw.setdefault("precision", PRECISION["value"])
     from wedetect_amd import weights as W
     from wedetect_amd.engine import ImageTower
     from wedetect_amd.pack import pack
     sd = W.make_state_dict(arch, seed=seed, num_prompts=num_prompts)
     tower = ImageTower(arch, pack(sd, arch), b, hw, hw, **kw)
-    imgs = W.make_images(b, hw, hw, seed=1234)
+    imgs = W.make_images(b, hw, hw, seed=seed_img)
     return sd, tower, imgs
 
 
@@ -127,22 +127,29 @@ def test_text_path_normalised_bank_vs_oracle():
 
 def _compare_detections(name, res, i, fx, prefix, ref_boxes=None):
     """Kept (anchor, class) lists against the reference-generated golden: identical up to reorderings inside near-tie
-    runs of the reference's own scores (tests/util.py: compare_kept_lists), logged to gpurun_out/parity_r02.jsonl."""
+    runs of the reference's own scores (tests/util.py: compare_kept_lists), logged to gpurun_out/parity_r04.jsonl.
+    Exactness is ASSERTED for the small maps and for the margin-robust 640 x 640 goldens (effective decision margins
+    >= 2e-5 recorded by the generator); the round-1 640 x 640 golden, whose reference decisions sit at the noise level, is
+    recorded only (round-3 review)."""
     from tests.util import compare_kept_lists
     n = int(res["count"][i])
     margins = fx[f"{prefix}.margins"] if f"{prefix}.margins" in fx else None
+    eff = fx[f"{prefix}.eff_margins"] if f"{prefix}.eff_margins" in fx else None
+    asserted = bool(min(eff[[0, 1, 3]]) > 2e-5) if eff is not None else int(fx["hw"]) < 640
     return compare_kept_lists(f"{name} [{PRECISION['value']}]", res["anchors"][i, :n], res["labels"][i, :n], res["scores"][i, :n],
                               fx[f"{prefix}.anchors"], fx[f"{prefix}.labels"], fx[f"{prefix}.scores"], margins,
-                              score_tol=TOL, got_boxes=res["bboxes"][i, :n] if ref_boxes is not None else None, ref_boxes=ref_boxes)
+                              score_tol=TOL, got_boxes=res["bboxes"][i, :n] if ref_boxes is not None else None, ref_boxes=ref_boxes,
+                              assert_exact=asserted, eff_margins=eff)
 
 
 @pytest.mark.parametrize("fixture,arch,b,hw", [("net_base_b1_64.npz", "base", 1, 64), ("net_base_b2_128.npz", "base", 2, 128),
-                                               ("net_base_b1_640.npz", "base", 1, 640)])
+                                               ("net_base_b1_640.npz", "base", 1, 640),
+                                               ("net_base_b1_640_robust_mm.npz", "base", 1, 640), ("net_base_b1_640_robust_uni.npz", "base", 1, 640)])
 def test_base_against_reference_goldens(fixture, arch, b, hw):
     from oracle import postprocess as opp
     from wedetect_amd import weights as W
     fx = golden(fixture)
-    sd_np, tower, imgs = build(arch, b, hw, num_prompts=int(fx["num_prompts"]), seed=int(fx["seed_w"]))
+    sd_np, tower, imgs = build(arch, b, hw, num_prompts=int(fx["num_prompts"]), seed=int(fx["seed_w"]), seed_img=int(fx["seed_img"]))
     a = tower.a
     tower.backbone(torch.from_numpy(imgs).cuda())
     for i in range(4):

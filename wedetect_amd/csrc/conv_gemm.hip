@@ -13,11 +13,11 @@
 //   block tile  BM = 16*TM*WM rows (m)  x  BN = 16*TN*WN cols (n),  K step BK (16 in production)
 //   wave tile   (16*TM) x (16*TN), TM*TN accumulators of 4 VGPRs
 //   production: 128 x 128 x 16 with 8 waves (32 x 64 wave tiles) for n % 128 == 0, and
-//   128 x {96,80,64,48} x 16 with 8 waves stacked along m otherwise; ~76 VGPRs and 41 KB of LDS,
+//   128 x {96,80,64,48} x 16 with 8 waves stacked along m otherwise; ~76 VGPRs and 49 KB of LDS,
 //   so three workgroups (6 waves per SIMD) stay resident per CU — on device that occupancy, not
 //   fragment reuse, is what keeps the (slow, 32-cycle) fp32 MFMA pipe fed.
 //   operands are staged global -> VGPR (16-byte loads, im2col gather; tails and conv padding are
-//   READ from a zero block so the K loop is branch-free) -> LDS [rows][BK+4], double buffered:
+//   READ from a zero block so the K loop is branch-free) -> LDS [rows][BK+8], double buffered:
 //   the loads of tile t+1 are issued before the MFMAs of tile t and written to the other LDS
 //   buffer after them (one barrier per K step).
 //   The MFMA "A" operand carries WEIGHT rows and the "B" operand ACTIVATION rows, so a lane
@@ -53,7 +53,14 @@ constexpr int ABL_NOLOAD = 4, ABL_NOBAR = 8, ABL_NOEPI = 16, ABL_NOLDS = 32;
 template <int TM, int TN, int WM, int WN, int BK_ = 32>
 struct Tile {
   static constexpr int BK = BK_;
-  static constexpr int LD = BK + 4;                      // floats; rows stay 16-byte aligned
+  // Row pitch in floats.  BK + 8 (10 / 6 sixteen-byte slots for BK = 32 / 16), not BK + 4: ds_read_b128 is served in four
+  // groups of 16 lanes — {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 — over a 256-byte bank row of sixteen
+  // 16-byte slots; a fragment read puts lane (i = lane & 15, g = lane >> 4) at slot (pitch * i + g) mod 16.  With a pitch of
+  // 9 (or 5) slots seven slots of every group are hit twice (two LDS cycles per group: SQ_LDS_BANK_CONFLICT was 35 % of
+  // SQ_LDS_IDX_ACTIVE on the similarity GEMM, round-3 review); 10 and 6 are the smallest pitches with 16 distinct slots in
+  // all four groups.  The staging ds_write_b128 (8 consecutive lanes = one row's 8 consecutive chunks) is conflict-free at
+  // any pitch.  Same arithmetic: results are bit-identical.
+  static constexpr int LD = BK + 8;
   static constexpr int KCH = BK / 4;                     // float4 chunks per row per K step
   static constexpr int BM = 16 * TM * WM;
   static constexpr int BN = 16 * TN * WN;

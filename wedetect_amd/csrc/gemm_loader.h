@@ -10,6 +10,22 @@ namespace {
 // whole MFMA phase.
 __device__ __attribute__((aligned(16))) float g_zero4[4] = {0.f, 0.f, 0.f, 0.f};
 
+// Device address of this translation unit's zero block ON THE CURRENT DEVICE: a __device__ symbol has one address per
+// device, and a process may drive several GPUs (round 3 cached the first device's address per process — ADVICE r3: a
+// second device would have read its halo zeros from device 0's memory).  nullptr on failure.
+static inline const float* wd_zero_block() {
+  static const float* zero[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  const float*& z = zero[dev & 63];
+  if (!z) {
+    void* zp = nullptr;
+    if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero4)) != hipSuccess || !zp) return nullptr;
+    z = static_cast<const float*>(zp);
+  }
+  return z;
+}
+
 // ---------------------------------------------------------------------------------------
 // A-operand gather, branch-free: an out-of-range chunk reads g_zero4.
 // CONV=false: plain row-major [m][k] with row stride lda.

@@ -126,7 +126,9 @@ extern "C" int64_t wd_p8_workspace_bytes(void) { return 4 * wd_p8_workspace_floa
 static int pick_presplit_cfg(int m, int n, int k, bool park) {
   if (k % 32 == 0 && k >= 256 && m % 8 == 0 && n % 256 == 0) {
     const long long tiles = (long long)((m + 255) / 256) * (n / 256);
-    if (park && wd_p8_persist_ok(m, n)) return 65;
+    // persistent (gang-scheduled, round 4) from K = 512: with fewer than 16 K tiles per tile the pieces' prologues cost more than
+    // the quantisation they remove (stage-2 pwconv1, K = 256: 452 -> 473 us; profiles/r04_persist_pmc.txt)
+    if (park && k >= 512 && wd_p8_persist_ok(m, n)) return 65;
     if (tiles >= 128) return 64;
   }
   if (k % 16 == 0 && n % 256 == 0 && m % 16 == 0 && m >= 131072) return 66;   // short K, very long m (stage-1 pwconv1)

@@ -313,12 +313,8 @@ int launch_conv_pp(const WdConvGemm& p, const void* wsp, float unscale, hipStrea
   const long long nblk = (long long)nbm * nbn * ksplits;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return WD_ERR_BAD_ARG;
   const int k16 = (p.k + 15) / 16 * 16;
-  static const float* zero = nullptr;
-  if (!zero) {
-    void* zp = nullptr;
-    if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero4)) != hipSuccess || !zp) return WD_ERR_LAUNCH;
-    zero = static_cast<const float*>(zp);
-  }
+  const float* zero = wd_zero_block();
+  if (!zero) return WD_ERR_LAUNCH;
   auto k = split_conv_pp_kernel<NBUF, TN, CSPLIT, ABL>;
   static WdAttrOnce attr;
   if (wd_set_max_lds(attr, reinterpret_cast<const void*>(k), LDS) != WD_OK) return WD_ERR_LAUNCH;

@@ -663,12 +663,8 @@ int launch_split(const WdConvGemm& p, const void* wsp, float unscale, hipStream_
   const int vec_res = p.res ? ((p.ldres % 4 == 0) && wd_aligned16(p.res)) : 0;
   const int vec_bias = p.bias ? wd_aligned16(p.bias) : 0;
   const unsigned char* w8 = static_cast<const unsigned char*>(wsp);
-  static const float* zero = nullptr;
-  if (!zero) {
-    void* zp = nullptr;
-    if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero4)) != hipSuccess || !zp) return WD_ERR_LAUNCH;
-    zero = static_cast<const float*>(zp);
-  }
+  const float* zero = wd_zero_block();
+  if (!zero) return WD_ERR_LAUNCH;
   static WdAttrOnce attr_plain, attr_conv;
   if constexpr (WHICH != 1) if (conv) {
     auto k = split_gemm_kernel<TM, TN, WM, WN, BKT, true, VAR>;

@@ -198,12 +198,8 @@ int launch_glds(const WdConvGemm& p, const void* wsp, float unscale, hipStream_t
   const int vec_c = (p.ldc % 4 == 0) && wd_aligned16(p.c);
   const int vec_res = p.res ? ((p.ldres % 4 == 0) && wd_aligned16(p.res)) : 0;
   const int vec_bias = p.bias ? wd_aligned16(p.bias) : 0;
-  static const float* zero = nullptr;
-  if (!zero) {
-    void* zp = nullptr;
-    if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero4)) != hipSuccess || !zp) return WD_ERR_LAUNCH;
-    zero = static_cast<const float*>(zp);
-  }
+  const float* zero = wd_zero_block();
+  if (!zero) return WD_ERR_LAUNCH;
   // column-tile group of the raster order: 4 (measured: -3 % on the wide pwconv1 layers, whose 4 MB of
   // weight panels otherwise compete with the activation panels for the 4 MB L2); must divide nbn
   int ngrp = 4;
@@ -500,12 +496,8 @@ int launch_pingpong(const WdConvGemm& p, const void* wsp, float unscale, hipStre
   const int vec_c = (p.ldc % 4 == 0) && wd_aligned16(p.c);
   const int vec_res = p.res ? ((p.ldres % 4 == 0) && wd_aligned16(p.res)) : 0;
   const int vec_bias = p.bias ? wd_aligned16(p.bias) : 0;
-  static const float* zero = nullptr;
-  if (!zero) {
-    void* zp = nullptr;
-    if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero4)) != hipSuccess || !zp) return WD_ERR_LAUNCH;
-    zero = static_cast<const float*>(zp);
-  }
+  const float* zero = wd_zero_block();
+  if (!zero) return WD_ERR_LAUNCH;
   auto k = split_gemm_pingpong_kernel<VAR, NBUF, TN>;
   static WdAttrOnce attr;
   if (wd_set_max_lds(attr, reinterpret_cast<const void*>(k), LDS) != WD_OK) return WD_ERR_LAUNCH;

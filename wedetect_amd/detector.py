@@ -590,8 +590,21 @@ class YOLOWorldDetector(_DeviceModule):
         nms = dict(cfg["nms"])
         if nms.get("type", "nms") != "nms":
             raise NotImplementedError(f"test_cfg.nms.type={nms.get('type')!r}: only the plain greedy 'nms' is implemented")
-        if set(nms) - {"type", "iou_threshold", "split_thr"}:      # class_agnostic / max_num / score_threshold: not built
-            raise NotImplementedError(f"test_cfg.nms options {sorted(set(nms) - {'type', 'iou_threshold', 'split_thr'})} are not implemented")
+        # mmcv.ops.batched_nms options (mmcv/ops/nms.py 2.1.0).  max_num: ``keep[:max_num]`` after NMS — followed by mmdet's
+        # ``results[:max_per_img]``, i.e. min(max_num, max_per_img) rows.  score_threshold: ``scores > score_threshold`` before
+        # NMS — the candidates already passed ``scores > score_thr`` and the nms_pre cut keeps the highest, so the two filters are
+        # one with the larger threshold.  class_agnostic: NMS on the un-offset boxes across classes — not built.
+        if nms.get("class_agnostic", False):
+            raise NotImplementedError("test_cfg.nms.class_agnostic=True (mmcv.ops.batched_nms on un-offset boxes across classes) "
+                                      "is not implemented; every shipped config uses class-aware NMS")
+        if set(nms) - {"type", "iou_threshold", "split_thr", "class_agnostic", "max_num", "score_threshold"}:
+            raise NotImplementedError("test_cfg.nms options "
+                                      f"{sorted(set(nms) - {'type', 'iou_threshold', 'split_thr', 'class_agnostic', 'max_num', 'score_threshold'})} are not implemented")
+        max_num = int(nms.get("max_num", -1))
+        if max_num > 0:
+            cfg["max_per_img"] = min(int(cfg["max_per_img"]), max_num)
+        if float(nms.get("score_threshold", 0.0)) > float(cfg["score_thr"]):
+            cfg["score_thr"] = float(nms["score_threshold"])
         self.test_cfg = cfg
         self.model_size = model_size
         self.img_scale = tuple(img_scale) if img_scale is not None else _IMG_SIZE[model_size]

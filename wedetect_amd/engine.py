@@ -65,13 +65,15 @@ class ImageTower:
         self.fixed_splitk = precision == "fp16x3" and os.environ.get("WEDETECT_FIXED_SPLITK", "1") == "1"
         self.fws = (torch.empty(2 * batch * 400 * 256 + 64, dtype=torch.float32, device=torch.device(device))
                     if self.fixed_splitk else None)
-        # 256 x 256 fp16x3 kernels for the big pre-split layers (split_gemm_p8.hip).  $WEDETECT_P8: "tile" (default) = one
-        # workgroup per output tile, picked by the library; "persist" = additionally offer the park workspace, which
-        # selects the persistent work-unit form where it applies (faster per launch in isolation on some shapes — profiles/r02_p8_ab.txt —,
-        # equal inside the round-2 step and 3.5 % slower inside the round-3 one: 819 vs 790 images/s, profiles/r03_p8_tile_vs_persist.txt;
-        # its flag words must start zero and it is never lent to split-K launches); "0" = neither
+        # 256 x 256 fp16x3 kernels for the big pre-split layers (split_gemm_p8.hip).  $WEDETECT_P8: "tile" = one workgroup per
+        # output tile, picked by the library; "persist" (default since round 4) = additionally offer the park workspace, which
+        # selects the persistent work-unit form where it applies (K >= 512, at least one gang tile per gang).  Rounds 2-3 dealt the
+        # units to single workgroups: 12 % slower inside the step (profiles/r03_p8_tile_vs_persist.txt) because every workgroup
+        # streamed its own row panel through the XCD's L2 (FETCH_SIZE 1.35 GB per launch against 0.33 - 0.58 GB); dealt to gangs
+        # (round 4, profiles/r04_persist_pmc.txt) it is 0.4 - 0.8 % faster than the tile form in the step.  Its flag words must
+        # start zero and it is never lent to split-K launches; "0" = neither
         # (the round-1 128 x 128 / ping-pong kernels, for A/B runs).
-        self.p8_mode = os.environ.get("WEDETECT_P8", "tile")
+        self.p8_mode = os.environ.get("WEDETECT_P8", "persist")
         self.s2d_down = os.environ.get("WEDETECT_S2D_DOWN", "1") != "0"     # downsample convs as plain GEMMs on space-to-depth LayerNorm rows
         self.park = None
         if precision == "fp16x3" and self.p8_mode == "persist" and L.p8_workspace_bytes() > 0:
