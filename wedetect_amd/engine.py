@@ -235,7 +235,14 @@ class ImageTower:
                                                                  park=True).endswith("/p8s"):
                 work = self.park
             elif plain and self.p8_mode == "0" and kw["cin"] % 16 == 0:
-                kw = dict(kw, split_cfg=63 if m >= 131072 else 60)
+                # A/B switch: the round-1 kernels (another K-tile order inside the launch, the same MFMA chain per output) for
+                # the layers those kernels cover — plain rows, no scatter / batch-stride / dual output, no residual on a
+                # split output; the rest stays on the implicit-GEMM kernel
+                flags_ = kw.get("split_flags", 0)
+                special = (kw.get("out_mode", 0) != 0 or kw.get("c_batch_stride", 0) > 0 or kw.get("seg") is not None
+                           or kw.get("sigmoid") or kw.get("c2") is not None or ((flags_ & L.SPLIT_C) and kw.get("res") is not None))
+                if not special:
+                    kw = dict(kw, split_cfg=63 if m >= 131072 else 60)
         if ws is not None:
             flags = kw.get("split_flags", 0)
             sa = self.sscale.get(a_key, 1.0) if a_key else 1.0
