@@ -173,6 +173,8 @@ class GemmTimer:
             dma = kw.get("w_split") is not None and bool(flags & lib.SPLIT_A) and not covered
             tag = lib.gemm_config(m, n, k, split=kw.get("w_split") is not None, conv=not plain,
                                   presplit=bool(flags & lib.SPLIT_A), park=park, dma=dma) + ("/plain" if plain else "/conv")
+            if os.environ.get("WEDETECT_BENCH_BY_SHAPE") == "1":       # diagnostic: one line per layer shape
+                tag += f" m{m} n{n} k{kh}x{kw_}x{kw['cin']} s{stride}" + (" ks2" if kw.get("k_splits") else "")
             s, e = self.pool.pop() if self.pool else self._pair()
             lib.time_next_gemm(s, e)
             orig(a, w, bias, c, **kw)

@@ -308,8 +308,11 @@ def test_presplit_neck_head_is_bit_identical_to_the_loader_split_path(arch, b, h
     monkeypatch.setenv("WEDETECT_NECK_PRESPLIT", "0")
     t_old = ImageTower(arch, packed, b, hw, hw, precision="fp16x3")
     monkeypatch.setenv("WEDETECT_NECK_PRESPLIT", "1")
+    monkeypatch.setenv("WEDETECT_CONV3", "0")                     # the tap-per-stage kernel: the K order of rounds 1-3
     t_new = ImageTower(arch, packed, b, hw, hw, precision="fp16x3")
-    assert not t_old._neck_split() and t_new._neck_split()
+    monkeypatch.setenv("WEDETECT_CONV3", "1")                     # round 4: the row-sharing 3 x 3 kernel — (kh, chunk, kw) order
+    t_new3 = ImageTower(arch, packed, b, hw, hw, precision="fp16x3")
+    assert not t_old._neck_split() and t_new._neck_split() and t_new3._neck_split() and t_new3.conv3 and not t_new.conv3
     e0, b0 = t_old.features(x)
     s0 = t_old.similarity(t_old.P["prompts"], normalize=False).clone()
     e1, b1 = t_new.features(x)
@@ -322,6 +325,13 @@ def test_presplit_neck_head_is_bit_identical_to_the_loader_split_path(arch, b, h
         bound = 2.0 ** -21 * p_old.double().abs() + 1e-7          # hi + lo carries the fp32 value to 2^-22 relative (3e-8 absolute below the fp16 normal range)
         assert bool((d <= bound).all()), f"{arch} P{i+3}: split storage off by {float(d.max()):.3e}"
     assert int(t_new.range_flags.sum()) == 0
+    # the row-sharing kernel sums the same products in another order: equal to fp32 rounding noise
+    e3, b3 = t_new3.features(x)
+    s3 = t_new3.similarity(t_new3.P["prompts"], normalize=False)
+    torch.cuda.synchronize()
+    assert float((e3 - e1).abs().max()) <= 2e-5 * float(e1.abs().max()), f"{arch}: conv3 embeddings {float((e3 - e1).abs().max()):.3e}"
+    assert float((b3 - b1).abs().max()) <= 2e-3 and float((s3 - s1).abs().max()) <= 1e-5
+    assert int(t_new3.range_flags.sum()) == 0
 
 
 @pytest.mark.parametrize("arch,b,hw,calibrate", [("base", 2, 128, False), ("base", 1, 640, True), ("base", 3, 96, False)])

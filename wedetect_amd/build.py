@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwedetect_hip.so")
-SOURCES = ["abi.hip", "conv_gemm.hip", "split_gemm.hip", "split_gemm_pre.hip", "split_gemm_p8.hip", "split_gemm_p4.hip", "split_gemm_conv.hip", "split_gemm_mlp.hip", "split_gemm_mlpw.hip", "probe.hip", "stem.hip", "elementwise.hip", "preprocess.hip", "text.hip", "bricks.hip", "evaluate.hip", "postprocess.hip"]
+SOURCES = ["abi.hip", "conv_gemm.hip", "split_gemm.hip", "split_gemm_pre.hip", "split_gemm_p8.hip", "split_gemm_p4.hip", "split_gemm_conv.hip", "split_gemm_conv3.hip", "split_gemm_mlp.hip", "split_gemm_mlpw.hip", "probe.hip", "stem.hip", "elementwise.hip", "preprocess.hip", "text.hip", "bricks.hip", "evaluate.hip", "postprocess.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-inline-asm",
          "-I", os.path.join(ROOT, "include"), "-I", CSRC]
@@ -43,7 +43,7 @@ def source_hash() -> str:
 # (scripts/check_sgpr_vmem_hazard.py: the gfx9 "VALU writes SGPR -> VMEM reads it" hazard the compiler's recogniser cannot see
 # inside asm blocks; scripts/check_asm_loads.py: no instruction may touch a register an asm load is still in flight to)
 ASM_VMEM_SOURCES = {"split_gemm_mlpw.hip": ["fused_mlp_wide_kernel"], "split_gemm_mlp.hip": [], "split_gemm_p8.hip": [],
-                    "split_gemm_p4.hip": [], "split_gemm_pre.hip": [], "split_gemm_conv.hip": [], "stem.hip": []}
+                    "split_gemm_p4.hip": [], "split_gemm_pre.hip": [], "split_gemm_conv.hip": [], "split_gemm_conv3.hip": [], "stem.hip": []}
 
 
 def check_isa(src: str, verbose: bool = True) -> None:

@@ -20,6 +20,7 @@
 //   multiples of 16, so the 16 lanes of a ds_read_b128 group hit 16 distinct bank quads);
 //   weights are the MFMA "A" operand, activations "B": a lane ends with 4 consecutive output
 //   channels of a pixel per accumulator quad, and the epilogue is the one of conv_gemm.hip.
+#include <stdlib.h>
 #include "split_gemm_impl.h"
 
 namespace {
@@ -107,6 +108,9 @@ bool wd_p8_persist_ok(int m, int n);
 bool wd_conv_pp_ok(const WdConvGemm& p, int flags);
 int wd_launch_conv_pp(const WdConvGemm& p, const void* w, float unscale, int flags, hipStream_t st, int ksplits, float* ws,
                       long long ws_floats, int variant);
+// split_gemm_conv3.hip: 3 x 3 / stride 1 / pad 1, one stage per (filter row, channel chunk) shared by the row's three taps
+bool wd_conv3_ok(const WdConvGemm& p, int flags);
+int wd_launch_conv3(const WdConvGemm& p, const void* w, float unscale, int flags, hipStream_t st, int variant);
 
 extern "C" int64_t wd_p8_workspace_bytes(void) { return 4 * wd_p8_workspace_floats(); }
 
@@ -198,6 +202,13 @@ static int conv_gemm_split_impl(const WdConvGemm* pp, const void* w_split, float
     // WD_SPLIT_C layer — runs the implicit-GEMM LDS-DMA kernel (split_gemm_conv.hip).  cfg 70 / 73 / 74 force it (A/B runs).
     const bool covered = plain && !special && !p.c2 && !((flags & WD_SPLIT_C) && p.res);
     const bool forced = cfg == 70 || cfg == 73 || cfg == 74 || (cfg >= 700 && cfg < 716);
+    // cfg 75 forces the row-sharing 3 x 3 kernel; production takes it wherever it applies and K is not split
+    // ($WEDETECT_CONV3=0 keeps the tap-per-stage kernel: A/B runs)
+    static const bool conv3_on = [] { const char* e = getenv("WEDETECT_CONV3"); return !(e && e[0] == '0'); }();
+    if (cfg == 75 || cfg == 76 || (production && conv3_on && force_splits <= 1 && !(force_splits == 0 && ws != nullptr))) {
+      if (wd_conv3_ok(p, flags) && wd_conv_pp_ok(p, flags)) return wd_launch_conv3(p, w_split, w_unscale, flags, st, cfg == 76 ? 2 : 0);
+      if (cfg == 75 || cfg == 76) return WD_ERR_UNSUPPORTED;
+    }
     if (forced || (production && !covered)) {
       if (!wd_conv_pp_ok(p, flags)) return forced || !covered ? WD_ERR_UNSUPPORTED : WD_ERR_BAD_ARG;
       const long long wsf = ws ? ws_bytes / 4 : 0;

@@ -78,6 +78,10 @@ class ImageTower:
         self.park = None
         if precision == "fp16x3" and self.p8_mode == "persist" and L.p8_workspace_bytes() > 0:
             self.park = torch.zeros(L.p8_workspace_bytes() // 4, dtype=torch.float32, device=torch.device(device))
+        # 3 x 3 / stride 1 convs of the pre-split neck / head on the row-sharing kernel (split_gemm_conv3.hip, round 4): one LDS
+        # stage per (filter row, channel chunk) serves the row's three taps.  Another K order than the tap-per-stage kernel
+        # (last-bit differences); "0" pins that one (cfg 70) for A/B runs and for the bit-identity tests against rounds 2-3
+        self.conv3 = os.environ.get("WEDETECT_CONV3", "1") != "0"
         self._park_mlp = None                    # park workspace of the persistent wide fused MLP (the same layout; shared with self.park)
         self.B, self.H, self.W = batch, height, width
         self.fuse_stem = os.environ.get("WEDETECT_FUSE_STEM", "1") == "1"      # stem as one fp32 kernel (bit-identical to the fp32 three-launch form)
@@ -228,6 +232,9 @@ class ImageTower:
                 and kw["hin"] * kw["win"] <= 400 and 9 * kw["cin"] >= 2304 and kw["n"] % 4 == 0
                 and 2 * self.B * kw["hin"] * kw["win"] * kw["n"] <= self.fws.numel()):
             work, kw = self.fws, dict(kw, k_splits=2)
+        if (ws is not None and (kw.get("split_flags", 0) & L.SPLIT_A) and not self.conv3 and kw.get("kh", 1) == 3
+                and kw.get("stride", 1) == 1 and "split_cfg" not in kw):
+            kw = dict(kw, split_cfg=70)
         if ws is not None and (kw.get("split_flags", 0) & L.SPLIT_A):
             plain = kw.get("kh", 1) == 1 and kw.get("kw", 1) == 1 and kw.get("stride", 1) == 1 and kw.get("pad", 0) == 0
             m = self.B * kw["hin"] * kw["win"]
