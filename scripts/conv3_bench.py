@@ -14,6 +14,7 @@ SHAPES = [  # b, h, w, cin, n, res, out
     (32, 20, 20, 512, 256, False, "split"),
 ]
 g = torch.Generator(device="cuda").manual_seed(1)
+work = torch.empty(2 * 32 * 400 * 256 + 64, device="cuda")
 print(f"{'shape':40s} {'cfg70 us':>9s} {'TF':>6s} | {'cfg75 us':>9s} {'TF':>6s}   max|d|/rms")
 for (b, h, w, ci, n, res, out) in SHAPES:
     m = b * h * w
@@ -24,6 +25,8 @@ for (b, h, w, ci, n, res, out) in SHAPES:
     ws, xs = L.split_weights(wt), to_split(x)
     geo = dict(batch=b, hin=h, win=w, cin=ci, lda=ci, kh=3, kw=3, stride=1, pad=1, n=n, ldc=n, act=L.ACT_SILU, res=r,
                ldres=n if res else 0, res_alpha=0.5, w_split=ws, split_flags=L.SPLIT_A)
+    if h * w <= 400 and 9 * ci >= 2304:                 # the engine's fixed two-way split-K on the small maps
+        geo.update(workspace=work, k_splits=2)
     c0, c1 = torch.empty(m, n, device="cuda"), torch.empty(m, n, device="cuda")
     t0 = timeit(lambda: L.conv_gemm(xs, None, bias, c0, split_cfg=70, **geo))
     t1 = timeit(lambda: L.conv_gemm(xs, None, bias, c1, split_cfg=75, **geo))
@@ -31,4 +34,4 @@ for (b, h, w, ci, n, res, out) in SHAPES:
     torch.cuda.synchronize()
     d = float((c0 - c1).abs().max()) / float(c0.double().pow(2).mean().sqrt())
     fl = 2.0 * m * n * 9 * ci
-    print(f"{b}x{h}x{w} c{ci}->{n} res={int(res)}".ljust(40) + f" {t0:9.1f} {fl / t0 / 1e6:6.1f} | {t1:9.1f} {fl / t1 / 1e6:6.1f}   {d:.2e}   cfg76 (narrow, ring 2, two workgroups / CU) {t2:7.1f}", flush=True)
+    print(f"{b}x{h}x{w} c{ci}->{n} res={int(res)}{' ks2' if 'k_splits' in geo else ''}".ljust(40) + f" {t0:9.1f} {fl / t0 / 1e6:6.1f} | {t1:9.1f} {fl / t1 / 1e6:6.1f}   {d:.2e}   cfg76 (narrow, ring 2, two workgroups / CU) {t2:7.1f}", flush=True)

@@ -555,8 +555,13 @@ def test_conv_pp_split_k_deconv_and_c_only_split():
     L.conv_gemm(x, None, bias, ref, **geo)
     got = torch.empty_like(ref)
     c2 = torch.empty_like(ref)
-    L.conv_gemm(_to_split(x), None, bias, got, split_flags=L.SPLIT_A | L.SPLIT_C, c2=c2, ldc2=co, **geo)
+    L.conv_gemm(_to_split(x), None, bias, got, split_flags=L.SPLIT_A | L.SPLIT_C, c2=c2, ldc2=co, split_cfg=70, **geo)   # tap-per-stage kernel
     assert torch.equal(c2, ref) and torch.equal(got.view(torch.int32), _to_split(ref).view(torch.int32))
+    # production: the row-sharing kernel with the same two-way split (another K order: rounding noise of an fp32 sum)
+    got3, c23 = torch.empty_like(ref), torch.empty_like(ref)
+    L.conv_gemm(_to_split(x), None, bias, got3, split_flags=L.SPLIT_A | L.SPLIT_C, c2=c23, ldc2=co, **geo)
+    _same(c23, ref, False, "conv3 split-K fp32 copy")
+    _same(_from_split(got3), ref.double(), False, "conv3 split-K hi/lo output")
     # (b) deconv scatter, hi/lo output into the first third of a concat buffer
     b_, h, w_, ci, co = 2, 5, 7, 64, 32
     a = _rand((b_ * h * w_, ci), 55)

@@ -110,7 +110,8 @@ int wd_launch_conv_pp(const WdConvGemm& p, const void* w, float unscale, int fla
                       long long ws_floats, int variant);
 // split_gemm_conv3.hip: 3 x 3 / stride 1 / pad 1, one stage per (filter row, channel chunk) shared by the row's three taps
 bool wd_conv3_ok(const WdConvGemm& p, int flags);
-int wd_launch_conv3(const WdConvGemm& p, const void* w, float unscale, int flags, hipStream_t st, int variant);
+int wd_launch_conv3(const WdConvGemm& p, const void* w, float unscale, int flags, hipStream_t st, int variant, int ksplits, float* ws,
+                    long long ws_floats);
 
 extern "C" int64_t wd_p8_workspace_bytes(void) { return 4 * wd_p8_workspace_floats(); }
 
@@ -205,8 +206,10 @@ static int conv_gemm_split_impl(const WdConvGemm* pp, const void* w_split, float
     // cfg 75 forces the row-sharing 3 x 3 kernel; production takes it wherever it applies and K is not split
     // ($WEDETECT_CONV3=0 keeps the tap-per-stage kernel: A/B runs)
     static const bool conv3_on = [] { const char* e = getenv("WEDETECT_CONV3"); return !(e && e[0] == '0'); }();
-    if (cfg == 75 || cfg == 76 || (production && conv3_on && force_splits <= 1 && !(force_splits == 0 && ws != nullptr))) {
-      if (wd_conv3_ok(p, flags) && wd_conv_pp_ok(p, flags)) return wd_launch_conv3(p, w_split, w_unscale, flags, st, cfg == 76 ? 2 : 0);
+    // (latency mode — a workspace on offer with the split count left to the library — stays with the tap-per-stage kernel's rule)
+    if (cfg == 75 || cfg == 76 || (production && conv3_on && !(force_splits == 0 && ws != nullptr))) {
+      if (wd_conv3_ok(p, flags) && wd_conv_pp_ok(p, flags))
+        return wd_launch_conv3(p, w_split, w_unscale, flags, st, cfg == 76 ? 2 : 0, force_splits > 1 ? force_splits : 1, ws, ws ? ws_bytes / 4 : 0);
       if (cfg == 75 || cfg == 76) return WD_ERR_UNSUPPORTED;
     }
     if (forced || (production && !covered)) {

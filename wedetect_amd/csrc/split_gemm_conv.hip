@@ -327,6 +327,11 @@ int launch_conv_pp(const WdConvGemm& p, const void* wsp, float unscale, hipStrea
 
 // What this family covers: pre-split activations (WD_SPLIT_A), cin % 16 == 0, at most 16 filter taps, n % 8 == 0,
 // vector-friendly pointers / strides; any geometry (1x1, 3x3 stride 1 / 2, ...), any output form of the epilogue above.
+// second pass of a split-K launch of the (row, 8 channels) epilogue family, also for split_gemm_conv3.hip
+int wd_launch_oct_reduce(const WdConvGemm& p, const float* ws, int splits, float unscale, bool csplit, hipStream_t st) {
+  return csplit ? launch_oct_reduce<true>(p, ws, splits, unscale, st) : launch_oct_reduce<false>(p, ws, splits, unscale, st);
+}
+
 bool wd_conv_pp_ok(const WdConvGemm& p, int flags) {
   if (!(flags & WD_SPLIT_A)) return false;
   if (p.cin % 16 || p.k % 16 || p.lda % 8 || p.kh * p.kw > 16 || p.n % 8) return false;

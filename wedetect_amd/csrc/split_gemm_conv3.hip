@@ -25,7 +25,9 @@
 // not exist before the margin-robust goldens of round 4 (tests/golden/make_golden.py: search_robust): index parity no longer
 // hangs on the summation order.  tests/test_gpu_split.py::test_conv3_* holds it to the fp32-MFMA kernel within 2e-5 like
 // every fp16x3 kernel, and to the tap-major kernel within 3e-5 of the output's rms (measured 3e-6 ... 1e-5).
-// Not covered (split_conv_pp_kernel keeps them): stride 2, split-K launches (the fixed split of the <= 20 x 20 maps), 1 x 1.
+// Split-K (the fixed two-way split of the <= 20 x 20 maps, engine.py): workgroup (tile, ks) walks the stages [ks * per, ...) and
+// writes raw partial sums to ws[ks][m][n]; splitk_oct_reduce_kernel (split_gemm_conv.hip) adds them in split order and applies
+// the epilogue.  Not covered (split_conv_pp_kernel keeps them): stride 2, 1 x 1, the deconv scatter.
 #include <stdlib.h>
 #include "split_epi_oct.h"
 
@@ -56,7 +58,7 @@ struct C3 {
 template <int TN, bool CSPLIT, int NB = 3>
 __global__ void __launch_bounds__(512, NB == 2 ? 4 : 2)
 split_conv3_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, const float* __restrict__ zero, int k16,
-                   float unscale, int nbn) {
+                   float unscale, int nbn, int ksplits, float* __restrict__ ws) {
   using T = C3<TN, NB>;
   constexpr int TM = 2, BM = C3_BM, BN = 64 * TN, ROWB = C3_ROWB, NJ = T::NJ, NBUF = T::NBUF, DIST = NBUF - 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -68,9 +70,15 @@ split_conv3_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, co
     const int q = nwg >> 3, r = nwg & 7;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
+  const int ntiles = gridDim.x / ksplits;
+  const int ks = tile / ntiles;
+  tile -= ks * ntiles;
   const int bn = tile % nbn, bm = tile / nbn;
   const int m0 = bm * BM, n0 = bn * BN;
-  const int nci = p.cin >> 4, nk = 3 * nci;                 // stages: (kh, 16-channel chunk)
+  const int nci = p.cin >> 4, nk_all = 3 * nci;             // stages: (kh, 16-channel chunk)
+  const int per_split = (nk_all + ksplits - 1) / ksplits;
+  const int s_begin = ks * per_split;
+  const int nk = (s_begin + per_split < nk_all ? s_begin + per_split : nk_all) - s_begin;
 
   // ---- DMA slots of this wave: slot j handles stage group g = wave + 8 j.  g < 17: activation rows [16 g, + 16) of the
   // staged window (staged row r <-> centre pixel m0 - 1 + r); 17 <= g < NG: tap (g - 17) / WG, weight rows
@@ -117,7 +125,7 @@ split_conv3_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, co
     }
   }
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_raw;
-  int i_kh = 0, i_ci = 0;                                   // stage cursor of the DMA stream
+  int i_kh = s_begin / nci, i_ci = (s_begin - (s_begin / nci) * nci) * 16;   // stage cursor of the DMA stream
   auto issue = [&](int buf) {
     const unsigned lbase = lds0 + buf * T::STAGE;
     const int a_off = ((i_kh - 1) * p.wout * p.lda + i_ci) * 4;          // hout == hin, wout == win (stride 1, pad 1)
@@ -228,15 +236,26 @@ split_conv3_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, co
 
   const int mw = m0 + group * 128 + wm * 64, nw = n0 + wn * 32 * TN;
   float* patch = reinterpret_cast<float*>(smem_raw) + wave * 32 * EPI_LDT;
+  if (ksplits > 1) {
+    WdConvGemm pr = p;                                 // raw partial sums, plain rows [m][n] of this split
+    pr.bias = nullptr; pr.res = nullptr; pr.c2 = nullptr; pr.range_flag = nullptr;
+    pr.c = ws + (size_t)ks * p.m * p.n; pr.ldc = p.n;
+    pr.out_mode = WD_OUT_ROWS; pr.c_batch_stride = 0; pr.seg_rows = 0; pr.sigmoid = 0; pr.out_scale = 1.0f; pr.out_bias = 0.0f;
+    pr.act = WD_ACT_NONE;
+    EpiOctOperands<TM, TN, false> ops;               // no bias, no residual: nothing to load
+    ops.load(pr, mw, nw, lane);
+    EpiOctWalk<0, TM, TN, WD_ACT_NONE, false, false, false>::run(pr, 1.0f, mw, nw, lane, acc, patch, ops);
+    return;
+  }
   epi_oct_all<TM, TN, CSPLIT, TN == 1>(p, unscale, mw, nw, lane, acc, patch);
 }
 
 template <int TN, bool CSPLIT, int NB = 3>
-int launch_conv3(const WdConvGemm& p, const void* wsp, float unscale, hipStream_t st) {
+int launch_conv3(const WdConvGemm& p, const void* wsp, float unscale, hipStream_t st, int ksplits = 1, float* ws = nullptr) {
   using T = C3<TN, NB>;
   constexpr int BN = 64 * TN;
   const int nbm = (p.m + C3_BM - 1) / C3_BM, nbn = (p.n + BN - 1) / BN;
-  const long long nblk = (long long)nbm * nbn;
+  const long long nblk = (long long)nbm * nbn * ksplits;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return WD_ERR_BAD_ARG;
   const int k16 = (p.k + 15) / 16 * 16;
   const float* zero = wd_zero_block();
@@ -244,7 +263,8 @@ int launch_conv3(const WdConvGemm& p, const void* wsp, float unscale, hipStream_
   auto k = split_conv3_kernel<TN, CSPLIT, NB>;
   static WdAttrOnce attr;
   if (wd_set_max_lds(attr, reinterpret_cast<const void*>(k), T::LDS) != WD_OK) return WD_ERR_LAUNCH;
-  WD_LAUNCH_GEMM(k, dim3((unsigned)nblk), dim3(512), T::LDS, st, p, static_cast<const unsigned char*>(wsp), zero, k16, unscale, nbn);
+  WD_LAUNCH_GEMM(k, dim3((unsigned)nblk), dim3(512), T::LDS, st, p, static_cast<const unsigned char*>(wsp), zero, k16, unscale, nbn,
+                 ksplits, ws);
   return wd_launch_status();
 }
 
@@ -259,10 +279,24 @@ bool wd_conv3_ok(const WdConvGemm& p, int flags) {
   return true;
 }
 
+int wd_launch_oct_reduce(const WdConvGemm& p, const float* ws, int splits, float unscale, bool csplit, hipStream_t st);   // split_gemm_conv.hip
+
 // variant: 0 = production choice, 2 / 3 = ring depth of the narrow (BN = 64) form forced (A/B runs)
-int wd_launch_conv3(const WdConvGemm& p, const void* w, float unscale, int flags, hipStream_t st, int variant) {
+int wd_launch_conv3(const WdConvGemm& p, const void* w, float unscale, int flags, hipStream_t st, int variant, int ksplits,
+                    float* ws, long long ws_floats) {
   if (!wd_conv3_ok(p, flags)) return WD_ERR_UNSUPPORTED;
   const bool csplit = (flags & WD_SPLIT_C) != 0;
+  if (ksplits < 1) ksplits = 1;
+  if (ksplits > 1) {
+    if (!ws || (long long)ksplits * p.m * p.n > ws_floats) return WD_ERR_WORKSPACE;
+    if (ksplits > 3 * (p.cin >> 4)) ksplits = 3 * (p.cin >> 4);
+    const bool narrow_ = (p.n % 128) != 0 && ((p.n + 63) / 64) * 64 < ((p.n + 127) / 128) * 128;
+    int rc;
+    if (narrow_) rc = csplit ? launch_conv3<1, true>(p, w, unscale, st, ksplits, ws) : launch_conv3<1, false>(p, w, unscale, st, ksplits, ws);
+    else rc = csplit ? launch_conv3<2, true>(p, w, unscale, st, ksplits, ws) : launch_conv3<2, false>(p, w, unscale, st, ksplits, ws);
+    if (rc != WD_OK) return rc;
+    return wd_launch_oct_reduce(p, ws, ksplits, unscale, csplit, st);
+  }
   const bool narrow = (p.n % 128) != 0 && ((p.n + 63) / 64) * 64 < ((p.n + 127) / 128) * 128;
   if (narrow) {
     // BN = 64: a stage is 30 KB.  With more tiles than CUs a ring of TWO stages (60 KB) lets two workgroups share a CU — one's
