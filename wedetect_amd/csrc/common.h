@@ -58,17 +58,18 @@ __device__ __forceinline__ float wd_sigmoid(float x) { return 1.0f / (1.0f + exp
 // instructions of the exact form — the similarity GEMM's epilogue is 20 sigmoids per lane
 __device__ __forceinline__ float wd_sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
-// Exact-erf GELU, 0.5*x*(1+erf(x/sqrt2)), with erf from Abramowitz-Stegun 7.1.26
-// (|error| <= 1.5e-7 absolute on erf, i.e. <= 1e-7*|x| on GELU — three orders below the 1e-3
-// parity budget) instead of the ~3x longer libdevice erff: the GELU epilogue was 11 % of the
-// pwconv1 GEMMs.  For x < 0 the complementary form is used directly, so there is no
-// cancellation in 1 + erf.  The reciprocal is the hardware v_rcp_f32 (1 ulp): a correctly rounded one is a ten-
-// instruction division sequence per element (a third of this function's instructions) for an error term of 6e-8
-// relative on erfc, below the approximation's own 1.5e-7.
+// Exact-erf GELU, 0.5*x*(1+erf(x/sqrt2)), with erfc from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 absolute on erfc,
+// i.e. <= 1e-7*|x| on GELU — three orders below the 1e-3 parity budget) instead of the ~3x longer libdevice erff: the GELU
+// epilogue was 11 % of the pwconv1 GEMMs.  The reciprocal is the hardware v_rcp_f32 (1 ulp), the exponential v_exp_f32.
+// Round 4: 13 instructions instead of 19 (the fused 128-channel block MLP is VALU-bound on this function, the pwconv1 launches
+// spend ~60 us of 370 in it).  With E = erfc(|x| / sqrt2) / 2 the two branches of the old form — 0.5 x (2 - 2E) for x >= 0,
+// 0.5 x (2E) below — are ONE expression:  GELU(x) = max(x, 0) - |x| E,  so the compare / select / subtract go; the 0.5 is
+// folded into the polynomial's coefficients, 1/sqrt2 into p, and exp(-x^2 / 2) = exp2(-(k x)^2) with k = sqrt(log2(e) / 2)
+// costs two multiplies.  Same approximation, same accuracy (max |error| 3.3e-7 against 4.2e-7 before, on 4 M points of
+// [-12, 12]; the two forms differ by at most 4.8e-7, i.e. by their last bits).  Non-finite inputs stay non-finite (+inf now
+// gives NaN instead of inf: the fp16x3 range guard tests "not finite").
+#ifdef WD_GELU_R3     // the 19-instruction form of rounds 2-3, for A/B builds only (scripts: profiles/r04_gelu_ab.txt)
 __device__ __forceinline__ float wd_gelu(float x) {
-  // Every fused multiply-add of this function is written as fmaf; nothing else may be contracted.  The GEMM epilogues of
-  // different kernels must produce the SAME bits for the same accumulator (pre-split and loader-split paths are compared bit
-  // for bit), and an optional contraction — here "2 - (y * t) * e" — is decided per inlining context by the compiler.
 #pragma clang fp contract(off)
   const float ax = fabsf(x) * 0.70710678118654752440f;
   const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
@@ -76,10 +77,28 @@ __device__ __forceinline__ float wd_gelu(float x) {
   y = fmaf(y, t, 1.421413741f);
   y = fmaf(y, t, -0.284496736f);
   y = fmaf(y, t, 0.254829592f);
-  const float erfc_abs = y * t * __expf(-ax * ax);        // erfc(|x|/sqrt2)
+  const float erfc_abs = y * t * __expf(-ax * ax);
   const float one_plus_erf = x >= 0.f ? 2.0f - erfc_abs : erfc_abs;
   return 0.5f * x * one_plus_erf;
 }
+#else
+__device__ __forceinline__ float wd_gelu(float x) {
+  // Every fused multiply-add of this function is written as fmaf; nothing else may be contracted.  The GEMM epilogues of
+  // different kernels must produce the SAME bits for the same accumulator (pre-split and loader-split paths are compared bit
+  // for bit), and an optional contraction is decided per inlining context by the compiler.
+#pragma clang fp contract(off)
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.23164189f, ax, 1.0f));          // 1 / (1 + p |x| / sqrt2), p = 0.3275911
+  float y = fmaf(0.5307027145f, t, -0.7265760135f);                             // A&S coefficients a5 .. a1, halved
+  y = fmaf(y, t, 0.7107068705f);
+  y = fmaf(y, t, -0.142248368f);
+  y = fmaf(y, t, 0.127414796f);
+  const float xs = x * 0.84932180f;                                             // sqrt(log2(e) / 2)
+  const float e = __builtin_amdgcn_exp2f(-(xs * xs));                           // exp(-x^2 / 2)
+  const float half_erfc = (y * t) * e;                                          // erfc(|x| / sqrt2) / 2
+  return fmaf(-ax, half_erfc, fmaxf(x, 0.0f));
+}
+#endif
 
 __device__ __forceinline__ float wd_act(float v, int act) {
   switch (act) {

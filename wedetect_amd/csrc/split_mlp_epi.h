@@ -12,7 +12,7 @@ namespace {
 // split.  One value at a time, scalar instructions only — v_pk_{fma,mul,add}_f32 do not overlap with MFMAs at all
 // (scripts/issue_probe.py: an MFMA hides six v_fma_f32 behind it, four v_pk_fma_f32 cost their full 18 cycles on top).  No
 // range check here: a non-finite accumulator or a hidden value beyond the fp16 range becomes an inf / NaN half, then a NaN
-// output accumulator, which the final epilogue reports (GELU maps +inf to inf, -inf and NaN to NaN).
+// output accumulator, which the final epilogue reports (GELU maps every non-finite input to inf / NaN).
 __device__ __forceinline__ void mc_epi_group(const f32x16& hid, int g, const f32x4 bq, float unscale1, float hid_scale, u32x2& hi, u32x2& lo) {
 #pragma clang fp contract(off)
   typedef _Float16 ph2 __attribute__((ext_vector_type(2)));
