@@ -63,13 +63,15 @@ KERNEL_SYMBOL = {
     "fp16x3 256x128x16/8w/pingpong/plain": ["split_gemm_pingpong_kernel<2048, 3, 2>", "split_gemm_pingpong_kernel<0, 3, 2>"],
     "fp16x3 128x256x16/4w/p4/plain": ["split_gemm_p4_kernel<2048>", "split_gemm_p4_kernel<0>"],
     "fp16x3 256x256x32/8w/p8s/plain": ["split_gemm_p8_kernel<2048, 0, true>", "split_gemm_p8_kernel<0, 0, true>"],
-    "fp16x3 256x256x32/8w/p8/plain": ["split_gemm_p8_kernel<2048, 0, false>", "split_gemm_p8_kernel<0, 0, false>"],
+    # tile form and gang-scheduled persistent form (the default where it applies since round 4) of both epilogue variants
+    "fp16x3 256x256x32/8w/p8/plain": ["split_gemm_p8_kernel<2048, 0, false>", "split_gemm_p8_kernel<0, 0, false>",
+                                      "split_gemm_p8_kernel<2048, 0, true>", "split_gemm_p8_kernel<0, 0, true>"],
     "fp16x3 256x128x16/8w/dma/conv": ["split_conv_pp_kernel<3, 2, true, 0>", "split_conv_pp_kernel<4, 2, true, 0>"],
 }
 
 
 def measured_traffic(tag):
-    """HBM bytes per launch from the committed PMC passes (profiles/r03_traffic.json, else r02_traffic.json, for the fp16x3
+    """HBM bytes per launch from the committed PMC passes (profiles/r04_traffic.json, else r03 / r02, for the fp16x3
     build; profiles/r01_traffic.json for the fp32 build: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same
     command, FETCH_SIZE doubled per MI355X_MICROARCH.md) — PMC passes cannot run inside the timed process, so the figure
     comes from a file, and its PROVENANCE is returned with it: the file, the commit and kernel-source hash it was taken
@@ -80,10 +82,11 @@ def measured_traffic(tag):
     if syms is None:
         return None, None
     syms = [syms] if isinstance(syms, str) else syms
-    for name in (("r03_traffic.json", "r02_traffic.json", "r01_fp16x3_traffic.json") if tag.startswith("fp16x3") else ("r01_traffic.json",)):
+    for name in (("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_fp16x3_traffic.json") if tag.startswith("fp16x3") else ("r01_traffic.json",)):
         try:
             doc = json.load(open(os.path.join(ROOT, "profiles", name)))
             rec = doc["kernels"]
+            syms = [s_ for s_ in syms if s_ in rec]               # the instantiations that ran in the profiled step
             n = sum(rec[s]["launches"] for s in syms)
             val = round(sum(rec[s]["hbm_bytes_per_launch"] * rec[s]["launches"] for s in syms) / n)
             now = source_hash()

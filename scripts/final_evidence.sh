@@ -1,8 +1,8 @@
 # end-of-round evidence on the GPU box: WD_COMMIT=<commit of the build> [QUICK=1: profile + default bench only] bash scripts/final_evidence.sh
 export WD_COMMIT=${WD_COMMIT:?set WD_COMMIT to the commit being measured (the box has no .git)}
 mkdir -p gpurun_out/final
-bash scripts/profile_final.sh r03 > gpurun_out/final/prof.log 2>&1
-cp gpurun_out/prof_r03/traffic.json profiles/r03_traffic.json
+bash scripts/profile_final.sh r04 > gpurun_out/final/prof.log 2>&1
+cp gpurun_out/prof_r04/traffic.json profiles/r04_traffic.json
 python bench.py > gpurun_out/final/bench_latest.json 2> gpurun_out/final/bench_latest.err
 if [ -z "$QUICK" ]; then
 Q="--steps 30 --warmup 8 --no-cpu-baseline --no-fp32-reference --no-host-fed"

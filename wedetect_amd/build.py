@@ -42,6 +42,9 @@ def source_hash() -> str:
 # sources whose kernels issue VMEM instructions from inline asm: their ISA is checked after every compile
 # (scripts/check_sgpr_vmem_hazard.py: the gfx9 "VALU writes SGPR -> VMEM reads it" hazard the compiler's recogniser cannot see
 # inside asm blocks; scripts/check_asm_loads.py: no instruction may touch a register an asm load is still in flight to)
+# kernels whose inline-asm vmcnt counting assumes that the compiler adds no VMEM operation of its own (scratch spills /
+# reloads): the build fails if one of them needs scratch (stem.hip)
+NO_SCRATCH = {"stem.hip": ["stem_fused_kernel"]}
 ASM_VMEM_SOURCES = {"split_gemm_mlpw.hip": ["fused_mlp_wide_kernel"], "split_gemm_mlp.hip": [], "split_gemm_p8.hip": [],
                     "split_gemm_p4.hip": [], "split_gemm_pre.hip": [], "split_gemm_conv.hip": [], "split_gemm_conv3.hip": [], "stem.hip": []}
 
@@ -60,6 +63,12 @@ def check_isa(src: str, verbose: bool = True) -> None:
         r = subprocess.run([sys.executable, os.path.join(scripts, "check_asm_loads.py"), asm, *syms], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"pending asm load touched in the ISA of {src}:\n{r.stdout[-2000:]}")
+    if src in NO_SCRATCH:
+        import re
+        meta = open(asm).read()
+        for m in re.finditer(r"\.name:\s+(\S+)(.*?)\.private_segment_fixed_size:\s+(\d+)", meta, re.S):
+            if any(k in m.group(1) for k in NO_SCRATCH[src]) and ".name:" not in m.group(2) and int(m.group(3)) != 0:
+                raise RuntimeError(f"{src}: kernel {m.group(1)} uses {m.group(3)} bytes of scratch — its counted vmcnt waits assume none")
     os.remove(asm)
     if verbose:
         print(f"ISA checks passed: {src}", flush=True)
