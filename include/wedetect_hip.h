@@ -365,6 +365,11 @@ int wd_stem_fused(const uint8_t* img, int32_t batch, int32_t h, int32_t w, const
  * ---------------------------------------------------------------------------------- */
 int wd_dwconv7(const float* x, const float* w7, const float* bias, float* y,
                int32_t batch, int32_t h, int32_t w, int32_t c, void* stream);
+/* The same with the kernel form chosen by the caller (A/B measurements and the identity test; every form gives the same
+ * bits): 0 = wd_dwconv7's own choice, 1 = generic strips from global memory, 2 = LDS tile / 1 x 4 strips, 3 = LDS tile /
+ * 1 x 8 strips (h % 16 == 0).  2-3 need c % 32 == 0 (WD_ERR_UNSUPPORTED otherwise). */
+int wd_dwconv7_variant(const float* x, const float* w7, const float* bias, float* y,
+                       int32_t batch, int32_t h, int32_t w, int32_t c, int32_t variant, void* stream);
 /* wd_dwconv7_ln — the same depthwise conv followed by LayerNorm over the channels of each pixel (eps, affine
  * gamma / beta), one kernel: ConvNeXt Block's dwconv -> norm (mm_backbone.py:113-116).  c % 32 == 0.  split != 0:
  * the normalised rows are written as fp16 hi/lo groups (as wd_layernorm_rows_split).  Results are bit-identical to

@@ -1,5 +1,7 @@
 """wd_dwconv7 on the ConvNeXt-Base stage shapes (batch 32): time per launch and HBM-side rate (algorithmic bytes = one
-read + one write of the activation).  WEDETECT_DWCONV=0 selects the round-1 1 x 4-strip kernel for A/B (debug switch)."""
+read + one write of the activation), every kernel form that takes the shape (wd_dwconv7_variant: 2 = LDS tile / 1 x 4 strips,
+3 = LDS tile / 1 x 8 strips; 0 = wd_dwconv7's own choice), with a
+bit-identity check against form 2."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,16 +13,26 @@ for name, (b, h, w, c) in {"s1 160x160x128": (32, 160, 160, 128), "s2 80x80x256"
     w7 = torch.randn(49, c, device=dev) * 0.1
     bias = torch.randn(c, device=dev)
     y = torch.empty_like(x)
-    for _ in range(3):
-        L.dwconv7(x, w7, bias, y, b, h, w, c)
-    ts = []
-    for _ in range(5):
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        for _ in range(10):
-            L.dwconv7(x, w7, bias, y, b, h, w, c)
-        e.record()
-        torch.cuda.synchronize()
-        ts.append(1e3 * s.elapsed_time(e) / 10)
-    nbytes = 2.0 * x.numel() * 4
-    print(f"{name:16s} {min(ts):8.1f} us ({nbytes / min(ts) / 1e6:5.2f} TB/s)  checksum {float(y.double().sum()):.6f} {float(y.double().abs().sum()):.6f}", flush=True)
+    ref = None
+    for variant in (2, 3, 0):
+        if variant == 3 and h % 16:
+            continue
+        if variant in (2, 3) and c % 32:
+            continue
+        y.zero_()
+        for _ in range(3):
+            L.dwconv7(x, w7, bias, y, b, h, w, c, variant=variant)
+        ts = []
+        for _ in range(5):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(10):
+                L.dwconv7(x, w7, bias, y, b, h, w, c, variant=variant)
+            e.record()
+            torch.cuda.synchronize()
+            ts.append(1e3 * s.elapsed_time(e) / 10)
+        if ref is None:
+            ref = y.clone()
+        same = "bit-identical" if torch.equal(ref, y) else f"DIFFERS max|d| {float((ref - y).abs().max()):.3e}"
+        nbytes = 2.0 * x.numel() * 4
+        print(f"{name:16s} form {variant}: {min(ts):8.1f} us ({nbytes / min(ts) / 1e6:5.2f} TB/s)  {same}", flush=True)

@@ -192,6 +192,32 @@ def test_dwconv7(L, c, h, w):
     assert_close(f"dwconv7 c{c} {h}x{w}", y, ref.permute(0, 2, 3, 1).numpy(), 1e-5, 1e-5)
 
 
+@pytest.mark.parametrize("c,h,w", [(32, 16, 16), (128, 20, 20), (512, 40, 40), (64, 64, 48), (32, 80, 37), (96, 9, 11), (1024, 7, 21), (256, 33, 18)])
+def test_dwconv7_kernel_forms_are_bit_identical(L, c, h, w):
+    """The generic kernel (form 1), the 1 x 4-strip tile kernel (2) and the 1 x 8-strip tile kernel (3, h % 16 == 0) accumulate
+    every output in the same order (bias, taps kh-major, kw ascending): identical bits, ragged tiles and map borders included;
+    unsupported forms are refused (wd_dwconv7_variant, round 4)."""
+    b_ = 3
+    x, wt, bias = rnd(61, b_, h, w, c), rnd(62, 49, c, scale=1 / 7), rnd(63, c)
+    xd, wd_, bd = dev(x), dev(wt), dev(bias)
+    outs = {}
+    for variant in (1, 2, 3, 0):
+        if variant == 3 and h % 16:
+            with pytest.raises(L.WedetectHipError):
+                L.dwconv7(xd, wd_, bd, torch.empty(b_, h, w, c, device="cuda"), b_, h, w, c, variant=variant)
+            continue
+        y = torch.full((b_, h, w, c), float("nan"), device="cuda")
+        L.dwconv7(xd, wd_, bd, y, b_, h, w, c, variant=variant)
+        outs[variant] = y
+    for variant, y in outs.items():
+        assert torch.equal(y, outs[1]), f"form {variant} differs from the generic kernel: max|d| {float((y - outs[1]).abs().max()):.3e}"
+    ref = F.conv2d(torch.from_numpy(x).double().permute(0, 3, 1, 2), torch.from_numpy(wt.T.reshape(c, 1, 7, 7).copy()).double(),
+                   torch.from_numpy(bias).double(), padding=3, groups=c)
+    assert_close(f"dwconv7 forms c{c} {h}x{w}", outs[2], ref.permute(0, 2, 3, 1).numpy(), 1e-5, 1e-5)
+    with pytest.raises(L.WedetectHipError):
+        L.dwconv7(xd[..., :24].contiguous(), wd_[:, :24].contiguous(), bd[:24], torch.empty(b_, h, w, 24, device="cuda"), b_, h, w, 24, variant=2)
+
+
 @pytest.mark.parametrize("c", [32, 64, 96, 128, 192, 256, 384, 512, 768, 1024, 1536])
 def test_layernorm_rows(L, c):
     rows = 77

@@ -831,12 +831,23 @@ extern "C" int wd_stem_patchify(const uint8_t* img, float* out, int32_t batch, i
   return wd_launch_status();
 }
 
-extern "C" int wd_dwconv7(const float* x, const float* w7, const float* bias, float* y, int32_t batch, int32_t h,
-                          int32_t w, int32_t c, void* stream) {
+// variant: 0 = the selection below; 1 = generic 1 x 8 strips from global memory, 2 = LDS tile / 1 x 4 strips, 3 = LDS tile /
+// 1 x 8 strips (needs h % 16 == 0).  All bit-identical; the non-zero values exist for the A/B script and the identity test.
+// Round 4 built and measured three more forms of the tile kernel on the 40 x 40 x 512 / 20 x 20 x 1024 maps and dropped them
+// (profiles/r04_dwconv_forms.txt): 2 x 4 output blocks with the taps read from L2 (73 vs 63 us — a wave-wide dwordx4 load
+// costs the address unit its 16 cycles even when the 64 lanes share one line), the same with the taps in the LDS (80 + 49
+// reads per 8 outputs instead of 238: 67 us), and the 1 x 4 kernel walking 2 / 4 channel blocks per workgroup with the next
+// halo tile requested ahead (68 - 72 us).  Halving the LDS reads and hiding the staging latency both changed nothing.
+static int launch_dwconv7(const float* x, const float* w7, const float* bias, float* y, int32_t batch, int32_t h,
+                          int32_t w, int32_t c, int variant, void* stream) {
   if (!x || !w7 || !bias || !y || x == y) return WD_ERR_BAD_ARG;
   if (batch <= 0 || h <= 0 || w <= 0 || c <= 0 || (c & 3)) return WD_ERR_BAD_ARG;
   if (!wd_aligned16(x) || !wd_aligned16(w7) || !wd_aligned16(bias) || !wd_aligned16(y)) return WD_ERR_BAD_ARG;
-  if (c % DT_CB == 0 && h % 16 == 0 && h >= 64) {   // tall tiles only where they tile the map exactly: the 8-row form of this kernel (128 threads) lost to the 1 x 4 kernel on the 40 x 40 and 20 x 20 maps (76 vs 68 us, 58 vs 52 us)
+  if (variant < 0 || variant > 3) return WD_ERR_BAD_ARG;
+  if (variant >= 2 && c % DT_CB) return WD_ERR_UNSUPPORTED;
+  if (variant == 3 && h % 16) return WD_ERR_UNSUPPORTED;
+  const bool strip16 = variant == 3 || (variant == 0 && c % DT_CB == 0 && h % 16 == 0 && h >= 64);
+  if (strip16) {   // tall tiles only where they tile the map exactly: the 8-row form of this kernel (128 threads) lost to the 1 x 4 kernel on the 40 x 40 and 20 x 20 maps (76 vs 68 us, 58 vs 52 us)
     // 16 x 16 tiles of 1 x 8 strips: 160 x 160 map 264 -> 222-240 us, 80 x 80 128 -> 110 us (profiles/r02_dwconv_ab.txt)
     const int th = h / 16, tw = (w + DT_TW - 1) / DT_TW;
     const long long nblk = (long long)batch * th * tw * (c / DT_CB);
@@ -845,7 +856,7 @@ extern "C" int wd_dwconv7(const float* x, const float* w7, const float* bias, fl
                        bias, y, h, w, c, th, tw);
     return wd_launch_status();
   }
-  if (c % DT_CB == 0) {
+  if (variant == 2 || (variant == 0 && c % DT_CB == 0)) {
     const int th = (h + DT_TH - 1) / DT_TH, tw = (w + DT_TW - 1) / DT_TW;
     const long long nblk = (long long)batch * th * tw * (c / DT_CB);
     if (nblk > 0x7fffffffLL) return WD_ERR_BAD_ARG;
@@ -860,6 +871,15 @@ extern "C" int wd_dwconv7(const float* x, const float* w7, const float* bias, fl
   hipLaunchKernelGGL(dwconv7_kernel, dim3((unsigned)grid), dim3(256), 0, static_cast<hipStream_t>(stream), x, w7, bias,
                      y, h, w, c, nstrip, total);
   return wd_launch_status();
+}
+
+extern "C" int wd_dwconv7(const float* x, const float* w7, const float* bias, float* y, int32_t batch, int32_t h,
+                          int32_t w, int32_t c, void* stream) {
+  return launch_dwconv7(x, w7, bias, y, batch, h, w, c, 0, stream);
+}
+extern "C" int wd_dwconv7_variant(const float* x, const float* w7, const float* bias, float* y, int32_t batch, int32_t h,
+                                  int32_t w, int32_t c, int32_t variant, void* stream) {
+  return launch_dwconv7(x, w7, bias, y, batch, h, w, c, variant, stream);
 }
 
 // wd_dwconv7_ln: depthwise 7x7 + bias, then LayerNorm over the channels of every pixel, one kernel (c % 32 == 0).

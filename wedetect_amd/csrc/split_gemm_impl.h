@@ -242,12 +242,12 @@ __device__ __forceinline__ void epi_lds_tile_csplit(const WdConvGemm& p, const E
         o1[r] = sact<ACT>(fmaf(v1[r], ev.unscale, b1[r]));
       }
       u32x2 h0, l0, h1, l1;
-      // c_split_scale: a power of two (exact).  Applied under a (wave-uniform) branch: with the scale at 1 the instruction
-      // stream is the unscaled one, so that path stays bit-identical to the loader-split kernels by construction
-      if (p.c_split_scale != 0.f && p.c_split_scale != 1.0f) {
-        o0 = o0 * p.c_split_scale;
-        o1 = o1 * p.c_split_scale;
-      }
+      // c_split_scale: a power of two (exact); 0 = none.  Always multiplied — x * 1.0f is x, bit for bit, so the unscaled path
+      // stays identical to the loader-split kernels — because hipcc turned the "only when it is not 1" branch of rounds 1-3
+      // into a multiply PLUS a v_cndmask per value (one extra VALU instruction in 23 of this epilogue)
+      const float cs = p.c_split_scale != 0.f ? p.c_split_scale : 1.0f;
+      o0 = o0 * cs;
+      o1 = o1 * cs;
       split4(o0, h0, l0);
       split4(o1, h1, l1);
       unsigned char* cp = reinterpret_cast<unsigned char*>(p.c + (size_t)m * p.ldc) + (size_t)(n >> 3) * 32;

@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("WEDETECT_LIB") or os.path.join(_HERE, "libwedetect_hi
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU = 0, 1, 2, 3
 OUT_ROWS, OUT_DECONV2X2 = 0, 1
 SPLIT_A, SPLIT_C = 1, 2
-ABI_VERSION = 11
+ABI_VERSION = 12
 NMS_VANILLA, NMS_TORCHVISION, NMS_MMCV = 0, 1, 2
 # torchvision/ops/boxes.py batched_nms: the per-class loop (_batched_nms_vanilla) above this many box coordinates
 # (boxes.numel()).  4000 / 20000 are the values of torchvision 0.15 ... 0.21 (the releases contemporary with the
@@ -29,7 +29,7 @@ TV_TRICK_MAX_NUMEL = {"cpu": 4000, "cuda": 20000}
 MMCV_SPLIT_THR = 10000                                 # mmcv/ops/nms.py batched_nms: per-class loop from this many candidates
 
 EXPORTS = (
-    "wd_abi_version", "wd_strerror", "wd_sizeof_conv_gemm", "wd_conv_gemm", "wd_conv_gemm_tuned", "wd_conv_gemm_config", "wd_stem_patchify", "wd_dwconv7",
+    "wd_abi_version", "wd_strerror", "wd_sizeof_conv_gemm", "wd_conv_gemm", "wd_conv_gemm_tuned", "wd_conv_gemm_config", "wd_stem_patchify", "wd_dwconv7", "wd_dwconv7_variant",
     "wd_layernorm_rows", "wd_l2norm_rows", "wd_dfl_decode", "wd_topk_workspace_bytes", "wd_topk_capacity",
     "wd_topk_candidates", "wd_nms_workspace_bytes", "wd_nms_gather", "wd_retrieval_max",
     "wd_split_weights_bytes", "wd_split_weights", "wd_conv_gemm_split", "wd_conv_gemm_split_ws", "wd_conv_gemm_split_config", "wd_layernorm_rows_split", "wd_layernorm_rows_split_s2d", "wd_letterbox_u8", "wd_retrieval_max_split", "wd_text_embed", "wd_attention_small", "wd_recall_scratch_floats", "wd_recall_match",
@@ -86,6 +86,7 @@ def _load():
     lib.wd_conv_gemm_config.argtypes = [i32, i32, i32]
     lib.wd_stem_patchify.argtypes = [vp, vp, i32, i32, i32, vp]
     lib.wd_dwconv7.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.wd_dwconv7_variant.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.wd_layernorm_rows.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, f32, vp]
     lib.wd_l2norm_rows.argtypes = [vp, vp, i64, i32, vp]
     lib.wd_dfl_decode.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]
@@ -281,7 +282,11 @@ def stem_fused(img_u8: torch.Tensor, wgt, bias, gamma, beta, out, eps=1e-6) -> N
                             stream_ptr()), "wd_stem_fused")
 
 
-def dwconv7(x, w7, bias, y, batch, h, w, c) -> None:
+def dwconv7(x, w7, bias, y, batch, h, w, c, variant: int = 0) -> None:
+    """variant != 0 pins the kernel form (wd_dwconv7_variant; all forms are bit-identical)."""
+    if variant:
+        check(LIB.wd_dwconv7_variant(_p(x), _p(w7), _p(bias), _p(y), batch, h, w, c, variant, stream_ptr()), "wd_dwconv7_variant")
+        return
     check(LIB.wd_dwconv7(_p(x), _p(w7), _p(bias), _p(y), batch, h, w, c, stream_ptr()), "wd_dwconv7")
 
 
