@@ -19,6 +19,8 @@ SOURCES = ["abi.hip", "conv_gemm.hip", "split_gemm.hip", "split_gemm_pre.hip", "
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-inline-asm",
          "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+for _d in os.environ.get("WD_EXTRA_DEFINES", "").split():   # A/B builds only (e.g. WD_GELU_R3, WD_CSPLIT_PLAIN_STORE): never in a release build
+    FLAGS.append("-D" + _d)
 if os.environ.get("WD_DEBUG_ABLATIONS") == "1":          # timing-only ablation kernels (wrong results): never in a release build
     FLAGS.append("-DWD_DEBUG_ABLATIONS")
 

@@ -253,8 +253,13 @@ __device__ __forceinline__ void epi_lds_tile_csplit(const WdConvGemm& p, const E
       unsigned char* cp = reinterpret_cast<unsigned char*>(p.c + (size_t)m * p.ldc) + (size_t)(n >> 3) * 32;
       // non-temporal: the hi/lo output of a C-split layer is a write-once stream (1.7 GB per stage-1 pwconv1) that its consumer
       // re-reads only after this launch is over: keep it from displacing the operand panels in L2 (-0.3 ms per step, same box)
+#ifdef WD_CSPLIT_PLAIN_STORE
+      *reinterpret_cast<u32x4*>(cp) = u32x4{h0[0], h0[1], h1[0], h1[1]};
+      *reinterpret_cast<u32x4*>(cp + 16) = u32x4{l0[0], l0[1], l1[0], l1[1]};
+#else
       __builtin_nontemporal_store(u32x4{h0[0], h0[1], h1[0], h1[1]}, reinterpret_cast<u32x4*>(cp));
       __builtin_nontemporal_store(u32x4{l0[0], l0[1], l1[0], l1[1]}, reinterpret_cast<u32x4*>(cp + 16));
+#endif
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
