@@ -15,7 +15,11 @@ scale/bias + sigmoid) -> score filter (> 0.001) / top-30000 / sort -> class-awar
 rank runs that on its own batch (images shard with no data-path collective) and the
 kept-region embeddings are exchanged with one all_gather_into_tensor per step (the
 retrieval gather, extract_embedding.py:1753-1756).  Weights/images/text are seeded
-synthetic (no checkpoints or datasets offline).
+synthetic (no checkpoints or datasets offline).  The steps are issued back to back: the top-k / NMS
+kernels of step i (and, at N > 1, its region gather) go to the tower's second stream and run beside
+the backbone of step i + 1 (ImageTower.detect(overlap_post=True); --no-overlap-post keeps every
+kernel of a step on one stream).  Every step's post-process completes inside the timed bracket —
+the closing torch.cuda.synchronize() drains both streams.
 
 Prints ONE JSON line (rank 0) with the driver's contract plus:
   roofline      — the dominant kernel (the GEMM that runs the ConvNeXt MLPs: fp16x3 direct-to-LDS, or fp32 MFMA),
@@ -119,6 +123,9 @@ def parse():
     ap.add_argument("--no-fp32-reference", action="store_true",
                     help="skip the short native-fp32 run that is reported beside an fp16x3 result (N = 1 only)")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the host-fed (PCIe-inclusive) leg (N = 1 only)")
+    ap.add_argument("--no-overlap-post", action="store_true",
+                    help="issue top-k / NMS on the main stream, in front of the next step's backbone (default: on the tower's "
+                         "second stream, beside it)")
     ap.add_argument("--no-calibrate", action="store_true",
                     help="skip the untimed range-calibration pass (an fp32 run of the tower): keeps it out of a rocprofv3 trace")
     ap.add_argument("--cpu-runs", type=int, default=5, help="timed CPU-oracle passes per leg (median reported; 3 warm-ups)")
@@ -484,10 +491,17 @@ def main():
     image_ids = torch.arange(rank * B, (rank + 1) * B, dtype=torch.int64, device="cuda")
     stall = []                                  # (event before, event after) around the gather hand-over of a step
 
+    import contextlib
+    overlap = not args.no_overlap_post
+
     def step(measure_stall=False):
+        # overlap_post: top-k / NMS of this step on the tower's second stream, beside the next step's backbone (all of it
+        # still inside the timed bracket: the closing torch.cuda.synchronize() drains both streams)
         res = tower.detect(images, text, meta, normalize_text=not uni, score_thr=0.0 if uni else 0.001,
-                           with_embed=True)
-        if gatherer is not None:
+                           with_embed=True, overlap_post=overlap)
+        if gatherer is None:
+            return res
+        with (torch.cuda.stream(tower.post_stream) if overlap else contextlib.nullcontext()):
             # the exchange of this batch's kept regions (embeddings + per-region scale / bias + counts + image ids:
             # the four lists of extract_embedding.py:1753-1756) runs behind the next batch's kernels
             lvl = tower.level_of(res["anchors"])
@@ -581,6 +595,9 @@ def main():
                        "global_batch": world * B, "per_gpu_batch": B, "image": [S, S], "classes": K,
                        "parallelism": f"image-shard x{world}" + (" + all-gather of kept-region embeddings" if world > 1 else ""),
                        "precision": tower.precision,
+                       "pipelining": ("top-k / NMS of step i on a second stream beside the backbone of step i + 1 (same kernels; every "
+                                      "step's post-process completes inside the timed bracket); --no-overlap-post issues them in line"
+                                      if overlap else "none: every kernel of a step on one stream"),
                        **({"precision_evidence": "error vs a float64 run of the same network (oracle, Base@128): embeddings "
                            "fp32 8.5e-6 / fp16x3 9.5e-6, scores 8.0e-7 / 9.2e-7 (tests/probe_split_precision.py); on device the "
                            "fp16x3 step is within 5e-5 (embeddings) / 1e-5 (scores) of the fp32 step at this size "

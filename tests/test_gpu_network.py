@@ -262,6 +262,36 @@ def test_split_k_latency_mode_matches_default_path():
     assert n0 == n1 and len(a0 & a1) >= 0.97 * n0
 
 
+def test_pipelined_post_process_equals_the_in_line_step():
+    """detect(overlap_post=True) — top-k / NMS on the tower's second stream, beside the next call's backbone — returns, for a
+    stream of DIFFERENT batches issued back to back without any host synchronisation in between, exactly the tensors of the
+    in-line step (round 4).  The staging copies are taken on the post stream, where the results are produced; a pipelined
+    call followed by an in-line one (which must wait for the pending post-process before it overwrites its inputs) too."""
+    from wedetect_amd import weights as W
+    _, t, _ = build("tiny", 3, 128, num_prompts=48)
+    meta = t.identity_meta()
+    batches = [torch.from_numpy(W.make_images(3, 128, 128, seed=900 + i)).cuda() for i in range(4)]
+    kw = dict(normalize_text=False, score_thr=0.0, with_embed=True)
+    ref = []
+    for x in batches:
+        r = t.detect(x, t.P["prompts"], meta, **kw)
+        torch.cuda.synchronize()
+        ref.append({k: v.clone() for k, v in r.items()})
+    got = []
+    for x in batches:                                   # no synchronisation between the calls
+        r = t.detect(x, t.P["prompts"], meta, overlap_post=True, **kw)
+        with torch.cuda.stream(t.post_stream):
+            got.append({k: v.clone() for k, v in r.items()})
+    r = t.detect(batches[0], t.P["prompts"], meta, **kw)     # in line, right behind a pipelined call
+    t.wait_post()
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(ref, got)):
+        for k in a:
+            assert torch.equal(a[k], b[k]), f"batch {i}: {k} differs between the pipelined and the in-line step"
+    for k in ref[0]:
+        assert torch.equal(ref[0][k], r[k]), f"in-line step behind a pipelined one: {k} differs"
+
+
 def test_hipgraph_replay_equals_eager_and_is_faster_at_batch1():
     """A captured step must reproduce the eager step bit for bit on new inputs, and at batch 1
     (the reference's operating point) it removes the host launch overhead."""

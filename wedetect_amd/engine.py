@@ -74,6 +74,7 @@ class ImageTower:
         # start zero and it is never lent to split-K launches; "0" = neither
         # (the round-1 128 x 128 / ping-pong kernels, for A/B runs).
         self.p8_mode = os.environ.get("WEDETECT_P8", "persist")
+        self.post_stream, self._post_ready, self._post_done = None, None, None      # detect(overlap_post=True)
         self.s2d_down = os.environ.get("WEDETECT_S2D_DOWN", "1") != "0"     # downsample convs as plain GEMMs on space-to-depth LayerNorm rows
         self.park = None
         if precision == "fp16x3" and self.p8_mode == "persist" and L.p8_workspace_bytes() > 0:
@@ -633,14 +634,47 @@ class ImageTower:
         return self.head()
 
     def detect(self, images_u8, text, meta, *, normalize_text: bool, score_thr: float, iou_thr: float = 0.7,
-               with_embed: bool = False, nms: Optional[str] = None, nms_param: Optional[int] = None, nms_device: str = "cpu"):
+               with_embed: bool = False, nms: Optional[str] = None, nms_param: Optional[int] = None, nms_device: str = "cpu",
+               overlap_post: bool = False):
         """The whole step.  ``nms`` None picks the library the reference's path of this text handling uses: normalised
-        text = BNContrastiveHead of the mmdet path -> "mmcv"; prompts as stored = the Uni scripts -> "torchvision"."""
+        text = BNContrastiveHead of the mmdet path -> "mmcv"; prompts as stored = the Uni scripts -> "torchvision".
+
+        ``overlap_post`` (a stream of batches; round 4): the post-process of this step — top-k over B x N x K scores and the
+        class-aware NMS, 0.75 ms of kernels that occupy 32 waves to a few hundred workgroups of a 256-CU chip — is issued
+        on the tower's own second stream behind the similarity GEMM, so that the NEXT call's backbone runs beside it
+        instead of behind it.  Same kernels, same buffers, same results; what changes is the contract: the returned
+        tensors are produced on ``self.post_stream`` — call ``wait_post()`` (or synchronise the device) before reading them
+        from another stream — and they are overwritten by the next call's post-process, as ever.  The next call's head
+        waits for this post-process before it overwrites the boxes / embeddings / scores it reads."""
         if nms is None:
             nms = "mmcv" if normalize_text else "torchvision"
-        self.features(images_u8)
+        if not overlap_post:
+            self.wait_post()                      # a pipelined step may still be reading the buffers this one is about to write
+            self.features(images_u8)
+            scores = self.similarity(text, normalize=normalize_text)
+            return self.postprocess(scores, score_thr, meta, iou_thr, with_embed, nms, nms_param, nms_device)
+        if self.post_stream is None:
+            self.post_stream = torch.cuda.Stream(device=self.dev)
+            self._post_ready = torch.cuda.Event()
+        main = torch.cuda.current_stream()
+        self.backbone(images_u8)
+        self.neck()
+        self.wait_post()
+        self.head()
         scores = self.similarity(text, normalize=normalize_text)
-        return self.postprocess(scores, score_thr, meta, iou_thr, with_embed, nms, nms_param, nms_device)
+        self._post_ready.record(main)
+        with torch.cuda.stream(self.post_stream):
+            self.post_stream.wait_event(self._post_ready)
+            res = self.postprocess(scores, score_thr, meta, iou_thr, with_embed, nms, nms_param, nms_device)
+            if self._post_done is None:
+                self._post_done = torch.cuda.Event()
+            self._post_done.record(self.post_stream)
+        return res
+
+    def wait_post(self) -> None:
+        """Makes the CURRENT stream wait for the post-process of the last ``detect(overlap_post=True)`` call (no-op otherwise)."""
+        if self._post_done is not None:
+            torch.cuda.current_stream().wait_event(self._post_done)
 
     def checked_counts(self, res: Dict[str, torch.Tensor], rerun, recalibrate=None) -> List[int]:
         """Kept-row counts of a step on the host (the one D2H sync a caller needs anyway) with the fp16x3 range guard:
