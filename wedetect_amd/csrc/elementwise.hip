@@ -436,6 +436,16 @@ __global__ void __launch_bounds__(256) layernorm_rows_kernel(const float* __rest
 }
 }
 
+// Workgroup b runs on XCD b % 8 (round-robin dispatch), and every XCD has its own L2.  Kernels whose neighbouring tiles
+// share input (halo rows / columns) renumber their workgroups so that each XCD walks a CONTIGUOUS run of tiles — the same
+// renumbering as the GEMM kernels' — instead of every eighth one: with the plain order the stage-1 dwconv + LayerNorm kernel
+// fetched 962 MB per launch for its 419 MB input (profiles/r04_traffic.json: every halo pixel came over the fabric once per
+// tile that touches it, because the tile next door ran on another XCD).
+__device__ __forceinline__ int wd_xcd_contiguous(int bid, int nwg) {
+  const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 // ---------------------------------------------------------------------------------------
 // depthwise 7x7 + LayerNorm in ONE kernel (ConvNeXt Block: dwconv -> permute -> norm, mm_backbone.py:113-116).
 // A workgroup owns an 8 x 16 pixel tile for ALL channels: it runs the LDS-tiled depthwise conv above over the
@@ -454,7 +464,7 @@ __global__ void __launch_bounds__(256) dwconv7_ln_kernel(const float* __restrict
   float* tw = lds + DT_IH * DT_IWP * DT_CP;
   const int t = threadIdx.x;
   const int ncb = c / DT_CB;
-  int bid = blockIdx.x;
+  int bid = wd_xcd_contiguous(blockIdx.x, gridDim.x);
   const int tx = bid % tiles_w; bid /= tiles_w;
   const int ty = bid % tiles_h;
   const long long b = bid / tiles_h;
@@ -614,7 +624,7 @@ __global__ void __launch_bounds__(256) dwconv7_ln_reg_kernel(const float* __rest
   float* tin = lds;
   float* tw = lds + IH * DS_IWP * DT_CB;
   const int t = threadIdx.x;
-  int bid = blockIdx.x;
+  int bid = wd_xcd_contiguous(blockIdx.x, gridDim.x);
   const int tx = bid % tiles_w; bid /= tiles_w;
   const int ty = bid % tiles_h;
   const long long b = bid / tiles_h;
@@ -695,7 +705,7 @@ __global__ void __launch_bounds__(256) dwconv7_ln_reg4_kernel(const float* __res
   float* tin = lds;
   float* tw = lds + DT_IH * DT_IWP * DT_CP;
   const int t = threadIdx.x;
-  int bid = blockIdx.x;
+  int bid = wd_xcd_contiguous(blockIdx.x, gridDim.x);
   const int tx = bid % tiles_w; bid /= tiles_w;
   const int ty = bid % tiles_h;
   const long long b = bid / tiles_h;
