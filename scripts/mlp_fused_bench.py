@@ -1,6 +1,7 @@
 """Stage-1 ConvNeXt block MLP: one fused launch (wd_mlp_fused_split) against the two-kernel chain, HIP-event timed.
     python scripts/mlp_fused_bench.py [rows]        (default 32 x 160 x 160 = WeDetect-Base batch 32 at 640)"""
-import sys
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from wedetect_amd import lib as L
 
