@@ -673,7 +673,7 @@ class ImageTower:
 
     def wait_post(self) -> None:
         """Makes the CURRENT stream wait for the post-process of the last ``detect(overlap_post=True)`` call (no-op otherwise)."""
-        if self._post_done is not None:
+        if self._post_done is not None and not torch.cuda.is_current_stream_capturing():
             torch.cuda.current_stream().wait_event(self._post_done)
 
     def checked_counts(self, res: Dict[str, torch.Tensor], rerun, recalibrate=None) -> List[int]:
@@ -762,6 +762,7 @@ class GraphedDetect:
         if self.generation != self.tower.generation:
             raise L.WedetectHipError("stale hipGraph: the tower re-allocated its similarity / top-k buffers (a larger class "
                                      "bank arrived) after this graph was captured; capture a new one")
+        self.tower.wait_post()                 # a pipelined eager step of the same tower may still be reading its buffers
         self.images.copy_(images_u8, non_blocking=True)
         self.text.copy_(text, non_blocking=True)
         self.meta.copy_(meta, non_blocking=True)
