@@ -131,9 +131,12 @@ extern "C" int64_t wd_p8_workspace_bytes(void) { return 4 * wd_p8_workspace_floa
 static int pick_presplit_cfg(int m, int n, int k, bool park) {
   if (k % 32 == 0 && k >= 256 && m % 8 == 0 && n % 256 == 0) {
     const long long tiles = (long long)((m + 255) / 256) * (n / 256);
-    // persistent (gang-scheduled, round 4) from K = 512: with fewer than 16 K tiles per tile the pieces' prologues cost more than
-    // the quantisation they remove (stage-2 pwconv1, K = 256: 452 -> 473 us; profiles/r04_persist_pmc.txt)
-    if (park && k >= 512 && wd_p8_persist_ok(m, n)) return 65;
+    // persistent (gang-scheduled, round 4) from K = 1024.  Isolated, the persistent form wins from K = 512 (stage-2 pwconv1, K = 256:
+    // 452 -> 473 us, profiles/r04_persist_pmc.txt); inside the step the stage-3 pwconv1 (K = 512, 1 600 tiles of 16 K tiles: 6.25
+    // pieces per CU, each with its own prologue) is 1 % of the STEP faster on the tile form, the K >= 1024 layers 0.2 - 0.3 %
+    // faster persistent (profiles/r04_persist_mink.txt; $WD_P8_PERSIST_MINK overrides for A/B runs)
+    static const int mink = [] { const char* e = getenv("WD_P8_PERSIST_MINK"); return e ? atoi(e) : 1024; }();
+    if (park && k >= mink && wd_p8_persist_ok(m, n)) return 65;
     if (tiles >= 128) return 64;
   }
   if (k % 16 == 0 && n % 256 == 0 && m % 16 == 0 && m >= 131072) return 66;   // short K, very long m (stage-1 pwconv1)
