@@ -67,7 +67,7 @@ class ImageTower:
                     if self.fixed_splitk else None)
         # 256 x 256 fp16x3 kernels for the big pre-split layers (split_gemm_p8.hip).  $WEDETECT_P8: "tile" = one workgroup per
         # output tile, picked by the library; "persist" (default since round 4) = additionally offer the park workspace, which
-        # selects the persistent work-unit form where it applies (K >= 512, at least one gang tile per gang).  Rounds 2-3 dealt the
+        # selects the persistent work-unit form where it applies (K >= 1024, at least one gang tile per gang).  Rounds 2-3 dealt the
         # units to single workgroups: 12 % slower inside the step (profiles/r03_p8_tile_vs_persist.txt) because every workgroup
         # streamed its own row panel through the XCD's L2 (FETCH_SIZE 1.35 GB per launch against 0.33 - 0.58 GB); dealt to gangs
         # (round 4, profiles/r04_persist_pmc.txt) it is 0.4 - 0.8 % faster than the tile form in the step.  Its flag words must
