@@ -164,6 +164,12 @@ def test_calibration_on_an_ordinary_checkpoint_changes_nothing_above_the_fp32_no
     assert all(2.0 ** 9 <= amax[k] * t1.sscale.get(k, 1.0) < 2.0 ** 10 for k in amax if amax[k] > 0)
     e1 = t1.features(x)[0].clone()
     assert not bool(t1.range_flags.any())
+    # the diagnostic fp32 views of the (scaled, split) P3..P5 buffers divide the scale out again (they used to
+    # return the stored value, off by the calibrated power of two whenever it is not 1)
+    assert any(t1.sscale.get(k, 1.0) != 1.0 for k in ("p3", "p4", "p5")), "the case must give the pyramid buffers a non-unit scale"
+    for i, (p0, p1) in enumerate(zip(t0.pyramid(), t1.pyramid())):
+        rms = float(p0.double().pow(2).mean().sqrt())
+        assert float((p0 - p1).abs().max()) <= 2e-5 * max(1.0, rms), f"P{i + 3}: calibrated view differs from the uncalibrated one"
     d01, d0, d1 = float((e0 - e1).abs().max()), float((e0 - e32).abs().max()), float((e1 - e32).abs().max())
     print(f"[range] ordinary checkpoint: |calibrated - uncalibrated| {d01:.3g}; vs fp32: uncalibrated {d0:.3g}, calibrated {d1:.3g}")
     assert d01 <= 2e-5 and d1 <= max(2e-5, 1.5 * d0)
