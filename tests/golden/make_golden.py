@@ -315,6 +315,7 @@ def search_robust(arch, k_text, start=5000, trials=120):
     cb = np.asarray([sd[HD + f"cls_contrasts.{l}.bias"].item() for l in range(3)], dtype=np.float32)
     pad, sf, ori = (8.0, 8.0, 0.0, 0.0), (0.5, 0.5), (int((640 - 16) / 0.5), int(640 / 0.5))
     best = {"mm": (-1.0, None), "uni": (-1.0, None)}
+    ranked = {"mm": [], "uni": []}          # every robust seed, (kept gap, seed): round 5 takes the two best per path
     for seed in range(start, start + trials):
         imgs = W.make_images(1, 640, 640, seed=seed)
         _, p = orc.forward_features(sd, a, imgs)
@@ -324,9 +325,13 @@ def search_robust(arch, k_text, start=5000, trials=120):
         eu = opp.uni_predict_image(fu["boxes"][0].numpy(), fu["embed"][0].numpy(), fu["scores"][0].numpy(), fu["level_of"].numpy(),
                                    ls, cb, effective=True)["eff_margins"]
         for key, e in (("mm", em), ("uni", eu)):
-            if min(e[0], e[1], e[3]) > ROBUST_MIN and e[2] > best[key][0]:
-                best[key] = (float(e[2]), seed)
+            if min(e[0], e[1], e[3]) > ROBUST_MIN:
+                ranked[key].append((float(e[2]), seed))
+                if e[2] > best[key][0]:
+                    best[key] = (float(e[2]), seed)
         print(f"seed {seed}: mm eff {em}  uni eff {eu}   best so far {best}", flush=True)
+    for key in ranked:
+        print(f"ranked {key}: {sorted(ranked[key], reverse=True)[:6]}", flush=True)
     return best
 
 
@@ -611,6 +616,72 @@ def case_mmdet_modules(arch="tiny", hw=64):
     np.savez_compressed(os.path.join(OUT, f"mm_{arch}_b1_{hw}.npz"), **fx)
 
 
+def case_tiny_config0(gp, hw=640, k_text=81, seed_img=1234):
+    """BASELINE configs[0] pinned to the REFERENCE (round 5; VERDICT r4 missing #5): WeDetect-Tiny, one hw x hw image, through
+    the plugin classes the shipped config builds (wedetect/models ConvNextVisionBackbone('tiny') + CSPRepBiFPANNeck(0.75,
+    'tiny'): wedetect_tiny.py:108, yolo_world_pafpn.py:987-1137) and the reference's head module with Tiny's widths
+    (generate_proposal.YOLOWorldHeadModule(768, [96, 192, 384], use_bn_head=True) — the same code as
+    yolo_world_head.py:174-294), text L2-normalised inside BNContrastiveHead.  Every tensor must be torch.equal to the
+    oracle's; the post-process (mmdet path, thr 0.001, mmcv NMS) is the oracle's, pinned elsewhere (filter_topk / nms /
+    head_predict goldens).  Written with the margins of its decisions like the robust 640 x 640 fixtures."""
+    print(f"== Tiny config[0] through the plugin classes @ {hw}")
+    arch = "tiny"
+    bbm, nkm = import_wedetect_models()
+    a = get_arch(arch)
+    sd_np = W.make_state_dict(arch, seed=2026)
+    sd = orc.to_torch(sd_np)
+    vis = bbm.ConvNextVisionBackbone(model_name=arch)
+    vis_sd = {k[len("backbone.image_model."):]: torch.from_numpy(v) for k, v in sd_np.items()
+              if k.startswith("backbone.image_model.")}
+    msg = vis.load_state_dict(vis_sd, strict=False)
+    assert not msg.unexpected_keys and all(k.startswith(("model.norm.", "model.head.")) for k in msg.missing_keys), msg
+    neck = nkm.CSPRepBiFPANNeck(scale_factor=a.neck_scale, model_size=arch)
+    nk_sd = {k[len("neck."):]: torch.from_numpy(v) for k, v in sd_np.items() if k.startswith("neck.")}
+    msg = neck.load_state_dict(nk_sd, strict=False)
+    assert not msg.unexpected_keys and all(k.endswith("num_batches_tracked") for k in msg.missing_keys), msg
+    head = gp.YOLOWorldHeadModule(embed_dims=768, in_channels=list(a.head_in), use_bn_head=True)
+    hd_sd = {k[len("bbox_head."):]: torch.from_numpy(v) for k, v in W.to_uni_keys(sd_np).items() if k.startswith("bbox_head.")}
+    msg = head.load_state_dict(hd_sd, strict=False)
+    assert not msg.unexpected_keys and all(k.endswith("num_batches_tracked") for k in msg.missing_keys), msg
+    for mod in (vis, neck, head):
+        torch.nn.Module.eval(mod)
+        for m in mod.modules():
+            m.training = False
+    imgs = W.make_images(1, hw, hw, seed=seed_img)
+    x = orc.preprocess_u8(imgs)
+    fx = dict(arch=arch, b=1, hw=hw, seed_w=2026, seed_img=seed_img, k_text=k_text, num_prompts=0)
+    with torch.no_grad():
+        c_ref = vis(x)
+        c_orc = orc.backbone(sd, a, x)
+        for i in range(4):
+            must_equal(f"cfg0.{arch}.c{i+1}", c_ref[i], c_orc[i])
+            put(fx, f"c{i+1}", checksum(c_ref[i].permute(0, 2, 3, 1)))
+        p_ref = neck(c_ref)
+        p_orc = orc.neck(sd, a, c_orc)
+        for i in range(3):
+            must_equal(f"cfg0.{arch}.p{i+3}", p_ref[i], p_orc[i])
+            put(fx, f"p{i+3}", checksum(p_ref[i].permute(0, 2, 3, 1)))
+        text = torch.from_numpy(W.make_text_bank(k_text) * np.float32(1.7))
+        text_b = text[None]
+        outs = head(p_ref, text_b)
+        for l in range(3):
+            e_orc, lg_orc, bb_orc = orc.head_level(sd, l, p_orc[l], text_b, normalize_text=True)
+            must_equal(f"cfg0.mm_logits{l}", outs[l][0], lg_orc)
+            must_equal(f"cfg0.mm_bbox{l}", outs[l][1], bb_orc)
+            put(fx, f"mm_logits{l}", checksum(outs[l][0].permute(0, 2, 3, 1)))
+            put(fx, f"embed{l}", checksum(e_orc.permute(0, 2, 3, 1)))
+        flat = orc.head_flat(sd, p_orc, text_b, normalize_text=True)
+    pad, sf, ori = (0.0, 0.0, 0.0, 0.0), (1.0, 1.0), (hw, hw)               # the demo entry feeds a network-sized image
+    o = opp.mmdet_predict_image(flat["boxes"][0].numpy(), flat["scores"][0].numpy(), pad, sf, ori, effective=True)
+    fx["mm.img0.pad"], fx["mm.img0.sf"], fx["mm.img0.ori"] = np.asarray(pad), np.asarray(sf), np.asarray(ori)
+    for key in ("bboxes", "scores", "labels", "anchors"):
+        fx[f"mm.img0.{key}"] = o[key]
+    fx["mm.img0.margins"] = _margins(o)
+    fx["mm.img0.eff_margins"] = o["eff_margins"]
+    print(f"  kept {o['scores'].shape[0]}, margins {fx['mm.img0.margins']}, effective {o['eff_margins']}")
+    np.savez_compressed(os.path.join(OUT, f"mm_{arch}_b1_{hw}_cfg0.npz"), **fx)
+
+
 def case_letterbox(gp):
     """The reference's own ``letterbox`` (generate_proposal.py:17-82, PIL BILINEAR resize + paste) on
     seeded images: down-scale, up-scale, tall, wide, already-square."""
@@ -845,6 +916,12 @@ if __name__ == "__main__":
         for arch in sys.argv[i + 1:] or ["base", "large"]:
             case_robust(gp, arch, 80 if arch == "base" else 1203)
         sys.exit(0)
+    if "--only-tiny-cfg0" in sys.argv:
+        # plugin files first (they import transformers), then the torchvision stand-in of generate_proposal
+        import_wedetect_models()
+        gp = import_generate_proposal()
+        case_tiny_config0(gp)
+        sys.exit(0)
     if "--only-nms" in sys.argv:
         case_nms()
         sys.exit(0)
@@ -858,6 +935,7 @@ if __name__ == "__main__":
     # loaded BEFORE the bare torchvision stand-in goes into sys.modules
     case_mmdet_modules("tiny", 64)
     gp = import_generate_proposal()
+    case_tiny_config0(gp)
     case_filter_topk(gp)
     case_nms()
     case_retrieval()

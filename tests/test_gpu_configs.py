@@ -20,7 +20,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import assert_close, assert_no_relaxations, check_checksum, compare_kept_lists, golden, to_np
+from tests.util import KNOWN_NOISE_LEVEL_CASES, assert_close, assert_no_relaxations, check_checksum, compare_kept_lists, golden, to_np
 
 pytestmark = pytest.mark.gpu
 
@@ -70,9 +70,10 @@ def _run_config(arch, b, k, fixture, precision):
     res = {kk: v.clone() for kk, v in tower.postprocess(scores, 0.001, meta, with_embed=False, nms="mmcv").items()}
     torch.cuda.synchronize()
     n0 = int(res["count"][0])
-    compare_kept_lists(f"{tag} mmdet img0 vs round-1 reference golden (recorded)", res["anchors"][0, :n0], res["labels"][0, :n0],
+    compare_kept_lists(f"{tag} mmdet img0 vs round-1 reference golden", res["anchors"][0, :n0], res["labels"][0, :n0],
                        res["scores"][0, :n0], fx["mm.img0.anchors"], fx["mm.img0.labels"], fx["mm.img0.scores"], fx["mm.img0.margins"],
-                       got_boxes=res["bboxes"][0, :n0], ref_boxes=fx["mm.img0.bboxes"], assert_exact=False)
+                       got_boxes=res["bboxes"][0, :n0], ref_boxes=fx["mm.img0.bboxes"],
+                       assert_exact=f"{tag} mmdet img0" not in KNOWN_NOISE_LEVEL_CASES, allow=("tie_run",))
     assert min(fx_mm["mm.img0.eff_margins"][[0, 1, 3]]) > ROBUST_MIN and min(fx_un["img0.eff_margins"][[0, 1, 3]]) > ROBUST_MIN
     n1 = int(res["count"][1])
     compare_kept_lists(f"{tag} mmdet img1 vs margin-robust reference golden", res["anchors"][1, :n1], res["labels"][1, :n1],
@@ -94,9 +95,10 @@ def _run_config(arch, b, k, fixture, precision):
     torch.cuda.synchronize()
     n0 = int(res_u["count"][0])
     ref_boxes = opp.unletterbox(fx["img0.bboxes"], (0.0, 0.0), 1.0, (640, 640))
-    jj, gg = compare_kept_lists(f"{tag} uni img0 vs round-1 reference golden (recorded)", res_u["anchors"][0, :n0], res_u["labels"][0, :n0],
+    jj, gg = compare_kept_lists(f"{tag} uni img0 vs round-1 reference golden", res_u["anchors"][0, :n0], res_u["labels"][0, :n0],
                                 res_u["scores"][0, :n0], fx["img0.anchors"], fx["img0.labels"], fx["img0.scores"], fx["img0.margins"],
-                                got_boxes=res_u["bboxes"][0, :n0], ref_boxes=ref_boxes, assert_exact=False)
+                                got_boxes=res_u["bboxes"][0, :n0], ref_boxes=ref_boxes,
+                                assert_exact=f"{tag} uni img0" not in KNOWN_NOISE_LEVEL_CASES, allow=("tie_run",))
     assert_close(f"{tag} uni img0 embeddings[:, :16]", to_np(res_u["embeddings"][0])[jj][:, :16], fx["img0.embed16"][gg], 1e-3, 1e-3)
     assert_close(f"{tag} uni img0 boxes", to_np(res_u["bboxes"][0])[jj], ref_boxes[gg], 2e-2, 1e-5)
     n2 = int(res_u["count"][2])

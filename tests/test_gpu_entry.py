@@ -103,11 +103,16 @@ def test_config0_tiny_through_the_infer_wedetect_entry(tmp_path, precision):
     assert_close("full scores", pi.scores, o["scores"], 1e-3)
     tower = model._h.tower(1, 640, 640)
     n = len(pi)
-    gap = float(np.min(-np.diff(o["scores"]))) if n > 1 else 1.0
-    if gap > 2e-5:                                                              # no near-tie: the order must be exact
-        assert np.array_equal(to_np(tower.out_anchors[0, :n]), o["anchors"]) and np.array_equal(to_np(pi.labels), o["labels"])
-    else:
-        assert np.mean(to_np(pi.labels) == o["labels"]) > 0.97
+    # the full kept list, position by position (round 5: the "> 97 % of the labels" fallback for near-tie images is gone;
+    # the one allowance is the counted tie-run permutation among rows whose ORACLE scores are closer than the score
+    # difference measured in this very comparison — printed and logged by compare_kept_lists, a membership change fails)
+    from tests.util import compare_kept_lists
+    o_eff = opp.mmdet_predict_image(flat["boxes"][0].numpy(), flat["scores"][0].numpy(), np.zeros(4, np.float32), (1.0, 1.0), (640, 640),
+                                    effective=True)
+    mg = o_eff["margins"]
+    compare_kept_lists(f"configs[0] tiny entry [{precision}]", tower.out_anchors[0, :n], pi.labels, pi.scores, o["anchors"], o["labels"],
+                       o["scores"], [mg["iou_margin"], mg["pair_gap"], mg["kept_gap"], mg["cut_gap"]], got_boxes=pi.bboxes,
+                       ref_boxes=o["bboxes"], eff_margins=o_eff["eff_margins"], allow=("tie_run",))
 
 
 def test_cv_resize_kernel_bit_exact_vs_oracle():

@@ -126,20 +126,21 @@ def test_text_path_normalised_bank_vs_oracle():
 
 
 def _compare_detections(name, res, i, fx, prefix, ref_boxes=None):
-    """Kept (anchor, class) lists against the reference-generated golden: identical up to reorderings inside near-tie
-    runs of the reference's own scores (tests/util.py: compare_kept_lists), logged to gpurun_out/parity_r04.jsonl.
-    Exactness is ASSERTED for the small maps and for the margin-robust 640 x 640 goldens (effective decision margins
-    >= 2e-5 recorded by the generator); the round-1 640 x 640 golden, whose reference decisions sit at the noise level, is
-    recorded only (round-3 review)."""
-    from tests.util import compare_kept_lists
+    """Kept (anchor, class) lists against the reference-generated golden, logged to gpurun_out/parity_r05.jsonl.
+    Exactness is ASSERTED for every golden (round 5; round 4 recorded the round-1 640 x 640 goldens without asserting them
+    because their all-candidate margins sit at the noise level — they reproduce exactly all the same, so the downgrade
+    only hid regressions): identical position by position, the one allowance being a permutation inside a run of
+    reference scores closer than the measured noise (tests/util.py: tie_run).  A case is demoted to "recorded" only by
+    name, in tests.util.KNOWN_NOISE_LEVEL_CASES, after it has actually failed within the reference's own margins."""
+    from tests.util import KNOWN_NOISE_LEVEL_CASES, compare_kept_lists
     n = int(res["count"][i])
     margins = fx[f"{prefix}.margins"] if f"{prefix}.margins" in fx else None
     eff = fx[f"{prefix}.eff_margins"] if f"{prefix}.eff_margins" in fx else None
-    asserted = bool(min(eff[[0, 1, 3]]) > 2e-5) if eff is not None else int(fx["hw"]) < 640
-    return compare_kept_lists(f"{name} [{PRECISION['value']}]", res["anchors"][i, :n], res["labels"][i, :n], res["scores"][i, :n],
+    case = f"{name} [{PRECISION['value']}]"
+    return compare_kept_lists(case, res["anchors"][i, :n], res["labels"][i, :n], res["scores"][i, :n],
                               fx[f"{prefix}.anchors"], fx[f"{prefix}.labels"], fx[f"{prefix}.scores"], margins,
                               score_tol=TOL, got_boxes=res["bboxes"][i, :n] if ref_boxes is not None else None, ref_boxes=ref_boxes,
-                              assert_exact=asserted, eff_margins=eff)
+                              assert_exact=case not in KNOWN_NOISE_LEVEL_CASES, eff_margins=eff, allow=("tie_run",))
 
 
 @pytest.mark.parametrize("fixture,arch,b,hw", [("net_base_b1_64.npz", "base", 1, 64), ("net_base_b2_128.npz", "base", 2, 128),
@@ -183,6 +184,40 @@ def test_base_against_reference_goldens(fixture, arch, b, hw):
     for i in range(b):
         jj, gg = _compare_detections(f"{fixture} mmdet img{i}", res, i, fx, f"mm.img{i}", fx[f"mm.img{i}.bboxes"])
         assert_close(f"{fixture} mmdet img{i} boxes", to_np(res["bboxes"][i])[jj], fx[f"mm.img{i}.bboxes"][gg], 4e-2, 1e-5)
+
+
+def test_tiny_config0_against_the_reference_plugin_classes_at_640():
+    """BASELINE configs[0] (WeDetect-Tiny, one 640 x 640 image, 80 prompts + blank) against a fixture generated by the
+    REFERENCE's plugin classes at that size (make_golden.case_tiny_config0: wedetect/models ConvNextVisionBackbone('tiny') +
+    CSPRepBiFPANNeck(0.75, 'tiny') + the reference head module with Tiny's widths; round 4 pinned Tiny to the plugin
+    classes at 64 x 64 only).  Network checksums within 1e-3; the mmdet-path kept list position by position (effective
+    margins of the reference's decisions: IoU 7.8e-4, pair 2.3e-3 — three decades above the score noise)."""
+    from wedetect_amd import weights as W
+    fx = golden("mm_tiny_b1_640_cfg0.npz")
+    k = int(fx["k_text"])
+    sd_np, tower, imgs = build("tiny", 1, 640, num_prompts=0, seed=int(fx["seed_w"]), seed_img=int(fx["seed_img"]), max_classes=k)
+    tower.backbone(torch.from_numpy(imgs).cuda())
+    for i in range(4):
+        check_checksum(f"cfg0 c{i+1}", tower.x[i], fx, f"c{i+1}", TOL, TOL)
+    tower.neck()
+    for i, t in enumerate(tower.pyramid()):
+        check_checksum(f"cfg0 p{i+3}", t, fx, f"p{i+3}", TOL, TOL)
+    embed, boxes = tower.head()
+    for l in range(3):
+        check_checksum(f"cfg0 embed{l}", embed[:, tower.off[l]:tower.off[l] + tower.nl[l]], fx, f"embed{l}", TOL, TOL)
+    text = torch.from_numpy(W.make_text_bank(k) * np.float32(1.7)).cuda()
+    scores = tower.similarity(text, normalize=True, sigmoid=False)
+    for l in range(3):                                               # raw logits of every level against the reference head's
+        check_checksum(f"cfg0 mm_logits{l}", scores[:, tower.off[l]:tower.off[l] + tower.nl[l]], fx, f"mm_logits{l}", TOL, TOL)
+    scores = tower.similarity(text, normalize=True)
+    pad, sf, ori = fx["mm.img0.pad"], fx["mm.img0.sf"], fx["mm.img0.ori"]
+    meta = torch.tensor([[float(pad[2]), float(pad[0]), 0.0, float(sf[0]), float(sf[1]), float(ori[1]), float(ori[0]), 1.0]],
+                        dtype=torch.float32).cuda()
+    res = tower.postprocess(scores, 0.001, meta, with_embed=False, nms="mmcv")
+    torch.cuda.synchronize()
+    assert min(fx["mm.img0.eff_margins"][[0, 1, 3]]) > 2e-5
+    jj, gg = _compare_detections("mm_tiny_b1_640_cfg0 mmdet img0", res, 0, fx, "mm.img0", fx["mm.img0.bboxes"])
+    assert_close("cfg0 boxes", to_np(res["bboxes"][0])[jj], fx["mm.img0.bboxes"][gg], 4e-2, 1e-5)
 
 
 def test_large_and_tiny_goldens():

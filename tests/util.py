@@ -51,13 +51,20 @@ def check_checksum(name: str, got_nhwc, fx, prefix: str, atol: float, rtol: floa
 
 
 # ------------------------------------------------------------------------------------------ index parity
-PARITY_LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_r04.jsonl")
+PARITY_LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_r05.jsonl")
+# Reference-generated cases whose kept lists are RECORDED instead of asserted exact.  Round 4 demoted every 640 x 640 golden
+# of round 1 by image size; round 5 turns that round: every golden is asserted (a tie-run permutation inside the
+# reference's own near-tie scores is the one allowance), and a case is only ever listed here — by NAME, with the observation
+# that put it here — after it actually failed with the reference's effective margins inside the measured noise.
+# Empty: all of them still reproduce exactly (profiles/r04_parity.jsonl, profiles/r05_parity.jsonl).
+KNOWN_NOISE_LEVEL_CASES: dict = {}
 RELAXATIONS = []          # (case, kind) of every comparison in this process that was not position-by-position identical
 REPORTED = []             # (case, exact) of the comparisons run with assert_exact=False: noise-level references, recorded not asserted
 
 
 def compare_kept_lists(name, got_anchor, got_label, got_score, ref_anchor, ref_label, ref_score, margins=None,
-                       score_tol: float = 1e-3, got_boxes=None, ref_boxes=None, assert_exact: bool = True, eff_margins=None):
+                       score_tol: float = 1e-3, got_boxes=None, ref_boxes=None, assert_exact: bool = True, eff_margins=None,
+                       allow=("tie_run", "cut_swap")):
     """Index parity of a kept-detection list against the reference's (north_star: "box indices/classes bit-exact").
 
     The assertion is EXACTNESS: the (anchor, class) lists must be identical, position by position, and the scores within
@@ -78,7 +85,9 @@ def compare_kept_lists(name, got_anchor, got_label, got_score, ref_anchor, ref_l
     appended to RELAXATIONS and the parity log like a tie run.  (3) ``assert_exact=False``: record only (REPORTED, the
     parity log) — for the round-3 goldens, whose margins sit at the noise level and which stay as reported-not-asserted
     cases next to the margin-robust ones; scores are still held to ``score_tol`` and the overlap to 0.97.
-    Returns (rows of got, rows of ref) of the common detections and appends one JSON line to gpurun_out/parity_r04.jsonl."""
+    Round 5.  ``allow``: which counted relaxations an asserted comparison may take — the reference-generated goldens pass
+    ("tie_run",): a membership trade across the cut fails them.
+    Returns (rows of got, rows of ref) of the common detections and appends one JSON line to gpurun_out/parity_r05.jsonl."""
     import json
     ga, gl, gs = (np.asarray(to_np(x)) for x in (got_anchor, got_label, got_score))
     ra, rl, rs = (np.asarray(x) for x in (ref_anchor, ref_label, ref_score))
@@ -167,7 +176,7 @@ def compare_kept_lists(name, got_anchor, got_label, got_score, ref_anchor, ref_l
     if not assert_exact:
         assert overlap >= 0.97, f"{name} (reported, not asserted exact): overlap {overlap:.4f} with the reference list"
         return jj, gg
-    assert exact or relaxation in ("tie_run", "cut_swap"), (
+    assert exact or relaxation in tuple(allow), (
         f"{name}: kept (anchor, class) list differs from the reference (overlap {overlap:.4f}, score noise {noise:.2e}, "
         f"margins [iou, pair, kept, cut] {margins}, effective {eff_margins}; reference decisions within the measured noise: "
         f"{within_noise or 'none'})")

@@ -46,7 +46,11 @@ def source_hash() -> str:
 # inside asm blocks; scripts/check_asm_loads.py: no instruction may touch a register an asm load is still in flight to)
 # kernels whose inline-asm vmcnt counting assumes that the compiler adds no VMEM operation of its own (scratch spills /
 # reloads): the build fails if one of them needs scratch (stem.hip)
-NO_SCRATCH = {"stem.hip": ["stem_fused_kernel"]}
+NO_SCRATCH = {"stem.hip": ["stem_fused_kernel"], "split_gemm_mlpw.hip": ["fused_mlp_wide_kernel"],
+              "split_gemm_mlp.hip": ["fused_mlp128_kernel"], "split_gemm_p8.hip": ["split_gemm_p8_kernel"],
+              "split_gemm_p4.hip": ["split_gemm_p4_kernel"], "split_gemm_conv.hip": ["split_conv_pp_kernel"],
+              "split_gemm_conv3.hip": ["split_conv3_kernel"],
+              "split_gemm_pre.hip": ["split_gemm_pingpong_kernel", "split_gemm_glds_kernel"]}
 ASM_VMEM_SOURCES = {"split_gemm_mlpw.hip": ["fused_mlp_wide_kernel"], "split_gemm_mlp.hip": [], "split_gemm_p8.hip": [],
                     "split_gemm_p4.hip": [], "split_gemm_pre.hip": [], "split_gemm_conv.hip": [], "split_gemm_conv3.hip": [], "stem.hip": []}
 
@@ -68,9 +72,19 @@ def check_isa(src: str, verbose: bool = True) -> None:
     if src in NO_SCRATCH:
         import re
         meta = open(asm).read()
-        for m in re.finditer(r"\.name:\s+(\S+)(.*?)\.private_segment_fixed_size:\s+(\d+)", meta, re.S):
-            if any(k in m.group(1) for k in NO_SCRATCH[src]) and ".name:" not in m.group(2) and int(m.group(3)) != 0:
-                raise RuntimeError(f"{src}: kernel {m.group(1)} uses {m.group(3)} bytes of scratch — its counted vmcnt waits assume none")
+        meta = meta[meta.index("amdhsa.kernels"):] if "amdhsa.kernels" in meta else ""
+        seen = set()
+        for blk in meta.split("- .agpr_count")[1:]:               # one metadata record per kernel
+            name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+            scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1))
+            for k in NO_SCRATCH[src]:
+                if k in name:
+                    seen.add(k)
+                    if scratch != 0:
+                        raise RuntimeError(f"{src}: kernel {name} uses {scratch} bytes of scratch — its counted vmcnt waits assume none")
+        missing = [k for k in NO_SCRATCH[src] if k not in seen]
+        if missing:
+            raise RuntimeError(f"{src}: NO_SCRATCH names no kernel of this source: {missing}")
     os.remove(asm)
     if verbose:
         print(f"ISA checks passed: {src}", flush=True)

@@ -580,9 +580,14 @@ int launch_mlp_wide(MwArgs q, hipStream_t st, float* ws, long long ws_floats) {
   q.nblk = nblk;
   const int wgs = mw_workgroups();
   // persistent form: every XCD chain needs at least one whole row block per workgroup (a shorter range would chain serially)
-  const bool persist = ws != nullptr && wgs > 0 && nblk / 8 >= wgs / 8 && nblk > wgs &&
+  // The persistent form is built for C = 256 only (round 5): at C = 512 hipcc gives it 44 bytes of scratch (10 VGPR + 359
+  // SGPR spills) — scratch reloads are VMEM operations the counted vmcnt waits of the chunk loop do not know about, and
+  // the build now refuses scratch in every kernel that counts (build.py: NO_SCRATCH).  The 512-channel form is off by
+  // default (2-3 % slower than the two launches either way, profiles/r04_mlp_wide.txt) and keeps the tile form.
+  constexpr bool PERSIST_BUILT = C != 512;
+  const bool persist = PERSIST_BUILT && ws != nullptr && wgs > 0 && nblk / 8 >= wgs / 8 && nblk > wgs &&
                        ws_floats >= 1024 + (long long)wgs * (4 * P::TN2 * 4 * 256 * 4);
-  if (persist) {
+  if constexpr (PERSIST_BUILT) if (persist) {
     q.flag = reinterpret_cast<unsigned*>(ws);                     // first 4 KB: flags (zero between launches)
     q.park = ws + 1024;
     static WdAttrOnce attr;
