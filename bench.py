@@ -86,13 +86,16 @@ def measured_traffic(tag):
     if syms is None:
         return None, None
     syms = [syms] if isinstance(syms, str) else syms
-    for name in (("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_fp16x3_traffic.json") if tag.startswith("fp16x3") else ("r01_traffic.json",)):
+    for name in (("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_fp16x3_traffic.json")
+                 if tag.startswith("fp16x3") else ("r01_traffic.json",)):
         try:
             doc = json.load(open(os.path.join(ROOT, "profiles", name)))
             rec = doc["kernels"]
-            syms = [s_ for s_ in syms if s_ in rec]               # the instantiations that ran in the profiled step
-            n = sum(rec[s]["launches"] for s in syms)
-            val = round(sum(rec[s]["hbm_bytes_per_launch"] * rec[s]["launches"] for s in syms) / n)
+            present = [s_ for s_ in syms if s_ in rec]            # the instantiations that ran in the profiled step (per FILE:
+            if not present:                                       # an older file is still tried with the full symbol list)
+                continue
+            n = sum(rec[s_]["launches"] for s_ in present)
+            val = round(sum(rec[s_]["hbm_bytes_per_launch"] * rec[s_]["launches"] for s_ in present) / n)
             now = source_hash()
             return val, {"file": f"profiles/{name}", "commit": doc.get("commit"), "kernel_source_sha256": doc.get("kernel_source_sha256"),
                          "running_kernel_source_sha256": now, "taken_on_these_sources": doc.get("kernel_source_sha256") == now}
@@ -110,10 +113,15 @@ def parse():
     ap.add_argument("--arch", default="base")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--size", type=int, default=640)
-    ap.add_argument("--classes", type=int, default=80)
-    ap.add_argument("--mode", choices=["detect", "uni"], default="detect",
+    ap.add_argument("--classes", type=int, default=None, help="text bank size (default 80; 1 000 000 in --mode retrieval)")
+    ap.add_argument("--regions", type=int, default=300, help="--mode retrieval: kept regions per image")
+    ap.add_argument("--mode", choices=["detect", "uni", "retrieval"], default="detect",
                     help="detect: normalised text bank, thr 0.001, rescale-before-NMS (configs[1]); "
-                         "uni: WeDetect-Uni prompts as stored, thr 0.0, NMS in network pixels (configs[3])")
+                         "uni: WeDetect-Uni prompts as stored, thr 0.0, NMS in network pixels (configs[3]); "
+                         "retrieval: the object-retrieval scoring step of configs[4] — 300 kept regions per image against a "
+                         "1M-class bank, class-sharded over the ranks (retrieval_metric.py:367-377)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short legs of configs[2] / [3] / [4] that the default line carries in `other_configs` (N = 1 only)")
     ap.add_argument("--precision", choices=["fp32", "fp16x3"], default=None,
                     help="arithmetic of the dense convs/linears (default: wedetect_amd.engine.DEFAULT_PRECISION); "
                          "fp16x3 = fp32 operands split into fp16 hi+lo, three MFMA passes, fp32 accumulate")
@@ -129,7 +137,10 @@ def parse():
     ap.add_argument("--no-calibrate", action="store_true",
                     help="skip the untimed range-calibration pass (an fp32 run of the tower): keeps it out of a rocprofv3 trace")
     ap.add_argument("--cpu-runs", type=int, default=5, help="timed CPU-oracle passes per leg (median reported; 3 warm-ups)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.classes is None:
+        a.classes = 1_000_000 if a.mode == "retrieval" else 80
+    return a
 
 
 class GemmTimer:
@@ -417,6 +428,173 @@ def host_fed_run(tower, images, text, meta, uni, steps):
             "kept_rows_last_image": int(h_out["count"][-1])}
 
 
+def detect_leg(timer, L, arch, B, K, uni, steps=5, warmup=2):
+    """A short run of ANOTHER BASELINE configuration inside the default invocation (configs[2] / [3] were
+    builder-run files only): same protocol as the headline — calibration, ``warmup`` untimed steps, ``steps`` timed steps
+    issued back to back with the post-process on the second stream, wall clock around a full drain — and the per-launch
+    GEMM timing on the last step for the similarity GEMM's fraction."""
+    from wedetect_amd import weights as W
+    from wedetect_amd.engine import ImageTower
+    from wedetect_amd.pack import pack
+    S = 640
+    tower = ImageTower(arch, pack(W.make_state_dict(arch), arch), B, S, S, max_classes=K)
+    images = torch.from_numpy(W.make_images(B, S, S, seed=1234)).cuda()
+    text = torch.from_numpy(W.make_text_bank(K)).cuda()
+    meta = tower.identity_meta()
+    if not uni:
+        meta[:, 7] = 1.0
+    kw = dict(normalize_text=not uni, score_thr=0.0 if uni else 0.001, with_embed=True, overlap_post=True)
+    tower.calibrate(images)
+    timer.rec.clear()
+    timer.count, timer.mode = 0, "count"
+    for _ in range(warmup):
+        tower.detect(images, text, meta, **kw)
+    torch.cuda.synchronize()
+    timer.prepare(timer.count // max(1, warmup))
+    timer.mode = "off"
+    t0 = time.perf_counter()
+    for i in range(steps):
+        if i == steps - 1:
+            timer.mode = "time"
+        res = tower.detect(images, text, meta, **kw)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    timer.mode = "off"
+    summ = timer.summary()
+    timer.rec.clear()
+    out = {"workload": f"WeDetect-{arch.capitalize()}{'-Uni' if uni else ''}, batch {B}x{S}x{S}, {K}-class similarity, mode "
+                       f"{'uni' if uni else 'detect'}", "value": round(B / dt, 3), "unit": "images/s", "ms_per_step": round(1e3 * dt, 3),
+           "steps": steps, "warmup": warmup, "kept_regions_last_step": int(res["count"].sum().item()),
+           "fp16x3_range_guard_tripped": bool(tower.range_flags.any().item())}
+    sim = summ.get(L.gemm_config(B * tower.ntot, K, 768) + "/plain")
+    if sim is not None:
+        out["sim_gemm"] = {"m": B * tower.ntot, "n": K, "k": 768, "achieved": round(sim["tflops"], 2), "peak": F32_MFMA_PEAK_TFLOPS,
+                           "unit": "TFLOP/s", "frac": round(sim["tflops"] / F32_MFMA_PEAK_TFLOPS, 4), "avg_launch_us": round(sim["avg_us"], 2)}
+    if summ:
+        dom_tag = max(summ, key=lambda k_: summ[k_]["flops_total"])
+        if dom_tag.startswith("fp16x3"):
+            out["dominant_gemm"] = {"tag": dom_tag, "avg_launch_us": round(summ[dom_tag]["avg_us"], 2),
+                                    "frac": round(summ[dom_tag]["tflops"] / (F16_MFMA_PEAK_TFLOPS / SPLIT_PASSES), 4)}
+    del tower
+    torch.cuda.empty_cache()
+    return out
+
+
+BANK_SLICE = 125_000
+
+
+def make_bank_rows(lo: int, hi: int, dim: int, device, seed: int = 4321) -> torch.Tensor:
+    """Rows [lo, hi) of the synthetic unit-norm text bank (N(0, 1) rows, L2-normalised), generated on the
+    device in fixed slices of 125 000 rows seeded by the slice index — the same bank whatever the class shard."""
+    out = torch.empty(hi - lo, dim, dtype=torch.float32, device=device)
+    for j in range(lo // BANK_SLICE, (hi + BANK_SLICE - 1) // BANK_SLICE):
+        a, b = max(lo, j * BANK_SLICE), min(hi, (j + 1) * BANK_SLICE)
+        g = torch.Generator(device=device).manual_seed(seed + j)
+        blk = torch.nn.functional.normalize(torch.randn(BANK_SLICE, dim, device=device, generator=g), dim=-1)
+        out[a - lo:b - lo] = blk[a - j * BANK_SLICE:b - j * BANK_SLICE]
+        del blk
+    return out
+
+
+class RetrievalTimer:
+    """HIP-event duration of the scoring kernel's own dispatch (wd_time_next_gemm), on selected steps."""
+
+    def __init__(self, lib):
+        self.lib, self.on, self.rec = lib, False, []
+        self._orig = lib.retrieval_max_split
+
+        def wrapped(*a, **kw):
+            if not self.on:
+                return self._orig(*a, **kw)
+            s_, e_ = GemmTimer._pair()
+            lib.time_next_gemm(s_, e_)
+            self._orig(*a, **kw)
+            self.rec.append((s_, e_))
+        lib.retrieval_max_split = wrapped
+
+    def avg_us(self):
+        return 1e3 * sum(a.elapsed_time(b) for a, b in self.rec) / max(1, len(self.rec))
+
+    def restore(self):
+        self.lib.retrieval_max_split = self._orig
+
+
+def retrieval_leg(L, n_img, regions, K, rank, world, steps, warmup, dist=None):
+    """configs[4]: per step, the kept regions of ``n_img`` images per rank ([n_img, regions, 768] resident in HBM) are scored
+    against a K-class bank — sigmoid(<e, t> exp(scale) + bias), max over an image's regions, logits never materialised
+    (retrieval_metric.py:367-377).  N > 1: images AND the bank are sharded (parallel.class_sharded_retrieval: all-gather of
+    the regions, every rank scores all images against its K / N classes, all-gather of the score blocks).  Returns the
+    JSON pieces: seconds per step (max over ranks is the caller's), the kernel's average launch time and its work."""
+    from wedetect_amd.parallel import BankScorer, class_sharded_retrieval, shard_range
+    dev = torch.device("cuda", torch.cuda.current_device())
+    D = 768
+    g = torch.Generator(device=dev).manual_seed(777 + rank)
+    e = torch.randn(n_img, regions, D, device=dev, generator=g) * 1.4
+    sc = torch.randn(n_img, regions, device=dev, generator=g) * 0.1 - 0.35
+    bi = torch.randn(n_img, regions, device=dev, generator=g) * 0.2 - 2.6
+    cnt = torch.full((n_img,), regions, dtype=torch.int32, device=dev)
+    mine = shard_range(K, world, rank)
+    shard = make_bank_rows(mine.start, mine.stop, D, dev)
+    scorer = BankScorer(shard)
+    score_fn = lambda e_, c_, s_, b_, bank_: scorer(e_, c_, s_, b_, check=False)     # the range flag is read once, after the run
+    rt = RetrievalTimer(L)
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(warmup):
+        out = class_sharded_retrieval(e, cnt, sc, bi, shard, K, score_fn=score_fn)
+    sync()
+    n_inst = min(steps, 2)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        rt.on = i >= steps - n_inst
+        out = class_sharded_retrieval(e, cnt, sc, bi, shard, K, score_fn=score_fn)
+    sync()
+    dt = time.perf_counter() - t0
+    rt.on = False
+    rt.restore()
+    rows = world * n_img * regions
+    flops = 2.0 * rows * len(mine) * D
+    nbytes = 4.0 * (len(mine) * D + rows * D + world * n_img * len(mine))
+    us = rt.avg_us()
+    tf = flops / (us * 1e-6) / 1e12 if us > 0 else 0.0
+    peak = round(F16_MFMA_PEAK_TFLOPS / SPLIT_PASSES, 1) if scorer.precision == "fp16x3" else F32_MFMA_PEAK_TFLOPS
+    return dict(dt=dt, precision=scorer.precision, tripped=scorer.tripped(), checksum=float(out[:, :: max(1, K // 4096)].double().sum().item()),
+                roofline={"kernel": ("split_gemm_p8_kernel<retrieval: bank rows x region rows, fp16x3 256x256x32/8w, in-register max over "
+                                     "regions + one sigmoid per (image, class)> (3 x v_mfma_f32_32x32x16_f16 per product)"
+                                     if scorer.precision == "fp16x3" else "retrieval_max_kernel (fp32 MFMA 16x16x4)"),
+                          "bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+                          "traffic": None, "timing": f"HIP events stamped by the kernel's own dispatch, last {n_inst} of the {steps} timed steps",
+                          "avg_launch_us": round(us, 1), "launches_per_step": 1,
+                          "algorithmic_gflop_per_launch": round(flops / 1e9, 2), "algorithmic_bytes_per_launch": int(nbytes),
+                          "peak_note": (f"fp16 dense MFMA peak {F16_MFMA_PEAK_TFLOPS} / {SPLIT_PASSES} passes per product"
+                                        if scorer.precision == "fp16x3" else "fp32 MFMA dense peak")})
+
+
+def retrieval_cpu_baseline(regions, K, sample_images=2, sample_classes=100_000):
+    """The oracle's retrieval lines (oracle/postprocess.py: retrieval_scores, the torch-fp32 op sequence of
+    retrieval_metric.py:369-375) on a bounded sample: ``sample_images`` images x ``sample_classes`` classes, timed on the usable
+    host cores; images/s at the full bank = the measured rate x sample_classes / K (the work is linear in the classes)."""
+    from oracle import postprocess as opp
+    torch.set_num_threads(usable_cores())
+    g = np.random.default_rng(5)
+    t = g.standard_normal((sample_classes, 768)).astype(np.float32)
+    t /= np.linalg.norm(t, axis=1, keepdims=True)
+    e = (g.standard_normal((sample_images, regions, 768)) * 1.4).astype(np.float32)
+    sc = np.full(regions, -0.35, np.float32)
+    bi = np.full(regions, -2.6, np.float32)
+    opp.retrieval_scores(e[0], t, sc, bi)
+    t0 = time.perf_counter()
+    for i in range(sample_images):
+        opp.retrieval_scores(e[i], t, sc, bi)
+    per_img = (time.perf_counter() - t0) / sample_images
+    return dict(value=round(sample_classes / K / per_img, 5), unit="images/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"oracle/postprocess.py retrieval_scores (torch fp32 einsum + sigmoid + max) on {sample_images} images x {regions} "
+                       f"regions x {sample_classes} classes: {per_img:.3f} s per image; value = that rate scaled to {K} classes (linear in K)")
+
+
 def launch_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, rendezvous on
     127.0.0.1) and pass their output through — rank 0 prints the one JSON line, everything else goes to stderr."""
@@ -457,14 +635,27 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dist = None
+    from wedetect_amd.parallel import PhaseWatchdog
+    # every rank carries its own progress deadline: a rank that makes no progress for WEDETECT_BENCH_TIMEOUT seconds
+    # (default 300) prints "rank r: stuck in <phase>" and exits non-zero, which makes the launcher fail the whole run —
+    # a hung rank names itself instead of leaving seven others waiting in a collective forever
+    dog = PhaseWatchdog(rank, float(os.environ.get("WEDETECT_BENCH_TIMEOUT", "300")))
+    dog.phase("process-group initialisation")
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # the image exports NCCL_DEBUG=VERSION, which makes RCCL print a version banner on STDOUT
         # (next to the one JSON line this script owes the driver): keep warnings, drop the banner
         if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
             os.environ["NCCL_DEBUG"] = "WARN"
-        dist.init_process_group(backend=os.environ.get("WEDETECT_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+        backend = os.environ.get("WEDETECT_BENCH_BACKEND", "nccl")
+        pg_kw = dict(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=dog.timeout_s))
+        if backend == "nccl":
+            # bind the communicator to THIS rank's device up front: barrier() otherwise guesses the device from the current
+            # context (the warning in GPUTEST_r04) and a wrong guess hangs on a multi-GPU node
+            pg_kw["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(**pg_kw)
 
     from wedetect_amd import lib as L
     from wedetect_amd import weights as W
@@ -473,6 +664,47 @@ def main():
     from wedetect_amd.parallel import RegionGatherer
 
     B, S, K = args.batch, args.size, args.classes
+    if args.mode == "retrieval":
+        dog.phase("retrieval leg")
+        r = retrieval_leg(L, B, args.regions, K, rank, world, args.steps, args.warmup, dist)
+        dt = r["dt"]
+        ranks_seen, backend_name = 1, None
+        if dist is not None:
+            dog.phase("closing collectives")
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+            one = torch.ones(1, dtype=torch.int32, device="cuda")
+            dist.all_reduce(one, op=dist.ReduceOp.SUM)
+            ranks_seen, backend_name = int(one.item()), str(dist.get_backend())
+        if rank == 0:
+            out = {"metric": f"images/s, object retrieval: {args.regions} kept regions per image x {K}-class text bank "
+                             "(sigmoid(<e, t> exp(scale) + bias), max over regions; logits never materialised)",
+                   "value": round(world * B * args.steps / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+                   "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+                   "vs_baseline": None,
+                   "dtype": ("f32-equivalent: fp32 operands carried as fp16 hi+lo pairs, 3 fp16-MFMA passes per product, fp32 accumulate "
+                             "(fp16x3), fp32 epilogue" if r["precision"] == "fp16x3" else "f32"),
+                   "data": "synthetic",
+                   "config": {"workload": f"configs[4]: {B} images per GPU x {args.regions} regions x 768 against a {K}-class bank"
+                                          + (f", class-sharded x{world} ({K // world} classes per GPU) + all-gather of regions and score blocks"
+                                             if world > 1 else ""),
+                              "global_batch": world * B, "per_gpu_batch": B, "regions_per_image": args.regions, "classes": K,
+                              "parallelism": f"image-shard x{world} + class-shard x{world}" if world > 1 else "one GPU, whole bank",
+                              "precision": r["precision"], "fp16x3_range_guard_tripped": r["tripped"], "score_checksum": r["checksum"]},
+                   "roofline": r["roofline"]}
+            if world > 1:
+                out["ranks_seen"], out["collective_backend"] = ranks_seen, backend_name
+            if world == 1 and not args.no_cpu_baseline:
+                dog.phase("cpu baseline")
+                out["cpu_baseline"] = retrieval_cpu_baseline(args.regions, K)
+            print(json.dumps(out), flush=True)
+        if dist is not None:
+            dog.phase("final barrier")
+            dist.barrier()
+            dist.destroy_process_group()
+        dog.stop()
+        return
     tower = ImageTower(args.arch, pack(W.make_state_dict(args.arch), args.arch), B, S, S, max_classes=K,
                        precision=args.precision, split_k=args.split_k or None)
     split = tower.precision == "fp16x3"
@@ -485,7 +717,7 @@ def main():
     timer = GemmTimer(L)
     timer.install()
 
-    gatherer = RegionGatherer() if world > 1 else None
+    gatherer = RegionGatherer(timeout_s=dog.timeout_s) if world > 1 else None
     lvl_scale = torch.tensor(tower.lvl_logit_scale, dtype=torch.float32, device="cuda")
     lvl_bias = torch.tensor(tower.lvl_bias, dtype=torch.float32, device="cuda")
     image_ids = torch.arange(rank * B, (rank + 1) * B, dtype=torch.int64, device="cuda")
@@ -521,12 +753,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    dog.phase("calibration + warm-up")
     if not args.no_calibrate:
         tower.calibrate(images)             # as the detectors do on a tower's first batch (untimed; all scales 1 here)
     timer.mode = "count"
     for _ in range(args.warmup):
         step()
     sync()
+    dog.phase("timed steps")
     # per-launch kernel timing covers the LAST n_inst steps of the timed region only: stamping every launch costs the
     # step ~1.2 ms (2.4 %: scripts/step_timer_overhead.py), so the headline would otherwise measure its own probe
     n_inst = min(args.steps, 1 if args.steps < 4 else 2)
@@ -545,6 +779,7 @@ def main():
     timer.mode = "off"
     per_rank = None
     ranks_seen, backend_name = 1, None
+    dog.phase("closing collectives")
     if dist is not None:
         own = dict(rank=rank, ms_per_step=round(1e3 * dt / args.steps, 3),
                    gather_handover_ms_per_step=round(sum(a.elapsed_time(b) for a, b in stall) / max(1, len(stall)), 3))
@@ -631,6 +866,8 @@ def main():
             out["sim_gemm"] = {"kernel": f"conv_gemm_kernel<{sim_tag}>", "m": B * tower.ntot, "n": K, "k": 768,
                                "achieved": round(sim["tflops"], 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(sim["tflops"] / F32_MFMA_PEAK_TFLOPS, 4), "avg_launch_us": round(sim["avg_us"], 2)}
+        dog.phase("side legs (fp32 reference, host-fed, other configurations, cpu baseline)")
+        dog.timeout_s = max(dog.timeout_s, 900.0)
         if world == 1 and split and not args.no_fp32_reference:
             # the same workload with native fp32 MFMA arithmetic, measured in this run (same images, weights, bank)
             out["fp32_mode"] = fp32_reference_run(args, tower, images, text, meta, uni)
@@ -640,12 +877,26 @@ def main():
             out["per_rank"] = per_rank
             out["ranks_seen"] = ranks_seen          # all_reduce(1) over the job's process group: the collective library saw this many
             out["collective_backend"] = backend_name
+        if (world == 1 and split and not args.no_other_configs
+                and (B, S, K, args.arch, args.mode) == (32, 640, 80, "base", "detect")):
+            # configs[2], [3] (one rank's share) and [4] (per-GPU form, whole bank) in the driver's one line: five timed steps
+            # each after two warm-ups, same protocol as the headline
+            other = {}
+            other["configs[2] large_b16_k1203"] = detect_leg(timer, L, "large", 16, 1203, uni=False)
+            other["configs[3] base_uni_b32_k256 (one rank's step; the exchange is the --gpus N path)"] = detect_leg(timer, L, "base", 32, 256, uni=True)
+            r = retrieval_leg(L, 32, 300, 1_000_000, 0, 1, steps=5, warmup=2)
+            other["configs[4] retrieval_1m_classes (per-GPU form: 32 images x 300 regions, whole bank)"] = {
+                "value": round(32 * 5 / r["dt"], 3), "unit": "images/s", "ms_per_step": round(1e3 * r["dt"] / 5, 3), "steps": 5, "warmup": 2,
+                "precision": r["precision"], "fp16x3_range_guard_tripped": r["tripped"], "roofline": r["roofline"]}
+            out["other_configs"] = other
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.arch, S, K, args.cpu_runs)
         print(json.dumps(out), flush=True)
     if dist is not None:
+        dog.phase("final barrier")
         dist.barrier()
         dist.destroy_process_group()
+    dog.stop()
 
 
 if __name__ == "__main__":

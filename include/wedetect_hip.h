@@ -237,14 +237,18 @@ int wd_letterbox_u8(const uint8_t* src, int32_t h, int32_t w, const int32_t* bou
                     uint8_t* dst, int32_t dst_h, int32_t dst_w, int32_t new_w, int32_t new_h, int32_t left, int32_t top,
                     int32_t fill_r, int32_t fill_g, int32_t fill_b, void* stream);
 
-/* wd_retrieval_max in fp16x3 arithmetic (2-3x the fp32 kernel at large banks): both operands as fp16
- * (hi, lo) groups from wd_split_weights — e_split: the [n_img * rows_per_img, dim] region rows with
- * scale 1, t_split: the [n_cls, dim] bank with a power-of-two scale = 1 / t_unscale.  Same result
- * definition as wd_retrieval_max (retrieval_metric.py:367-377); out is zeroed, then max-reduced with
- * atomics (deterministic: max is order independent).  dim % 16 == 0. */
+/* wd_retrieval_max in fp16x3 arithmetic (2-4x the fp32 kernel at large banks): both operands as fp16
+ * (hi, lo) groups from wd_split_weights (whose buffers are padded to whole groups of 8 rows: the kernel fetches
+ * 8-row groups) — e_split: the [n_img * rows_per_img, dim] region rows with scale 1, t_split: the [n_cls, dim]
+ * bank with a power-of-two scale = 1 / t_unscale.  Same result definition as wd_retrieval_max
+ * (retrieval_metric.py:367-377; sigmoid is applied to the maximum of the affine logits — it is monotone); out is
+ * zeroed, then max-reduced with atomics (deterministic: max is order independent).  dim % 16 == 0; with
+ * dim % 32 == 0 and 16-byte aligned scale / bias the 256 x 256 kernel runs (ABI 13).
+ * range_flag (may be NULL; ABI 13): set to 1 (sticky) when an accumulator is inf / NaN, i.e. an operand left
+ * the fp16 range — the caller repeats the step with wd_retrieval_max (fp32). */
 int wd_retrieval_max_split(const void* e_split, const void* t_split, float t_unscale, const float* scale,
                            const float* bias, const int32_t* count, float* out, int32_t n_img, int32_t rows_per_img,
-                           int32_t n_cls, int32_t dim, void* stream);
+                           int32_t n_cls, int32_t dim, uint32_t* range_flag, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Text tower pieces (mm_backbone.py:341-390, HF XLMRobertaModel): the embedding

@@ -625,3 +625,73 @@ def test_region_gather_world2_gloo():
         assert len(piped) == 3
         for step, (pe, pc) in enumerate(piped):
             assert pe == [i + 10.0 * step for i in range(6)] and pc == [i % 5 + 1 + step for i in range(6)]
+
+
+# ------------------------------------------------------------------------------------------ failure paths of the N > 1 run (round 5)
+def test_phase_watchdog_names_the_rank_and_phase():
+    """PhaseWatchdog: no progress mark within the deadline -> the rank reports itself and the phase it is stuck in (the
+    default action, os._exit(3), is replaced by a callback here); marks that keep coming never trip it."""
+    import time
+    from wedetect_amd.parallel import PhaseWatchdog
+    fired = []
+    dog = PhaseWatchdog(5, 0.3, on_expire=lambda d: fired.append(d.expired), poll_s=0.05)
+    for _ in range(8):                                        # 0.8 s of steady progress: silent
+        dog.phase("timed steps")
+        time.sleep(0.1)
+    assert not fired
+    dog.phase("region gather")
+    time.sleep(0.7)
+    assert len(fired) == 1 and fired[0].startswith("rank 5: no progress for") and "'region gather'" in fired[0]
+    quiet = PhaseWatchdog(0, 0.2, on_expire=lambda d: fired.append("late"), poll_s=0.05)
+    quiet.stop()
+    time.sleep(0.4)
+    assert fired == fired[:1]
+
+
+def _hung_rank_worker(rank, world, port, q):
+    import os
+    import time
+    import torch.distributed as dist
+    from wedetect_amd.parallel import RegionGatherer
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=30))
+    g = RegionGatherer(timeout_s=1.5)
+    emb, cnt = torch.full((2, 3, 4), float(rank)), torch.tensor([3, 1], dtype=torch.int32)
+    g.submit(emb, cnt)
+    first = g.collect()                                       # both ranks take part: completes
+    ok = first["embeddings"][:, 0, 0].tolist() == [0.0, 0.0, 1.0, 1.0]
+    if rank == 1:                                             # rank 1 "hangs": it never submits the second step
+        time.sleep(4.0)
+        q.put((rank, ok, "slept"))
+        q.close(); q.join_thread()
+        os._exit(0)
+    g.submit(emb, cnt)
+    try:
+        g.collect()
+        q.put((rank, ok, "completed"))
+    except RuntimeError as ex:
+        q.put((rank, ok, str(ex)))
+    q.close(); q.join_thread()                                # flush the queue's feeder thread before the hard exit
+    os._exit(0)                                               # the process group is wedged by design: no clean destroy
+
+
+def test_a_hung_rank_fails_the_gather_with_rank_and_collective_named():
+    """A rank that stops submitting must not leave the others waiting for the backend's 30-minute default: the bounded
+    wait of RegionGatherer.collect raises within its deadline and names the rank that waited and the collective."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hung_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = dict()
+    for _ in procs:
+        rank, ok, msg = q.get(timeout=120)
+        outs[rank] = (ok, msg)
+    for p in procs:
+        p.join(timeout=60)
+    assert outs[0][0] and outs[1][0]
+    assert outs[1][1] == "slept"
+    assert outs[0][1].startswith("rank 0: collective 'region gather: embeddings' did not complete within 2 s"), outs[0][1]

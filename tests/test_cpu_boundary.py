@@ -142,8 +142,12 @@ def test_detector_options_are_honoured_or_refused():
         YOLOWorldDetector("nano", test_cfg=dict(nms=dict(type="nms", iou_threshold=0.5, class_agnostic=True)))
     # round 4: mmcv's max_num / score_threshold fold into max_per_img / score_thr (keep[:max_num] then results[:max_per_img];
     # two strict score filters around a top-k are one filter with the larger threshold)
-    d = YOLOWorldDetector("nano", test_cfg=dict(max_per_img=300, nms=dict(type="nms", iou_threshold=0.5, max_num=120, score_threshold=0.05)))
+    d = YOLOWorldDetector("nano", test_cfg=dict(max_per_img=300, nms_pre=5000, nms=dict(type="nms", iou_threshold=0.5, max_num=120, score_threshold=0.05)))
     assert d._h.max_out == 120 and d.test_cfg["score_thr"] == 0.05
+    # round 5: mmcv picks its branch on the PRE-filter count; when nms_pre candidates can reach split_thr the merged filter
+    # cannot reproduce that and the option is refused (a score_threshold BELOW score_thr filters nothing and stays legal)
+    with pytest.raises(NotImplementedError, match="score_threshold"):
+        YOLOWorldDetector("nano", test_cfg=dict(max_per_img=300, nms=dict(type="nms", iou_threshold=0.5, score_threshold=0.05)))
     d = YOLOWorldDetector("nano", test_cfg=dict(max_per_img=100, score_thr=0.1, nms=dict(type="nms", iou_threshold=0.5, max_num=500, score_threshold=0.05)))
     assert d._h.max_out == 100 and d.test_cfg["score_thr"] == 0.1
     # split_thr is mmcv.ops.batched_nms' own option and reaches wd_nms_gather as mode_param

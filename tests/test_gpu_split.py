@@ -30,8 +30,9 @@ def test_split_weights_layout_bit_exact():
         hi = x.astype(np.float16)
         lo = (x - hi.astype(np.float32)).astype(np.float16)
         want = np.stack([hi.reshape(n, k16 // 8, 8), lo.reshape(n, k16 // 8, 8)], axis=2).reshape(n, 2 * k16)
-        got = to_np(buf).view(np.float16).reshape(n, 2 * k16)
-        assert np.array_equal(got.view(np.uint16), want.view(np.uint16))
+        n8 = (n + 7) // 8 * 8                      # round 5: rows zero-padded to whole groups of eight (DMA-fed kernels fetch 8-row groups)
+        got = to_np(buf).view(np.float16).reshape(n8, 2 * k16)
+        assert np.array_equal(got[:n].view(np.uint16), want.view(np.uint16)) and not got[n:].view(np.uint16).any()
         # hi + lo reproduces the scaled weight to 2^-22 relative
         rec = hi.astype(np.float64) + lo.astype(np.float64)
         assert np.max(np.abs(rec - x) / np.maximum(np.abs(x), 1e-30)) < 2.0 ** -21
@@ -290,6 +291,75 @@ def test_retrieval_max_split_matches_fp32_kernel_and_shards():
         parts.append(o)
     # every shard picks its own power-of-two weight scale: exact, so the shards reproduce the whole-bank bits
     assert torch.equal(torch.cat(parts, dim=1), out)
+
+
+@pytest.mark.parametrize("n_img,rows,k,dim", [(5, 300, 10_000, 768), (3, 300, 1203, 768), (7, 20, 515, 64), (33, 7, 264, 96),
+                                              (2, 301, 81, 768), (1, 64, 8, 32), (4, 129, 2049, 256)])
+def test_retrieval_on_the_256_tile_kernel(n_img, rows, k, dim, monkeypatch):
+    """Round 5: wd_retrieval_max_split on the 256 x 256 kernel with the operand roles swapped (bank = lane axis, region rows =
+    register axis, in-register max, ONE sigmoid per (image, class)) against (a) fp64 torch on the definition of
+    retrieval_metric.py:369-375, (b) the 256 x 128 ping-pong form it replaces ($WEDETECT_RETR_P8=0), (c) itself on a
+    class-sharded bank (bit for bit).  Shapes: class counts that are no multiple of 8 (padded split buffers), images of
+    7 / 20 rows (many images per 64-row wave block), 301 rows (every wave block straddles), ragged and zero counts."""
+    import os
+    from wedetect_amd import lib as L
+    from wedetect_amd.parallel import shard_range
+    g = torch.Generator(device="cuda").manual_seed(11 + n_img)
+    e = torch.randn(n_img, rows, dim, device="cuda", generator=g) * (1.4 * (768 / dim) ** 0.5)
+    t = torch.nn.functional.normalize(torch.randn(k, dim, device="cuda", generator=g), dim=-1)
+    scale = torch.randn(n_img, rows, device="cuda", generator=g) * 0.1 - 0.35
+    bias = torch.randn(n_img, rows, device="cuda", generator=g) * 0.2 - 2.6
+    cnt = torch.randint(0, rows + 1, (n_img,), device="cuda", generator=g, dtype=torch.int32)
+    cnt[0] = rows
+    if n_img > 2:
+        cnt[1], cnt[2] = 0, 1
+    ts = L.split_weights(t)
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    monkeypatch.setenv("WEDETECT_RETR_P8", "1")
+    out = torch.full((n_img, k), -1.0, device="cuda")
+    L.retrieval_max_split(e, ts, scale, bias, cnt, out, n_img, rows, k, dim, range_flag=flag)
+    monkeypatch.setenv("WEDETECT_RETR_P8", "0")
+    old = torch.full((n_img, k), -1.0, device="cuda")
+    L.retrieval_max_split(e, ts, scale, bias, cnt, old, n_img, rows, k, dim)
+    monkeypatch.setenv("WEDETECT_RETR_P8", "1")
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0
+    lg = torch.einsum("nrd,kd->nrk", e.double(), t.double()) * scale.double().exp()[..., None] + bias.double()[..., None]
+    valid = torch.arange(rows, device="cuda")[None, :] < cnt[:, None]
+    ref = torch.where(valid[..., None], torch.sigmoid(lg), torch.zeros((), dtype=torch.float64, device="cuda")).amax(dim=1)
+    assert_close("retrieval p8 vs fp64", out, ref, 3e-6)
+    assert_close("retrieval p8 vs the ping-pong form", out, old, 1e-6)
+    assert torch.equal(out == 0, ref == 0)                             # images / rows without regions: exactly 0
+    parts = []
+    for r in range(3):
+        sr = shard_range(k, 3, r)
+        o = torch.empty(n_img, len(sr), device="cuda")
+        L.retrieval_max_split(e, L.split_weights(t[sr.start:sr.stop].contiguous()), scale, bias, cnt, o, n_img, rows, len(sr), dim)
+        parts.append(o)
+    assert torch.equal(torch.cat(parts, dim=1), out)
+    # the range guard: one embedding beyond the fp16 maximum raises the flag
+    e2 = e.clone()
+    e2[0, 0, 0] = 1e5
+    L.retrieval_max_split(e2, ts, scale, bias, cnt, out, n_img, rows, k, dim, range_flag=flag)
+    assert int(flag.item()) == 1
+
+
+def test_bank_scorer_falls_back_to_fp32_when_an_embedding_leaves_the_fp16_range():
+    from wedetect_amd.parallel import BankScorer
+    g = torch.Generator(device="cuda").manual_seed(3)
+    n, r, d, k = 4, 300, 768, 640
+    e = torch.randn(n, r, d, device="cuda", generator=g)
+    bank = torch.nn.functional.normalize(torch.randn(k, d, device="cuda", generator=g), dim=-1)
+    sc, bi = torch.full((n, r), -0.4, device="cuda"), torch.full((n, r), -2.0, device="cuda")
+    cnt = torch.full((n,), r, dtype=torch.int32, device="cuda")
+    fast, exact = BankScorer(bank), BankScorer(bank, "fp32")
+    assert fast.precision == "fp16x3"
+    assert_close("fp16x3 scorer vs fp32 scorer", fast(e, cnt, sc, bi), exact(e, cnt, sc, bi), 3e-6)
+    assert not fast.overflowed
+    e[1, 5, 7] = 9e4
+    with pytest.warns(UserWarning, match="fp16 range"):
+        got = fast(e, cnt, sc, bi)
+    assert fast.overflowed and fast.precision == "fp32" and torch.equal(got, exact(e, cnt, sc, bi))
 
 
 @pytest.mark.parametrize("m,n,k", [(264, 320, 64), (1000, 256, 96), (520, 512, 128), (2048, 768, 1024), (304, 40, 160), (257, 320, 64), (8, 8, 32)])

@@ -32,9 +32,9 @@ namespace {
 __global__ void split_weights_kernel(const float* __restrict__ w, int n, int k, int k16, float scale,
                                      unsigned short* __restrict__ out) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long long)n * k16) return;
+  if (idx >= (long long)((n + 7) & ~7) * k16) return;              // rows zero-padded to a whole group of eight (round 5)
   const int row = (int)(idx / k16), kk = (int)(idx % k16);
-  const float x = kk < k ? w[(size_t)row * k + kk] * scale : 0.0f;
+  const float x = (kk < k && row < n) ? w[(size_t)row * k + kk] * scale : 0.0f;
   const _Float16 hi = (_Float16)x;
   const _Float16 lo = (_Float16)(x - (float)hi);
   unsigned short* o = out + (size_t)row * 2 * k16 + (kk >> 3) * 16 + (kk & 7);
@@ -78,13 +78,13 @@ int launch_reduce(const WdConvGemm& p, const float* ws, int splits, float unscal
 
 extern "C" int64_t wd_split_weights_bytes(int32_t n, int32_t k) {
   if (n <= 0 || k <= 0) return 0;
-  return (int64_t)n * ((k + 15) / 16 * 16) * 4;
+  return (int64_t)((n + 7) & ~7) * ((k + 15) / 16 * 16) * 4;          // rows padded to 8: DMA-fed kernels fetch whole 8-row groups
 }
 
 extern "C" int wd_split_weights(const float* w, int32_t n, int32_t k, float scale, void* out, void* stream) {
   if (!w || !out || n <= 0 || k <= 0 || !(scale > 0.0f) || !wd_aligned16(out)) return WD_ERR_BAD_ARG;
   const int k16 = (k + 15) / 16 * 16;
-  const long long total = (long long)n * k16;
+  const long long total = (long long)((n + 7) & ~7) * k16;
   hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), w, n, k, k16, scale, static_cast<unsigned short*>(out));
   return wd_launch_status();

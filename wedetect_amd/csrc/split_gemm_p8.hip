@@ -103,10 +103,99 @@ struct P8Persist {
   int ntiles;            // gang tiles: row panels x column groups
 };
 
+// ---- retrieval scoring on this kernel (round 5; wd_retrieval_max_split, retrieval_metric.py:367-377) ----------------------
+// The GEMM is run with the operand ROLES SWAPPED: the text bank is the "activation" operand (p.a, p.m = classes of this
+// launch) and the region rows of all images, back to back, are the "weight" operand (wsp, p.n = region rows).  In the
+// accumulator layout of v_mfma_f32_32x32x16 the activation row is the LANE and the weight row the REGISTER, so a lane then
+// holds, for ONE class, 32 of the wave's 64 region rows: the max over an image's regions is 31 in-register v_max plus one
+// lane exchange (the form on the 256 x 128 ping-pong kernel — classes in registers, rows in lanes — paid a five-step
+// segmented shuffle reduction PER VALUE: ~28 VALU instructions per accumulator element).  sigmoid is monotone, so it is
+// applied once to the maximum of the affine logits instead of to every (row, class): max_r s(x_r) = s(max_r x_r).
+// Tile order: region-row tiles in groups of eight, four bank blocks x eight row tiles live per XCD at a time (the gang
+// order of the MLP launches): per 32 tiles an L2 fetches 12 operand panels instead of 33, the bank streams from HBM once per
+// row-tile group (five times for 32 images x 300 regions), the region rows (29 MB) stay in the Infinity Cache.
+constexpr int P8VAR_RETR = 4096;
+struct P8Retr {
+  const float* scale;    // [region rows]: logit scale of a row, applied as exp(scale)
+  const float* bias;     // [region rows]
+  const int* count;      // [images]: valid rows of an image (the first count[i] of its rows_per_img)
+  float* out;            // [images][ldo] zero-filled: max over an image's valid rows of sigmoid(<e, t> exp(scale) + bias)
+  int rows_per_img, ldo;
+};
+
+template <int TM, int TN>
+__device__ __forceinline__ void p8_retr_epilogue(const WdConvGemm& p, const P8Retr& rt, float unscale, int mw, int nw, int lane,
+                                                 const f32x16 (&acc)[TM][TN]) {
+  const int nrows = p.n;
+  if (nw >= nrows || mw >= p.m) return;                            // wave-uniform
+  const int half = lane >> 5;
+  if (p.range_flag) {                                              // an fp16 half that overflowed to inf: inf / NaN accumulators
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          bad |= wd_any_nonfinite4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+    if (bad) *p.range_flag = 1u;
+  }
+  // this lane's rows: row(j, r) = nw + 32 j + 8 (r >> 2) + 4 half + (r & 3).  Their exp(scale) * unscale and bias are
+  // loaded per (image, j) — 32 live registers next to the 128 accumulators; holding all 64 spilled (the build refuses scratch)
+  const float ninf = -__builtin_inff();
+  const int rpi = rt.rows_per_img;
+  const int last = (nw + 63 < nrows ? nw + 63 : nrows - 1);
+  const int img_last = last / rpi;
+  for (int img = nw / rpi; img <= img_last; ++img) {               // usually one image, two where a wave's 64 rows straddle
+    int cnt = rt.count[img];
+    cnt = cnt < rpi ? cnt : rpi;
+    if (cnt <= 0) continue;
+    const int d = nw - img * rpi + 4 * half;                       // row(j, r) - first row of the image = d + const(j, r)
+    float v[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) v[i] = ninf;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float e_[16], b_[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int base = nw + 32 * j + 8 * g + 4 * half;
+        f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, b4 = {0.f, 0.f, 0.f, 0.f};
+        if (base + 3 < nrows) {
+          s4 = *reinterpret_cast<const f32x4*>(rt.scale + base);
+          b4 = *reinterpret_cast<const f32x4*>(rt.bias + base);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (base + q < nrows) { s4[q] = rt.scale[base + q]; b4[q] = rt.bias[base + q]; }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool in = (unsigned)(d + 32 * j + 8 * g + q) < (unsigned)cnt;
+          e_[4 * g + q] = in ? expf(s4[q]) * unscale : 0.0f;       // rows of other images / beyond the count: 0 * acc - inf
+          b_[4 * g + q] = in ? b4[q] : ninf;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[i] = fmaxf(v[i], fmaf(acc[i][j][r], e_[r], b_[r]));
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const float o = __shfl_xor(v[i], 32, 64);                    // the other four rows of every group of eight
+      const float m = fmaxf(v[i], o);
+      const int cls = mw + 32 * i + (lane & 31);
+      if ((i & 1) == half && cls < p.m && m > ninf)                // sigmoid > 0 and out starts at 0: uint order = float order
+        atomicMax(reinterpret_cast<unsigned int*>(rt.out + (size_t)img * rt.ldo + cls), __float_as_uint(wd_sigmoid(m)));
+    }
+  }
+}
+
 template <int VAR, int ABL = 0, bool PERSIST = false>
 __global__ void __launch_bounds__(512, 2)
 split_gemm_p8_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, int k16, float unscale, int nbn,
-                     int vec_c, int vec_res, int vec_bias, int ngrp, int nbm, const P8Persist ps) {
+                     int vec_c, int vec_res, int vec_bias, int ngrp, int nbm, const P8Persist ps, const P8Retr rt) {
   constexpr int TM = 4, TN = 2, BM = 256, BN = 256, ROWB = P8_ROWB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int t = threadIdx.x, lane = t & 63;
@@ -177,6 +266,7 @@ split_gemm_p8_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, 
     const int grp = tile / gsz, rem = tile - grp * gsz;
     const int bm = rem / ngrp, bn = grp * ngrp + (rem - bm * ngrp);
     const int m0 = bm * BM, n0 = bn * BN;
+    if ((VAR & P8VAR_RETR) && n0 >= p.n) continue;               // row-tile groups are padded to eight tiles: nothing to do
 
     // request K tile kt (relative to kb) of one operand region into LDS offset `reg` (buffer / ring slot included):
     // two 1 KB DMAs per wave.  half: 0 = A0 / W0, 1 = A1 / W1.  The 8-row group's first row is wave-uniform and rides
@@ -185,7 +275,8 @@ split_gemm_p8_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, 
       if (ABL & 1) return;
       const unsigned char* base = is_w ? wsp : abase;
       const unsigned pitch = (unsigned)(is_w ? k16 : p.lda) * 4u;
-      const int limit = (is_w ? p.n : p.m) - 8;
+      // retrieval: any row counts — the operand buffers of wd_split_weights are padded to whole groups of eight rows
+      const int limit = (VAR & P8VAR_RETR) ? (((is_w ? p.n : p.m) + 7) & ~7) - 8 : (is_w ? p.n : p.m) - 8;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         int row = is_w ? n0 + (2 * j + (wave >> 2)) * 64 + (wave & 3) * 8 + half * 32 : m0 + j * 128 + wave * 8 + half * 64;
@@ -408,6 +499,10 @@ split_gemm_p8_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, 
       if (sum == 12345.678f) p.c[t] = sum;
       continue;
     }
+    if constexpr ((VAR & P8VAR_RETR) != 0) {
+      p8_retr_epilogue<TM, TN>(p, rt, unscale, m0 + group * 128, n0 + wn * 64, lane, acc);
+      continue;
+    }
     const EpiVec ev{vec_c, vec_res, vec_bias, unscale};
     const int mw = m0 + group * 128, nw = n0 + wn * 64;
     float* patch = reinterpret_cast<float*>(smem_raw) + wave * 32 * EPI_LDT;
@@ -491,7 +586,23 @@ int launch_p8(const WdConvGemm& p, const void* wsp, float unscale, hipStream_t s
   static WdAttrOnce attr;
   if (wd_set_max_lds(attr, reinterpret_cast<const void*>(k), P8_LDS) != WD_OK) return WD_ERR_LAUNCH;
   WD_LAUNCH_GEMM(k, dim3((unsigned)grid), dim3(512), P8_LDS, st, p, static_cast<const unsigned char*>(wsp), k16, unscale, nbn,
-                 vec_c, vec_res, vec_bias, ngrp, nbm, ps);
+                 vec_c, vec_res, vec_bias, ngrp, nbm, ps, P8Retr{});
+  return wd_launch_status();
+}
+
+// retrieval scoring: p.a = bank rows [p.m][p.lda] (fp16 hi/lo groups), wsp = region rows [p.n][k16], see P8Retr
+int launch_p8_retr(const WdConvGemm& p, const void* wsp, float unscale, const P8Retr& rt, hipStream_t st) {
+  const int nbm = (p.m + 255) / 256, nbn = ((p.n + 255) / 256 + 7) / 8 * 8;      // row tiles padded to whole groups of eight
+  const long long nblk = (long long)nbm * nbn;
+  if (nblk <= 0 || nblk > 0x7fffffffLL) return WD_ERR_BAD_ARG;
+  const int k16 = (p.k + 15) / 16 * 16;
+  if ((unsigned long long)((p.m + 7) & ~7) * p.lda * 4 >= (1ull << 32) || (unsigned long long)((p.n + 7) & ~7) * k16 * 4 >= (1ull << 32))
+    return WD_ERR_UNSUPPORTED;
+  auto k = split_gemm_p8_kernel<P8VAR_RETR, 0, false>;
+  static WdAttrOnce attr;
+  if (wd_set_max_lds(attr, reinterpret_cast<const void*>(k), P8_LDS) != WD_OK) return WD_ERR_LAUNCH;
+  WD_LAUNCH_GEMM(k, dim3((unsigned)nblk), dim3(512), P8_LDS, st, p, static_cast<const unsigned char*>(wsp), k16, unscale, nbn,
+                 0, 0, 0, 8, nbm, P8Persist{nullptr, nullptr, nullptr, (int)nblk}, rt);
   return wd_launch_status();
 }
 
@@ -540,4 +651,23 @@ int wd_launch_p8(const WdConvGemm& p, const void* w, float unscale, bool csplit,
     return persist ? launch_p8<SVAR_CSPLIT, 0, true>(p, w, unscale, st, ws, ws_floats) : launch_p8<SVAR_CSPLIT>(p, w, unscale, st);
   }
   return persist ? launch_p8<0, 0, true>(p, w, unscale, st, ws, ws_floats) : launch_p8<0>(p, w, unscale, st);
+}
+
+// wd_retrieval_max_split on the 256 x 256 kernel (operand roles swapped, see P8Retr): bank rows [n_cls][dim] as the
+// activation operand, region rows [n_rows][dim] as the weight operand; out [images][ldo] must be zero.  Needs dim % 32 == 0,
+// 16-byte aligned scale / bias, both split buffers padded to whole groups of eight rows (wd_split_weights does that).
+int wd_launch_p8_retrieval(const void* t_split, int n_cls, const void* e_split, int n_rows, int dim, float unscale,
+                           const float* scale, const float* bias, const int* count, int rows_per_img, float* out, int ldo,
+                           unsigned* range_flag, hipStream_t st) {
+  if (dim % 32 || dim < 32 || n_cls <= 0 || n_rows <= 0 || rows_per_img <= 0) return WD_ERR_UNSUPPORTED;
+  if (!wd_aligned16(t_split) || !wd_aligned16(e_split) || !wd_aligned16(scale) || !wd_aligned16(bias)) return WD_ERR_UNSUPPORTED;
+  WdConvGemm p{};
+  p.a = static_cast<const float*>(t_split);
+  p.c = out;
+  p.batch = 1; p.hin = 1; p.win = n_cls; p.cin = dim; p.lda = dim;
+  p.kh = p.kw = p.stride = 1; p.hout = 1; p.wout = n_cls;
+  p.m = n_cls; p.n = n_rows; p.k = dim; p.ldc = ldo;
+  p.out_scale = 1.0f;
+  p.range_flag = range_flag;
+  return launch_p8_retr(p, e_split, unscale, P8Retr{scale, bias, count, out, rows_per_img, ldo}, st);
 }

@@ -6,6 +6,7 @@
 //   LayerNorm -> pwconv1 (+GELU, output written split) -> pwconv2 (+residual, fp32 output),
 //   LayerNorm -> 2x2 stride-2 downsample conv.
 #include <cstdlib>
+#include <stdlib.h>
 #include "split_gemm_impl.h"
 
 namespace { constexpr int EPI_RES_DEPTH = 2; }   // residual tiles in flight ahead of the one being stored (ping-pong kernel; the 128 x 128 kernel has registers for one)
@@ -571,10 +572,17 @@ int wd_launch_presplit(const WdConvGemm& p, const void* w, float unscale, int cf
 
 // wd_retrieval_max with fp16x3 arithmetic: e_split = region embeddings [n_img * rows_per_img, dim] and
 // t_split = text bank [n_cls, dim], both as fp16 hi/lo groups (wd_split_weights; the bank pre-scaled
-// by 1 / t_unscale).  out is zeroed here, then filled by atomic max.
+// by 1 / t_unscale).  out is zeroed here, then filled by atomic max.  Round 5: on the 256 x 256 kernel with the operand
+// roles swapped (split_gemm_p8.hip: P8Retr) wherever it applies — dim % 32 == 0, aligned scale / bias — in bank chunks of
+// 2^20 classes (32-bit DMA offsets); the 256 x 128 ping-pong form below remains for the other shapes and as the A/B
+// reference ($WEDETECT_RETR_P8=0).
+int wd_launch_p8_retrieval(const void* t_split, int n_cls, const void* e_split, int n_rows, int dim, float unscale,
+                           const float* scale, const float* bias, const int* count, int rows_per_img, float* out, int ldo,
+                           unsigned* range_flag, hipStream_t st);   // split_gemm_p8.hip
+
 extern "C" int wd_retrieval_max_split(const void* e_split, const void* t_split, float t_unscale, const float* scale,
                                       const float* bias, const int32_t* count, float* out, int32_t n_img,
-                                      int32_t rows_per_img, int32_t n_cls, int32_t dim, void* stream) {
+                                      int32_t rows_per_img, int32_t n_cls, int32_t dim, uint32_t* range_flag, void* stream) {
   if (!e_split || !t_split || !scale || !bias || !count || !out) return WD_ERR_BAD_ARG;
   if (n_img <= 0 || n_cls <= 0 || rows_per_img <= 0 || dim <= 0 || dim % 16 || !(t_unscale > 0.f)) return WD_ERR_BAD_ARG;
   if ((long long)n_img * rows_per_img > 0x7fffffffLL) return WD_ERR_BAD_ARG;
@@ -582,6 +590,20 @@ extern "C" int wd_retrieval_max_split(const void* e_split, const void* t_split, 
   hipStream_t st = static_cast<hipStream_t>(stream);
   const long long total = (long long)n_img * n_cls;
   hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, out, total);
+  const long long n_rows = (long long)n_img * rows_per_img;
+  const char* env_p8 = getenv("WEDETECT_RETR_P8");                // read per call: the tests toggle it
+  const bool use_p8 = !(env_p8 && env_p8[0] == '0');
+  if (use_p8 && dim % 32 == 0 && wd_aligned16(scale) && wd_aligned16(bias) &&
+      (unsigned long long)((n_rows + 7) & ~7ll) * dim * 4 < (1ull << 32)) {
+    const int chunk = 1 << 20;
+    for (long long c0 = 0; c0 < n_cls; c0 += chunk) {
+      const int nc = (int)(n_cls - c0 < chunk ? n_cls - c0 : chunk);
+      const int rc = wd_launch_p8_retrieval(static_cast<const unsigned char*>(t_split) + (size_t)c0 * dim * 4, nc, e_split, (int)n_rows,
+                                            dim, t_unscale, scale, bias, count, rows_per_img, out + c0, n_cls, range_flag, st);
+      if (rc != WD_OK) return rc;
+    }
+    return WD_OK;
+  }
   WdConvGemm p{};
   p.a = static_cast<const float*>(e_split);
   p.c = out;

@@ -604,6 +604,14 @@ class YOLOWorldDetector(_DeviceModule):
         if max_num > 0:
             cfg["max_per_img"] = min(int(cfg["max_per_img"]), max_num)
         if float(nms.get("score_threshold", 0.0)) > float(cfg["score_thr"]):
+            # mmcv decides between its one-call and its per-class branch on the candidate count BEFORE this filter
+            # (boxes.shape[0] < split_thr, mmcv/ops/nms.py batched_nms), the merged filter decides on the count after it: the two
+            # can only differ when nms_pre candidates can reach split_thr — then the option is refused rather than emulated
+            # with last-bit IoU differences.  No shipped config sets score_threshold.
+            if int(cfg["nms_pre"]) >= int(nms.get("split_thr", 10000)):
+                raise NotImplementedError("test_cfg.nms.score_threshold above score_thr with nms_pre >= split_thr: mmcv picks its NMS "
+                                          "branch on the pre-filter candidate count, which the merged filter cannot reproduce; raise "
+                                          "score_thr instead, or lower nms_pre below split_thr")
             cfg["score_thr"] = float(nms["score_threshold"])
         self.test_cfg = cfg
         self.model_size = model_size

@@ -663,6 +663,11 @@ class ImageTower:
         self.head()
         scores = self.similarity(text, normalize=normalize_text)
         self._post_ready.record(main)
+        # the caller's tensors are read by kernels on post_stream after this call returns: tell the caching allocator, or a
+        # caller that drops `meta` / `text` right away could see the block reused while top-k / NMS still read it
+        for t_ in (meta, text):
+            if isinstance(t_, torch.Tensor) and t_.is_cuda:
+                t_.record_stream(self.post_stream)
         with torch.cuda.stream(self.post_stream):
             self.post_stream.wait_event(self._post_ready)
             res = self.postprocess(scores, score_thr, meta, iou_thr, with_embed, nms, nms_param, nms_device)
@@ -687,6 +692,7 @@ class ImageTower:
         scales from THIS batch (detector._TowerHolder.recalibrate: scales only ever go down, every tower of the checkpoint
         adopts them); it is tried once per trip before the fp32 fallback — a first batch of blank images may have chosen
         scales under which an ordinary image overflows, which is a calibration problem, not a checkpoint that needs fp32."""
+        self.wait_post()                         # a pipelined step's counts are produced on post_stream: order the read behind it
         counts = res["count"].tolist()
         flags = self.range_flags.tolist() if self.precision == "fp16x3" else [0, 0]
         if flags[1] and not self.neck_pin:
@@ -702,7 +708,7 @@ class ImageTower:
         if min(counts, default=0) >= 0 and not tripped:
             return counts
         self.range_flags.zero_()
-        if self.precision == "fp16x3" and recalibrate is not None and self.sscale:
+        if self.precision == "fp16x3" and recalibrate is not None:     # also with all-unit scales: a later batch may need scales < 1
             before = dict(self.sscale)
             recalibrate()
             if self.sscale != before:                       # new scales: one more fp16x3 attempt, fp32 only if that trips too

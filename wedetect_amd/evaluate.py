@@ -160,14 +160,16 @@ def load_retrieval_file(path: str) -> dict:
     return pred
 
 
-def retrieval_scores(records: List[dict], text_embedding: torch.Tensor, device="cuda", images_per_launch: int = 256
-                     ) -> torch.Tensor:
+def retrieval_scores(records: List[dict], text_embedding: torch.Tensor, device="cuda", images_per_launch: int = 256,
+                     precision=None) -> torch.Tensor:
     """[len(records), K] fp32 on the device: per image the max over its regions of
     sigmoid(<e, t_k> * exp(scale) + bias) (retrieval_metric.py:369-375); images without regions score 0."""
     dev = torch.device(device)
     t = text_embedding.to(dev, torch.float32).contiguous()
     k, dim = t.shape
     out = torch.zeros(len(records), k, dtype=torch.float32, device=dev)
+    from .parallel import BankScorer
+    scorer = BankScorer(t, precision)          # fp16x3 under its range guard by default (round 5; fp32 before)
     for lo in range(0, len(records), images_per_launch):
         chunk = records[lo:lo + images_per_launch]
         rows = max(1, max(int(r["embedding"].shape[0]) for r in chunk))
@@ -180,7 +182,9 @@ def retrieval_scores(records: List[dict], text_embedding: torch.Tensor, device="
                 raise ValueError(f"record of image {r.get('image_id')} is inconsistent with the text bank / itself")
             e[i, :n], sc[i, :n], bi[i, :n], cnt[i] = r["embedding"], r["scale"], r["bias"], n
         ed, sd, bd, cd = e.to(dev), sc.to(dev), bi.to(dev), cnt.to(dev)
-        L.retrieval_max(ed, t, sd, bd, cd, out[lo:lo + len(chunk)], len(chunk), rows, k, dim)
+        if scorer.precision == "fp32" and rows > 320:
+            raise ValueError("the fp32 retrieval kernel takes at most 320 regions per image")
+        scorer(ed, cd, sd, bd, out=out[lo:lo + len(chunk)])
     return out
 
 

@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("WEDETECT_LIB") or os.path.join(_HERE, "libwedetect_hi
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU = 0, 1, 2, 3
 OUT_ROWS, OUT_DECONV2X2 = 0, 1
 SPLIT_A, SPLIT_C = 1, 2
-ABI_VERSION = 12
+ABI_VERSION = 13
 NMS_VANILLA, NMS_TORCHVISION, NMS_MMCV = 0, 1, 2
 # torchvision/ops/boxes.py batched_nms: the per-class loop (_batched_nms_vanilla) above this many box coordinates
 # (boxes.numel()).  4000 / 20000 are the values of torchvision 0.15 ... 0.21 (the releases contemporary with the
@@ -106,7 +106,7 @@ def _load():
     lib.wd_conv_gemm_split_ws.argtypes = [C.POINTER(ConvGemm), vp, f32, i32, i32, vp, i64, i32, vp]
     lib.wd_layernorm_rows_split.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, f32, vp]
     lib.wd_layernorm_rows_split_s2d.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]
-    lib.wd_retrieval_max_split.argtypes = [vp, vp, f32, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.wd_retrieval_max_split.argtypes = [vp, vp, f32, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
     lib.wd_recall_scratch_floats.restype = i64
     lib.wd_recall_scratch_floats.argtypes = [i32, i32]
     lib.wd_recall_match.argtypes = [vp, vp, vp, vp, i32, vp, i32, vp, i64, vp, i32, i32, vp]
@@ -395,15 +395,16 @@ def retrieval_max(e, t, scale, bias, count, out, n_img, rows_per_img, n_cls, dim
                                stream_ptr()), "wd_retrieval_max")
 
 
-def retrieval_max_split(e, t_split, scale, bias, count, out, n_img, rows_per_img, n_cls, dim) -> None:
+def retrieval_max_split(e, t_split, scale, bias, count, out, n_img, rows_per_img, n_cls, dim, range_flag=None) -> None:
     """fp16x3 variant of :func:`retrieval_max`.  ``e``: fp32 region rows [n_img, rows, dim] (split here, scale
-    1: a few MB); ``t_split``: ``split_weights(bank)`` prepared once for the (possibly class-sharded) bank."""
+    1: a few MB); ``t_split``: ``split_weights(bank)`` prepared once for the (possibly class-sharded) bank.
+    ``range_flag``: int32 [1] device tensor, set to 1 when an operand left the fp16 range (inf / NaN accumulator)."""
     _f32(e, "e")
     rows = e.reshape(-1, dim).contiguous()
     es = torch.empty(LIB.wd_split_weights_bytes(rows.shape[0], dim), dtype=torch.uint8, device=e.device)
     check(LIB.wd_split_weights(_p(rows), rows.shape[0], dim, 1.0, _p(es), stream_ptr()), "wd_split_weights")
     check(LIB.wd_retrieval_max_split(_p(es), _p(t_split[0]), float(t_split[1]), _p(scale), _p(bias), _p(count), _p(out),
-                                     n_img, rows_per_img, n_cls, dim, stream_ptr()), "wd_retrieval_max_split")
+                                     n_img, rows_per_img, n_cls, dim, _p(range_flag), stream_ptr()), "wd_retrieval_max_split")
 
 
 def text_embed(ids, pos_ids, word, pos, type0, out) -> None:

@@ -15,6 +15,57 @@ import torch
 import torch.distributed as dist
 
 
+class PhaseWatchdog:
+    """Per-rank progress deadline for multi-process runs (round 5).  A collective never returns when one rank is missing, and
+    seven healthy ranks waiting in an all-gather say nothing about WHICH rank is gone.  Every rank therefore carries its
+    own deadline: ``phase(name)`` marks progress and names what the rank is doing; when ``timeout_s`` pass without a new
+    mark, a daemon thread prints ``rank r: no progress for T s in phase '<name>'`` to stderr and calls ``on_expire``
+    (default ``os._exit(3)``): the launcher (torch.distributed.run) then tears the job down with a non-zero status.  The
+    rank that is stuck OUTSIDE a collective names itself; the ranks waiting for it name the collective they wait in."""
+
+    def __init__(self, rank: int, timeout_s: float, on_expire=None, poll_s: float = 0.25):
+        import threading
+        import time
+        self.rank, self.timeout_s, self._name = rank, float(timeout_s), "start"
+        self._t0, self._time, self._stop = time.monotonic(), time, False
+        self._on_expire = on_expire
+        self.expired = None
+        self._th = threading.Thread(target=self._loop, args=(poll_s,), daemon=True)
+        self._th.start()
+
+    def phase(self, name: str) -> None:
+        self._name, self._t0 = name, self._time.monotonic()
+
+    def stop(self) -> None:
+        self._stop = True
+
+    def _loop(self, poll_s: float) -> None:
+        import os
+        import sys
+        while not self._stop:
+            self._time.sleep(poll_s)
+            waited = self._time.monotonic() - self._t0
+            if not self._stop and waited > self.timeout_s:
+                self.expired = f"rank {self.rank}: no progress for {waited:.0f} s in phase '{self._name}'"
+                print(f"wedetect_amd watchdog: {self.expired}; failing the run", file=sys.stderr, flush=True)
+                if self._on_expire is not None:
+                    self._on_expire(self)
+                    return
+                os._exit(3)
+
+
+def bounded_wait(work, timeout_s: float, what: str, rank: int) -> None:
+    """``work.wait`` with a deadline: a collective that does not complete within ``timeout_s`` raises with the rank and
+    the collective's name instead of blocking for the backend's default (30 min for gloo / RCCL)."""
+    import datetime
+    try:
+        ok = work.wait(datetime.timedelta(seconds=timeout_s))
+    except RuntimeError as ex:                       # gloo / RCCL raise on a timed-out wait
+        raise RuntimeError(f"rank {rank}: collective '{what}' did not complete within {timeout_s:.0f} s ({ex})") from ex
+    if ok is False:
+        raise RuntimeError(f"rank {rank}: collective '{what}' did not complete within {timeout_s:.0f} s")
+
+
 def shard_range(total: int, world: int, rank: int) -> range:
     """Contiguous shard of ``range(total)`` for ``rank`` — the same split as
     InferenceSampler._get_local_indices (extract_embedding.py:1631-1638): the first
@@ -91,8 +142,10 @@ class RegionGatherer:
     The block is cleared on every ``submit``: a field the caller leaves out reads as zeros, never as the previous
     step's values."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, timeout_s: Optional[float] = None):
+        """``timeout_s``: deadline for the host-side wait on a gather in ``collect`` (None: the backend's own)."""
         self.group = group
+        self.timeout_s = timeout_s
         self.slots = [None, None]
         self.turn = 0
         self.pending = None               # (work handles, slot, has_extra)
@@ -145,8 +198,12 @@ class RegionGatherer:
         handles, s, extra = self.pending
         self.pending = None
         if handles is not None:
-            for h in handles:
-                h.wait()
+            for i, h in enumerate(handles):
+                if self.timeout_s is None:
+                    h.wait()
+                else:
+                    bounded_wait(h, self.timeout_s, "region gather: " + ("embeddings" if i == 0 else "metadata"),
+                                 dist.get_rank(self.group))
         e, m = s["out_e"], s["out_m"]
         r = e.shape[1]
         out = dict(embeddings=e, count=m[:, 2 * r])
@@ -246,16 +303,80 @@ def shard_bank_by_class(bank: torch.Tensor, world: int, rank: int) -> torch.Tens
     return bank[r.start:r.stop]
 
 
+class BankScorer:
+    """Scores kept regions against a [K, D] text bank (or a rank's class shard of it): [N, K] fp32, per image the max over
+    its kept regions of sigmoid(<e, t_k> exp(scale) + bias) (retrieval_metric.py:369-375), logits never materialised.
+
+    ``precision`` (None = $WEDETECT_RETRIEVAL_PRECISION, default "fp16x3"): "fp16x3" = wd_retrieval_max_split — operands as
+    fp16 (hi, lo) pairs, three fp16-MFMA passes, fp32 accumulate, the bank split ONCE here — under the tower's kind of
+    range guard: the kernel raises a sticky flag when an accumulator is inf / NaN (an embedding beyond 65504), and the
+    scorer then switches to the fp32-MFMA kernel (wd_retrieval_max) for good and repeats the call.  "fp32" = that kernel
+    from the start.  Round 4 shipped the fp32 kernel here and kept the 2.5 x faster one for tests and scripts."""
+
+    def __init__(self, bank: torch.Tensor, precision: Optional[str] = None):
+        import os
+        if precision is None:
+            precision = os.environ.get("WEDETECT_RETRIEVAL_PRECISION", "fp16x3")
+        if precision not in ("fp32", "fp16x3"):
+            raise ValueError("precision must be 'fp32' or 'fp16x3'")
+        if bank.dim() != 2 or bank.dtype != torch.float32 or not bank.is_cuda:
+            raise ValueError("bank must be a device float32 [K, D] tensor")
+        self.bank = bank.contiguous()
+        self.precision = precision
+        self.overflowed = False
+        self._split = None
+        self.flag = torch.zeros(1, dtype=torch.int32, device=bank.device)
+
+    def _launch(self, e, c, s, b, out):
+        from . import lib as L
+        n, r, d = e.shape
+        k = self.bank.shape[0]
+        if self.precision == "fp16x3" and d % 16 == 0:
+            if self._split is None:
+                self._split = L.split_weights(self.bank)
+            L.retrieval_max_split(e, self._split, s, b, c, out, n, r, k, d, range_flag=self.flag)
+            return True
+        L.retrieval_max(e, self.bank, s, b, c, out, n, r, k, d)
+        return False
+
+    def __call__(self, embeddings, count, scales, bias, out: Optional[torch.Tensor] = None, check: bool = True) -> torch.Tensor:
+        """``check`` False skips the host read of the range flag (a caller that pipelines steps reads ``tripped()`` itself
+        before it trusts the scores)."""
+        n = embeddings.shape[0]
+        if out is None:
+            out = torch.empty(n, self.bank.shape[0], dtype=torch.float32, device=embeddings.device)
+        e, c = embeddings.contiguous(), count.to(torch.int32).contiguous()
+        s, b = scales.contiguous(), bias.contiguous()
+        guarded = self._launch(e, c, s, b, out)
+        if guarded and check and self.tripped():
+            import warnings
+            warnings.warn("wedetect_amd: a region embedding left the fp16 range in the fp16x3 retrieval kernel; this scorer now "
+                          "runs the fp32 MFMA kernel")
+            self.precision, self.overflowed = "fp32", True
+            self.flag.zero_()
+            self._launch(e, c, s, b, out)
+        return out
+
+    def tripped(self) -> bool:
+        return bool(int(self.flag.item()))
+
+
+_SCORERS: list = []      # small cache of (key, BankScorer): the split of a 1M-class bank is a pass over 3 GB, done once per bank
+
+
 def device_retrieval_scores(embeddings: torch.Tensor, count: torch.Tensor, scales: torch.Tensor, bias: torch.Tensor,
-                            bank: torch.Tensor) -> torch.Tensor:
+                            bank: torch.Tensor, precision: Optional[str] = None) -> torch.Tensor:
     """[N, K] fp32: max over an image's kept regions of sigmoid(<e, t_k> exp(scale) + bias) on the device
-    (wd_retrieval_max; retrieval_metric.py:369-375).  ``embeddings`` [N, R, D], ``scales`` / ``bias`` [N, R], ``count`` [N]."""
-    from . import lib as L
-    n, r, d = embeddings.shape
-    out = torch.empty(n, bank.shape[0], dtype=torch.float32, device=embeddings.device)
-    L.retrieval_max(embeddings.contiguous(), bank.contiguous(), scales.contiguous(), bias.contiguous(),
-                    count.to(torch.int32).contiguous(), out, n, r, bank.shape[0], d)
-    return out
+    (retrieval_metric.py:369-375).  ``embeddings`` [N, R, D], ``scales`` / ``bias`` [N, R], ``count`` [N].  Runs the fp16x3
+    kernel under its range guard by default (:class:`BankScorer`); the bank's split form is cached per bank tensor."""
+    key = (bank.data_ptr(), tuple(bank.shape), bank._version, str(bank.device), precision)
+    for k_, sc in _SCORERS:
+        if k_ == key:
+            return sc(embeddings, count, scales, bias)
+    sc = BankScorer(bank, precision)
+    _SCORERS.append((key, sc))
+    del _SCORERS[:-2]
+    return sc(embeddings, count, scales, bias)
 
 
 def class_sharded_retrieval(embeddings: torch.Tensor, count: torch.Tensor, scales: torch.Tensor, bias: torch.Tensor,
