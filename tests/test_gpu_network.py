@@ -145,7 +145,8 @@ def _compare_detections(name, res, i, fx, prefix, ref_boxes=None):
 
 @pytest.mark.parametrize("fixture,arch,b,hw", [("net_base_b1_64.npz", "base", 1, 64), ("net_base_b2_128.npz", "base", 2, 128),
                                                ("net_base_b1_640.npz", "base", 1, 640),
-                                               ("net_base_b1_640_robust_mm.npz", "base", 1, 640), ("net_base_b1_640_robust_uni.npz", "base", 1, 640)])
+                                               ("net_base_b1_640_robust_mm.npz", "base", 1, 640), ("net_base_b1_640_robust_uni.npz", "base", 1, 640),
+                                               ("net_base_b1_640_robust2_mm.npz", "base", 1, 640), ("net_base_b1_640_robust2_uni.npz", "base", 1, 640)])
 def test_base_against_reference_goldens(fixture, arch, b, hw):
     from oracle import postprocess as opp
     from wedetect_amd import weights as W
@@ -325,6 +326,58 @@ def test_pipelined_post_process_equals_the_in_line_step():
             assert torch.equal(a[k], b[k]), f"batch {i}: {k} differs between the pipelined and the in-line step"
     for k in ref[0]:
         assert torch.equal(ref[0][k], r[k]), f"in-line step behind a pipelined one: {k} differs"
+
+
+@pytest.mark.parametrize("arch,b,hw", [("base", 2, 320), ("tiny", 3, 128)])
+def test_neck_head_dag_on_side_streams_equals_the_serial_chain(arch, b, hw):
+    """Round 5: the neck / head issued as a DAG — BiFusion input branches on lanes 1 / 2 from the start of the neck, every
+    BepC3's cv2 on lane 3 beside its 3 x 3 chain, head level l on the side lanes the moment P(l+3) exists, cls / reg branches
+    apart — must give EXACTLY the tensors of the one-stream chain: same kernels, same arguments, only the issue order and
+    the streams differ.  Checked for a stream of different batches issued back to back with no host synchronisation (also
+    with the post-process pipelined on its own stream), for the separately called neck() / head(), and under hipGraph
+    capture."""
+    from wedetect_amd import weights as W
+    from wedetect_amd.engine import GraphedDetect
+    _, t, _ = build(arch, b, hw, num_prompts=48)
+    meta = t.identity_meta()
+    batches = [torch.from_numpy(W.make_images(b, hw, hw, seed=700 + i)).cuda() for i in range(4)]
+    kw = dict(normalize_text=False, score_thr=0.0, with_embed=True)
+    t.dag = False
+    ref, feats = [], []
+    for x in batches:
+        r = t.detect(x, t.P["prompts"], meta, **kw)
+        torch.cuda.synchronize()
+        ref.append({k: v.clone() for k, v in r.items()})
+        feats.append((t.embed.clone(), t.boxes.clone(), [p.clone() for p in (t.p3, t.p4, t.p5)]))
+    t.dag = True
+    assert t._dag_on()
+    for overlap in (False, True):
+        got = []
+        for x in batches:                               # no synchronisation between the calls
+            r = t.detect(x, t.P["prompts"], meta, overlap_post=overlap, **kw)
+            with torch.cuda.stream(t.post_stream if overlap else torch.cuda.current_stream()):
+                got.append({k: v.clone() for k, v in r.items()})
+        t.wait_post()
+        torch.cuda.synchronize()
+        assert len(t._side) == 3 and t._ev_i > 10           # the side lanes were really used
+        for i, (a_, b_) in enumerate(zip(ref, got)):
+            for k in a_:
+                assert torch.equal(a_[k], b_[k]), f"batch {i} (overlap_post={overlap}): {k} differs between the DAG and the serial chain"
+    # neck() and head() called apart (the tests and diagnostics do): each is internally parallel, the pair is still exact
+    t.backbone(batches[2])
+    t.neck()
+    t.head()
+    torch.cuda.synchronize()
+    e_, b_, ps = feats[2]
+    assert torch.equal(t.embed, e_) and torch.equal(t.boxes, b_)
+    for got_p, ref_p in zip((t.p3, t.p4, t.p5), ps):
+        assert torch.equal(got_p, ref_p)
+    # captured: the side streams join the capture through the lane events and come back before it ends
+    g = GraphedDetect(t, 48, normalize_text=False, score_thr=0.0)
+    out = {k: v.clone() for k, v in g(batches[3], t.P["prompts"], meta).items()}
+    torch.cuda.synchronize()
+    for k in ref[3]:
+        assert torch.equal(ref[3][k], out[k]), f"hipGraph replay of the DAG step: {k} differs"
 
 
 def test_hipgraph_replay_equals_eager_and_is_faster_at_batch1():

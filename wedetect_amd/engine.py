@@ -75,6 +75,21 @@ class ImageTower:
         # (the round-1 128 x 128 / ping-pong kernels, for A/B runs).
         self.p8_mode = os.environ.get("WEDETECT_P8", "persist")
         self.post_stream, self._post_ready, self._post_done = None, None, None      # detect(overlap_post=True)
+        # Neck / head as a DAG on side streams (round 5; $WEDETECT_DAG = "auto" (default): batches of >= 8 x 640 x 640 pixels,
+        # "1": always, "0": never = the serial chain of rounds 1-4).  The neck + head are ~110 launches of which the 20 x 20 /
+        # 40 x 40 ones fill 50 - 200 of 256 CUs, issued as ONE dependent chain although the graph is not one: the BiFusion
+        # input branches only read backbone outputs, a BepC3's cv2 is independent of its 3 x 3 chain, head level 0 (the largest
+        # head convs) needs only P3, which exists before downsample2 -> Rep_n3 -> downsample1 -> Rep_n4 run, and the cls / reg
+        # branches of a level are independent (yolo_world_pafpn.py:1114-1137, yolo_world_head.py:271-294).  Same kernels, same
+        # arguments, same buffers (disjoint channel slices where two lanes write one buffer): bit-identical results.
+        dag = os.environ.get("WEDETECT_DAG", "auto")
+        self.dag = dag == "1" or (dag == "auto" and batch * height * width >= 8 * 640 * 640)
+        self._side: List[torch.cuda.Stream] = []
+        self._events: List[torch.cuda.Event] = []
+        self._ev_i = 0
+        self._lane_i = 0
+        self._fws_lane: Dict[int, torch.Tensor] = {}
+        self._head_evs: List[torch.cuda.Event] = []
         self.s2d_down = os.environ.get("WEDETECT_S2D_DOWN", "1") != "0"     # downsample convs as plain GEMMs on space-to-depth LayerNorm rows
         self.park = None
         if precision == "fp16x3" and self.p8_mode == "persist" and L.p8_workspace_bytes() > 0:
@@ -232,15 +247,15 @@ class ImageTower:
         if (ws is not None and self.fixed_splitk and self.kws is None and kw.get("kh", 1) == 3 and kw.get("stride", 1) == 1
                 and kw["hin"] * kw["win"] <= 400 and 9 * kw["cin"] >= 2304 and kw["n"] % 4 == 0
                 and 2 * self.B * kw["hin"] * kw["win"] * kw["n"] <= self.fws.numel()):
-            work, kw = self.fws, dict(kw, k_splits=2)
+            work, kw = self._lane_fws(), dict(kw, k_splits=2)
         if (ws is not None and (kw.get("split_flags", 0) & L.SPLIT_A) and not self.conv3 and kw.get("kh", 1) == 3
                 and kw.get("stride", 1) == 1 and "split_cfg" not in kw):
             kw = dict(kw, split_cfg=70)
         if ws is not None and (kw.get("split_flags", 0) & L.SPLIT_A):
             plain = kw.get("kh", 1) == 1 and kw.get("kw", 1) == 1 and kw.get("stride", 1) == 1 and kw.get("pad", 0) == 0
             m = self.B * kw["hin"] * kw["win"]
-            if plain and self.park is not None and L.gemm_config(m, kw["n"], kw["cin"], split=True, presplit=True,
-                                                                 park=True).endswith("/p8s"):
+            if plain and self.park is not None and self._lane_i == 0 and L.gemm_config(m, kw["n"], kw["cin"], split=True, presplit=True,
+                                                                                       park=True).endswith("/p8s"):
                 work = self.park
             elif plain and self.p8_mode == "0" and kw["cin"] % 16 == 0:
                 # A/B switch: the round-1 kernels (another K-tile order inside the launch, the same MFMA chain per output) for
@@ -332,6 +347,63 @@ class ImageTower:
         self._gemm(a, w, b, c, hin=hin, win=win, cin=cin, lda=lda, kh=k, kw=k, stride=stride,
                    pad=(k // 2 if k == 3 else 0), n=n, ldc=ldc, act=act, res=res, ldres=ldres, res_alpha=res_alpha, **kw)
 
+    # ------------------------------------------------------------------ DAG lanes (side streams)
+    N_LANES = 4            # lane 0 = the caller's stream; 1, 2 = branch work (BiFusion inputs, head cls / reg); 3 = BepC3 cv2
+
+    def _dag_on(self) -> bool:
+        """Side streams are used for a step only outside the calibration pass (its recorders are torch ops on the current
+        stream) and without the opt-in latency split-K (one shared workspace)."""
+        return self.dag and self._calib is None and self.kws is None
+
+    def _lane_fws(self) -> torch.Tensor:
+        """Fixed split-K workspace of the lane that is launching: two lanes may run split-K convs at the same time."""
+        if self._lane_i == 0:
+            return self.fws
+        w = self._fws_lane.get(self._lane_i)
+        if w is None:
+            w = self._fws_lane[self._lane_i] = torch.empty_like(self.fws)
+        return w
+
+    class _Lane:
+        def __init__(self, tower, i):
+            self.t, self.i, self.ctx = tower, i, None
+
+        def __enter__(self):
+            t = self.t
+            self.prev = t._lane_i
+            t._lane_i = self.i
+            if self.i > 0:
+                self.ctx = torch.cuda.stream(t._side[self.i - 1])
+                self.ctx.__enter__()
+            return self
+
+        def __exit__(self, *a):
+            if self.ctx is not None:
+                self.ctx.__exit__(*a)
+            self.t._lane_i = self.prev
+
+    def _lane(self, i: int) -> "ImageTower._Lane":
+        while len(self._side) < self.N_LANES - 1:
+            self._side.append(torch.cuda.Stream(device=self.dev))
+        return ImageTower._Lane(self, i)
+
+    def _mark(self) -> torch.cuda.Event:
+        """Event recorded on the CURRENT stream, from a per-tower pool (no allocation per step; re-recorded every step)."""
+        if self._ev_i == len(self._events):
+            self._events.append(torch.cuda.Event())
+        ev = self._events[self._ev_i]
+        self._ev_i += 1
+        ev.record(torch.cuda.current_stream())
+        return ev
+
+    @staticmethod
+    def _after(*evs) -> None:
+        """The current stream waits for the given events."""
+        st = torch.cuda.current_stream()
+        for ev in evs:
+            if ev is not None:
+                st.wait_event(ev)
+
     # ------------------------------------------------------------------ backbone
     def backbone(self, images_u8: torch.Tensor) -> List[torch.Tensor]:
         a, B = self.a, self.B
@@ -397,7 +469,8 @@ class ImageTower:
 
     # ------------------------------------------------------------------ neck
     def _bepc3(self, name: str, x, ldx: int, cin: int, hw: Tuple[int, int], out, cout: int, xkey: str, okey: str):
-        """xkey / okey: split-scale keys of the input / output buffers (calibrate())."""
+        """xkey / okey: split-scale keys of the input / output buffers (calibrate()).  DAG mode: cv2 (a 1 x 1 conv of the block
+        input into the second half of ``cat``) runs on lane 3 beside the 3 x 3 chain; cv3 waits for both."""
         bf = self._bep[name]
         c_ = bf["c_"]
         h, w = hw
@@ -406,6 +479,18 @@ class ImageTower:
         S = self._neck_split()
         fl = (L.SPLIT_A | L.SPLIT_C) if S else 0
         sfx = "s" if S else ""
+        D = self._dag_on()
+
+        def cv2():
+            self._conv(x, f"{name}.cv2.w", f"{name}.cv2.b", cat[:, c_:], hin=h, win=w, cin=cin, lda=ldx, n=c_,
+                       ldc=2 * c_, act=L.ACT_SILU, split_flags=fl, a_key=xkey, c_key=name + ".cat")
+        ev_cv2 = None
+        if D:
+            ev_in = self._mark()                    # the block input is complete on the caller's stream
+            with self._lane(3):
+                self._after(ev_in)
+                cv2()
+                ev_cv2 = self._mark()
         # cv1 output: the 3x3 chain reads it (split) AND the first BottleRep adds it back (fp32): dual write
         self._conv(x, f"{name}.cv1.w", f"{name}.cv1.b", bf["u0" + sfx], hin=h, win=w, cin=cin, lda=ldx, n=c_, ldc=c_,
                    act=L.ACT_SILU, split_flags=fl, c2=bf["u0"] if S else None, ldc2=c_ if S else 0, a_key=xkey, c_key=name + ".u0")
@@ -421,35 +506,52 @@ class ImageTower:
                        c2=bf[nxt] if (S and not last) else None, ldc2=c_ if (S and not last) else 0,
                        a_key=name + ".t", c_key=name + ".cat" if last else f"{name}.{nxt}")
             cur, nxt = nxt, cur
-        self._conv(x, f"{name}.cv2.w", f"{name}.cv2.b", cat[:, c_:], hin=h, win=w, cin=cin, lda=ldx, n=c_,
-                   ldc=2 * c_, act=L.ACT_SILU, split_flags=fl, a_key=xkey, c_key=name + ".cat")
+        if D:
+            self._after(ev_cv2)
+        else:
+            cv2()
         self._conv(cat, f"{name}.cv3.w", f"{name}.cv3.b", out, hin=h, win=w, cin=2 * c_, lda=2 * c_, n=cout,
                    ldc=cout, act=L.ACT_SILU, split_flags=fl, a_key=name + ".cat", c_key=okey)
 
-    def _bifusion(self, name: str, top, ld_top: int, hw_top, mid, c_mid: int, hw_mid, low, c_low: int, hw_low,
-                  cat, tbuf, out, cout: int, topkey: str, midkey: str, lowkey: str, okey: str):
-        """cat = [upsample(top) | cv1(mid) | downsample(cv2(low))] -> cv3 -> out  (yolo_world_pafpn.py:711-715)."""
-        ht, wt = hw_top
+    def _bifusion_mid(self, name: str, mid, c_mid: int, hw_mid, cat, cout: int, midkey: str):
         hm, wm = hw_mid
+        fc = L.SPLIT_C if self._neck_split() else 0       # fp32 residual stream in (split by the loader), hi/lo groups out
+        self._conv(mid, name + ".cv1.w", name + ".cv1.b", cat[:, cout:], hin=hm, win=wm, cin=c_mid, lda=c_mid, n=cout,
+                   ldc=3 * cout, act=L.ACT_RELU, fp32=True, split_flags=fc, a_key=midkey, c_key=name + ".cat")   # mid / low: residual streams
+
+    def _bifusion_low(self, name: str, low, c_low: int, hw_low, cat, tbuf, cout: int, lowkey: str):
         hl, wl = hw_low
         S = self._neck_split()
         fl = (L.SPLIT_A | L.SPLIT_C) if S else 0
-        fc = L.SPLIT_C if S else 0            # fp32 residual stream in (split by the loader), hi/lo groups out
-        self._gemm(top, name + ".up.w", name + ".up.b", cat, hin=ht, win=wt, cin=cout, lda=ld_top, n=4 * cout,
-                   ldc=3 * cout, out_mode=L.OUT_DECONV2X2, split_flags=fl, a_key=topkey, c_key=name + ".cat")
-        self._conv(mid, name + ".cv1.w", name + ".cv1.b", cat[:, cout:], hin=hm, win=wm, cin=c_mid, lda=c_mid, n=cout,
-                   ldc=3 * cout, act=L.ACT_RELU, fp32=True, split_flags=fc, a_key=midkey, c_key=name + ".cat")   # mid / low: residual streams
+        fc = L.SPLIT_C if S else 0
         self._conv(low, name + ".cv2.w", name + ".cv2.b", tbuf, hin=hl, win=wl, cin=c_low, lda=c_low, n=cout, ldc=cout,
                    act=L.ACT_RELU, fp32=True, split_flags=fc, a_key=lowkey, c_key=name + ".t")
         self._conv(tbuf, name + ".downsample.w", name + ".downsample.b", cat[:, 2 * cout:], hin=hl, win=wl, cin=cout,
                    lda=cout, n=cout, ldc=3 * cout, k=3, stride=2, act=L.ACT_RELU, split_flags=fl, a_key=name + ".t",
                    c_key=name + ".cat")
+
+    def _bifusion(self, name: str, top, ld_top: int, hw_top, mid, c_mid: int, hw_mid, low, c_low: int, hw_low,
+                  cat, tbuf, out, cout: int, topkey: str, midkey: str, lowkey: str, okey: str, pre=None):
+        """cat = [upsample(top) | cv1(mid) | downsample(cv2(low))] -> cv3 -> out  (yolo_world_pafpn.py:711-715).
+        ``pre``: events of the mid / low branches when the caller already issued them on side lanes (DAG mode: they read
+        backbone outputs only)."""
+        ht, wt = hw_top
+        hm, wm = hw_mid
+        fl = (L.SPLIT_A | L.SPLIT_C) if self._neck_split() else 0
+        self._gemm(top, name + ".up.w", name + ".up.b", cat, hin=ht, win=wt, cin=cout, lda=ld_top, n=4 * cout,
+                   ldc=3 * cout, out_mode=L.OUT_DECONV2X2, split_flags=fl, a_key=topkey, c_key=name + ".cat")
+        if pre is None:
+            self._bifusion_mid(name, mid, c_mid, hw_mid, cat, cout, midkey)
+            self._bifusion_low(name, low, c_low, hw_low, cat, tbuf, cout, lowkey)
+        else:
+            self._after(*pre)
         self._conv(cat, name + ".cv3.w", name + ".cv3.b", out, hin=hm, win=wm, cin=3 * cout, lda=3 * cout, n=cout,
                    ldc=cout, act=L.ACT_RELU, split_flags=fl, a_key=name + ".cat", c_key=okey)
 
-    def neck(self) -> List[torch.Tensor]:
+    def neck(self, _level_ready=None) -> List[torch.Tensor]:
         """P3, P4, P5 buffers.  In the pre-split mode (see __init__) they hold fp16 hi/lo groups, like every other neck
-        buffer: ``pyramid()`` gives fp32 views for diagnostics."""
+        buffer: ``pyramid()`` gives fp32 views for diagnostics.  ``_level_ready(l)`` (features()): called the moment P3 / P4 /
+        P5 is complete on the caller's stream, so that a head level can be issued beside the rest of the neck."""
         a = self.a
         nc = a.neck_channels
         c1, c2, c3, c4 = self.x
@@ -459,35 +561,64 @@ class ImageTower:
         S = self._neck_split()
         fl = (L.SPLIT_A | L.SPLIT_C) if S else 0
         fpn_out0 = self.cat_n4[:, nc["d1"]:]
+        fpn_out1 = self.cat_n3[:, nc["d2"]:]
+        D = self._dag_on()
+        self._ev_i = 0
+        self._head_evs = []
+        pre0 = pre1 = None
+        if D:
+            # the mid / low branches of BOTH BiFusion blocks read backbone outputs only: lanes 1 and 2, from the start
+            ev0 = self._mark()
+            with self._lane(1):
+                self._after(ev0)
+                self._bifusion_mid("Bifusion0", c3, nc["c3"], hw4, self.cat_b0, nc["p5r"], "c3")
+                e_m0 = self._mark()
+                self._bifusion_mid("Bifusion1", c2, nc["c2"], hw3, self.cat_b1, nc["p4r"], "c2")
+                e_m1 = self._mark()
+            with self._lane(2):
+                self._after(ev0)
+                self._bifusion_low("Bifusion0", c2, nc["c2"], hw3, self.cat_b0, self.b0_t, nc["p5r"], "c2")
+                e_l0 = self._mark()
+                self._bifusion_low("Bifusion1", c1, nc["c1"], hw2, self.cat_b1, self.b1_t, nc["p4r"], "c1")
+                e_l1 = self._mark()
+            pre0, pre1 = (e_m0, e_l0), (e_m1, e_l1)
         self._conv(c4, "reduce_layer0.w", "reduce_layer0.b", fpn_out0, hin=hw5[0], win=hw5[1], cin=nc["c4"],
                    lda=nc["c4"], n=nc["p5r"], ldc=ld4, act=L.ACT_RELU, fp32=True, split_flags=L.SPLIT_C if S else 0,
                    a_key="c4", c_key="cat_n4")
         self._bifusion("Bifusion0", fpn_out0, ld4, hw5, c3, nc["c3"], hw4, c2, nc["c2"], hw3, self.cat_b0, self.b0_t,
-                       self.f0, nc["p5r"], "cat_n4", "c3", "c2", "f0")
+                       self.f0, nc["p5r"], "cat_n4", "c3", "c2", "f0", pre=pre0)
         self._bepc3("Rep_p4", self.f0, nc["p5r"], nc["p5r"], hw4, self.f_out0, nc["p5r"], "f0", "f_out0")
-        fpn_out1 = self.cat_n3[:, nc["d2"]:]
         self._conv(self.f_out0, "reduce_layer1.w", "reduce_layer1.b", fpn_out1, hin=hw4[0], win=hw4[1], cin=nc["p5r"],
                    lda=nc["p5r"], n=nc["p4r"], ldc=ld3, act=L.ACT_RELU, split_flags=fl, a_key="f_out0", c_key="cat_n3")
         self._bifusion("Bifusion1", fpn_out1, ld3, hw4, c2, nc["c2"], hw3, c1, nc["c1"], hw2, self.cat_b1, self.b1_t,
-                       self.f1, nc["p4r"], "cat_n3", "c2", "c1", "f1")
+                       self.f1, nc["p4r"], "cat_n3", "c2", "c1", "f1", pre=pre1)
         self._bepc3("Rep_p3", self.f1, nc["p4r"], nc["p4r"], hw3, self.p3, nc["p4r"], "f1", "p3")
+        if _level_ready is not None:
+            _level_ready(0)
         self._conv(self.p3, "downsample2.w", "downsample2.b", self.cat_n3, hin=hw3[0], win=hw3[1], cin=nc["p4r"],
                    lda=nc["p4r"], n=nc["d2"], ldc=ld3, k=3, stride=2, act=L.ACT_RELU, split_flags=fl, a_key="p3", c_key="cat_n3")
         self._bepc3("Rep_n3", self.cat_n3, ld3, ld3, hw4, self.p4, nc["n3"], "cat_n3", "p4")
+        if _level_ready is not None:
+            _level_ready(1)
         self._conv(self.p4, "downsample1.w", "downsample1.b", self.cat_n4, hin=hw4[0], win=hw4[1], cin=nc["n3"],
                    lda=nc["n3"], n=nc["d1"], ldc=ld4, k=3, stride=2, act=L.ACT_RELU, split_flags=fl, a_key="p4", c_key="cat_n4")
         self._bepc3("Rep_n4", self.cat_n4, ld4, ld4, hw5, self.p5, nc["n4"], "cat_n4", "p5")
+        if _level_ready is not None:
+            _level_ready(2)
         return [self.p3, self.p4, self.p5]
 
     # ------------------------------------------------------------------ head
-    def head(self) -> Tuple[torch.Tensor, torch.Tensor]:
-        """Region embeddings (post contrastive-BN) [B, N, 768] and decoded boxes [B, N, 4]."""
-        feats = [self.p3, self.p4, self.p5]
+    def _head_level(self, l: int) -> None:
+        """One level of the head.  DAG mode: the classification branch (3 x 3, 3 x 3, 256 -> 768 embedding conv) on lane 1 and
+        the regression branch (3 x 3, 3 x 3, DFL logits, decode) on lane 2 — the last level keeps its classification branch on
+        the caller's stream, which has nothing else left to run; ``_head_join`` makes the caller's stream wait for all of it."""
+        feat, cin = (self.p3, self.p4, self.p5)[l], self.a.head_in[l]
         S = self._neck_split()                  # P3..P5 and the branch intermediates as fp16 hi/lo groups; embeddings and
         fl = (L.SPLIT_A | L.SPLIT_C) if S else 0     # DFL logits (read by fp32 kernels) stay fp32
         fa = L.SPLIT_A if S else 0
-        for l, (feat, cin) in enumerate(zip(feats, self.a.head_in)):
-            h, w = self.lv[l]
+        h, w = self.lv[l]
+
+        def cls_branch():
             c1, c2 = self.hc[l]
             self._conv(feat, f"head{l}.cls0.w", f"head{l}.cls0.b", c1, hin=h, win=w, cin=cin, lda=cin, n=CLS_MID,
                        ldc=CLS_MID, k=3, act=L.ACT_SILU, split_flags=fl, a_key=f"p{l + 3}", c_key=f"h{l}.c1")
@@ -496,6 +627,8 @@ class ImageTower:
             dst = self.embed.view(-1, EMBED_DIM)[self.off[l]:]
             self._conv(c2, f"head{l}.embed.w", f"head{l}.embed.b", dst, hin=h, win=w, cin=CLS_MID, lda=CLS_MID,
                        n=EMBED_DIM, ldc=EMBED_DIM, c_batch_stride=self.ntot, split_flags=fa, a_key=f"h{l}.c2")
+
+        def reg_branch():
             r1, r2, dist = self.hr[l]
             self._conv(feat, f"head{l}.reg0.w", f"head{l}.reg0.b", r1, hin=h, win=w, cin=cin, lda=cin, n=REG_MID,
                        ldc=REG_MID, k=3, act=L.ACT_SILU, split_flags=fl, a_key=f"p{l + 3}", c_key=f"h{l}.r1")
@@ -504,6 +637,32 @@ class ImageTower:
             self._conv(r2, f"head{l}.dist.w", f"head{l}.dist.b", dist, hin=h, win=w, cin=REG_MID, lda=REG_MID, n=64,
                        ldc=64, split_flags=fa, a_key=f"h{l}.r2")
             L.dfl_decode(dist, 64, self.boxes, self.B, h, w, STRIDES[l], self.off[l], self.ntot)
+        if not self._dag_on():
+            cls_branch()
+            reg_branch()
+            return
+        ev = self._mark()                       # this level's pyramid map is complete on the caller's stream
+        with self._lane(2):
+            self._after(ev)
+            reg_branch()
+            self._head_evs.append(self._mark())
+        if l == 2:
+            cls_branch()
+        else:
+            with self._lane(1):
+                self._after(ev)
+                cls_branch()
+                self._head_evs.append(self._mark())
+
+    def _head_join(self) -> None:
+        self._after(*self._head_evs)
+        self._head_evs = []
+
+    def head(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Region embeddings (post contrastive-BN) [B, N, 768] and decoded boxes [B, N, 4]."""
+        for l in range(3):
+            self._head_level(l)
+        self._head_join()
         return self.embed, self.boxes
 
     # ------------------------------------------------------------------ similarity
@@ -628,10 +787,20 @@ class ImageTower:
         return (a >= self.off[1]).to(torch.int64) + (a >= self.off[2]).to(torch.int64)
 
     # ------------------------------------------------------------------ whole steps
+    def neck_head(self):
+        """Neck and head as ONE schedule: in DAG mode a head level is issued on the side lanes the moment its pyramid map
+        exists (level 0 beside downsample2 -> Rep_n3 -> downsample1 -> Rep_n4, level 1 beside Rep_n4); otherwise the serial
+        chain neck(); head()."""
+        if not self._dag_on():
+            self.neck()
+            return self.head()
+        self.neck(_level_ready=self._head_level)
+        self._head_join()
+        return self.embed, self.boxes
+
     def features(self, images_u8: torch.Tensor):
         self.backbone(images_u8)
-        self.neck()
-        return self.head()
+        return self.neck_head()
 
     def detect(self, images_u8, text, meta, *, normalize_text: bool, score_thr: float, iou_thr: float = 0.7,
                with_embed: bool = False, nms: Optional[str] = None, nms_param: Optional[int] = None, nms_device: str = "cpu",
@@ -658,9 +827,13 @@ class ImageTower:
             self._post_ready = torch.cuda.Event()
         main = torch.cuda.current_stream()
         self.backbone(images_u8)
-        self.neck()
-        self.wait_post()
-        self.head()
+        if self._dag_on():
+            self.wait_post()                  # head level 0 starts inside the neck: the previous post-process must be done with
+            self.neck_head()                  # boxes / embeddings before ANY head kernel is issued (it had the whole backbone)
+        else:
+            self.neck()
+            self.wait_post()
+            self.head()
         scores = self.similarity(text, normalize=normalize_text)
         self._post_ready.record(main)
         # the caller's tensors are read by kernels on post_stream after this call returns: tell the caching allocator, or a
