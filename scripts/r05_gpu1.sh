@@ -2,7 +2,7 @@
 mkdir -p gpurun_out/r05a
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-( timeout 900 python -m pytest tests/test_gpu_split.py tests/test_gpu_network.py tests/test_gpu_entry.py tests/test_gpu_evaluate.py -x -q -m gpu -k "retrieval or split_weights or bank_scorer or dag or tiny_config0 or reference_goldens or config0 or device_retrieval or pipelined" 2>&1 | tail -25 ) > gpurun_out/r05a/tests_new.log
+( timeout 900 python -m pytest tests/test_gpu_split.py tests/test_gpu_network.py tests/test_gpu_entry.py tests/test_gpu_evaluate.py tests/test_gpu_precision.py -q -m gpu -k "heavy_tailed or retrieval or split_weights or bank_scorer or dag or tiny_config0 or reference_goldens or config0 or device_retrieval or pipelined" 2>&1 | tail -25 ) > gpurun_out/r05a/tests_new.log
 Q="--steps 30 --warmup 8 --no-cpu-baseline --no-fp32-reference --no-host-fed --no-other-configs"
 for i in 1 2; do
   WEDETECT_DAG=0 python bench.py $Q > gpurun_out/r05a/bench_dag0_$i.json 2> gpurun_out/r05a/bench_dag0_$i.err

@@ -173,3 +173,72 @@ def test_calibration_on_an_ordinary_checkpoint_changes_nothing_above_the_fp32_no
     d01, d0, d1 = float((e0 - e1).abs().max()), float((e0 - e32).abs().max()), float((e1 - e32).abs().max())
     print(f"[range] ordinary checkpoint: |calibrated - uncalibrated| {d01:.3g}; vs fp32: uncalibrated {d0:.3g}, calibrated {d1:.3g}")
     assert d01 <= 2e-5 and d1 <= max(2e-5, 1.5 * d0)
+
+
+def _heavy_tail_checkpoint(arch, n_out=4, mag=1e3, gamma=0.1):
+    """A "trained-like" checkpoint (VERDICT r4 weak #3 / next #5d): a few channels of every residual stream carry values
+    ``mag`` x the median — the outlier channels real ConvNeXt checkpoints develop — fed by the stem LayerNorm / the
+    downsample convs and kept alive through the stage by the blocks' own updates; layer scale ``gamma`` ~ 0.1 (initialised
+    at 1e-6 and grown by training, mm_backbone.py:106-108).  NOTHING inside the backbone is compensated: the block
+    LayerNorms see the outliers (the ordinary channels of a normalised row shrink to ~1 / (0.18 mag)), pwconv1 sums over
+    them.  Only the five neck layers that read c1..c4 divide the outlier columns back, as weights trained on such streams
+    would."""
+    from wedetect_amd import weights as W
+    from wedetect_amd.arch import get_arch
+    a = get_arch(arch)
+    sd = W.make_state_dict(arch)
+    bb = "backbone.image_model.model."
+    scales = []
+    for i, c in enumerate(a.dims):
+        s = np.ones(c, np.float32)
+        s[[c // 7, c // 3, c // 2 + 1, c - 5][:n_out]] = mag
+        scales.append(s)
+        if i == 0:
+            sd[bb + "downsample_layers.0.1.weight"] = sd[bb + "downsample_layers.0.1.weight"] * s
+            sd[bb + "downsample_layers.0.1.bias"] = sd[bb + "downsample_layers.0.1.bias"] * s
+        else:
+            sd[bb + f"downsample_layers.{i}.1.weight"] = sd[bb + f"downsample_layers.{i}.1.weight"] * s[:, None, None, None]
+            sd[bb + f"downsample_layers.{i}.1.bias"] = sd[bb + f"downsample_layers.{i}.1.bias"] * s
+        for j in range(a.depths[i]):
+            q = bb + f"stages.{i}.{j}."
+            sd[q + "gamma"] = (np.sign(sd[q + "gamma"]) * np.float32(gamma) * s).astype(np.float32)
+    for name, i in (("reduce_layer0", 3), ("Bifusion0.cv1", 2), ("Bifusion0.cv2", 1), ("Bifusion1.cv1", 1), ("Bifusion1.cv2", 0)):
+        k = f"neck.{name}.block.conv.weight"
+        sd[k] = sd[k] / scales[i][None, :, None, None]
+    return sd
+
+
+def test_fp16x3_on_a_heavy_tailed_checkpoint_at_base_640():
+    """fp16x3 has only met the O(1) synthetic generator; real residual streams carry outlier channels 10^2 - 10^3 x the
+    median, and the split scales are per TENSOR.  Base @ 640, four channels per stream at 10^3 x: the calibrated fp16x3 tower
+    must stay on the fp16x3 kernels (no range-guard trip, neither flag) and within the north-star tolerance of the fp32
+    tower — embeddings <= 1e-3 of their rms, scores <= 1e-3 absolute — through the detectors' own guard path
+    (checked_counts).  The per-tensor scale holds because a tensor's maximum is placed at 2^10 and the halves stay normal
+    down to 2^-13 of it (8 000 x): three decades of outlier are inside the window; the measured error is printed."""
+    from wedetect_amd import weights as W
+    from wedetect_amd.engine import ImageTower
+    from wedetect_amd.pack import pack
+    arch, b, hw, k = "base", 1, 640, 80
+    packed = pack(_heavy_tail_checkpoint(arch), arch)
+    x = torch.from_numpy(W.make_images(b, hw, hw, seed=11)).cuda()
+    bank = torch.from_numpy(W.make_text_bank(k)).cuda()
+    ref = ImageTower(arch, packed, b, hw, hw, max_classes=k, precision="fp32")
+    meta = ref.identity_meta()
+    meta[:, 7] = 1.0
+    kw = dict(normalize_text=True, score_thr=0.001, with_embed=True)
+    ref.detect(x, bank, meta, **kw)
+    e_ref, s_ref = ref.embed.clone(), ref.scores.view(-1)[: b * ref.ntot * k].clone()
+    streams = [float(t.abs().max()) / float(t.abs().median()) for t in ref.x]
+    assert min(streams) > 300.0, f"the checkpoint must really be heavy-tailed: max / median of c1..c4 = {streams}"
+    t = ImageTower(arch, packed, b, hw, hw, max_classes=k, precision="fp16x3")
+    amax = t.calibrate(x)
+    res = t.detect(x, bank, meta, **kw)
+    counts = t.checked_counts(res, lambda: t.detect(x, bank, meta, **kw))
+    assert t.precision == "fp16x3" and not t.overflowed and not t.neck_pin and not bool(t.range_flags.any()), \
+        "the range guard tripped on the heavy-tailed checkpoint: per-tensor scales are not enough"
+    rms = float(e_ref.pow(2).mean().sqrt())
+    err_e = float((t.embed - e_ref).abs().max()) / rms
+    err_s = float((t.scores.view(-1)[: s_ref.numel()] - s_ref).abs().max())
+    print(f"[range] heavy-tailed Base@640: stream max / median {['%.0f' % v for v in streams]}; embeddings rms {rms:.3g}, max err / rms "
+          f"{err_e:.3g}; scores max |d| {err_s:.3g}; {len(t.sscale)} of {len(amax)} tensors rescaled; kept {counts}")
+    assert err_e <= 1e-3 and err_s <= 1e-3
