@@ -594,14 +594,20 @@ def test_time_next_gemm_stamps_exactly_one_launch():
 
 
 @pytest.mark.parametrize("b,h,w,c", [(2, 20, 20, 1024), (1, 40, 40, 512), (3, 17, 23, 96), (1, 8, 16, 32), (2, 33, 9, 192), (1, 5, 5, 1536),
-                                     (3, 160, 160, 128), (1, 37, 53, 128), (4, 20, 36, 64), (2, 16, 16, 128)])
+                                     (3, 160, 160, 128), (1, 37, 53, 128), (4, 20, 36, 64), (2, 16, 16, 128),
+                                     # round 5: the wide register form (c = 256 / 384 / 512: channel blocks dealt to one or two thread
+                                     # groups, the LayerNorm butterfly's last block step through the LDS): BASELINE stage shapes, ragged
+                                     # tiles, both sides of the four-rows-per-group LayerNorm threshold at c = 256 (rows >= 65536)
+                                     (32, 40, 40, 512), (3, 40, 40, 512), (2, 13, 21, 512), (33, 80, 80, 256), (2, 80, 80, 256), (1, 9, 7, 256),
+                                     (2, 40, 40, 384), (1, 11, 19, 384)])
 @pytest.mark.parametrize("split", [False, True])
 def test_dwconv7_ln_fused_bit_identical_to_the_pair(b, h, w, c, split):
     """wd_dwconv7_ln == wd_dwconv7 followed by wd_layernorm_rows(_split) in place, bit for bit.  c > 128: one workgroup = an
     8 x 16 pixel tile over ALL channels, rows normalised from L2 right after they were written.  c <= 128 (round 3): a
     16 x 16 tile whose pre-norm values stay in registers, the LayerNorm butterfly done as register adds over the channel
     blocks + three lane exchanges.  Ragged tiles, every LN lane-group shape (8 / 16 / 32 lanes x 1 quad, NV 1..6), row counts
-    on both sides of the four-rows-per-group LayerNorm threshold (65536), fp32 and fp16 hi/lo outputs."""
+    on both sides of the four-rows-per-group LayerNorm threshold (65536), fp32 and fp16 hi/lo outputs.  Round 5: c = 256 / 384 /
+    512 take the wide register form (dwconv7_ln_wide_kernel)."""
     from wedetect_amd import lib as L
     g = torch.Generator(device="cuda").manual_seed(c + h)
     x = torch.randn(b * h * w, c, device="cuda", generator=g) * 2.0

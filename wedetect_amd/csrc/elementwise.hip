@@ -2,6 +2,7 @@
 // LayerNorm over channels, L2 row normalisation, DFL + box decode.  NHWC fp32, 16-byte
 // per-lane accesses with lanes running along the channel axis (coalesced 1 KiB per wave
 // instruction whenever C >= 256).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -771,6 +772,228 @@ __global__ void __launch_bounds__(256) dwconv7_ln_reg4_kernel(const float* __res
   dwln_reg_rows<NBLK, SPLIT, 4>(acc, y, gamma, beta, (b * h + (row_ok ? ho : h0)) * (long long)w, w, w0 + wg * 4, C, eps, q, row_ok);
 }
 
+// ---------------------------------------------------------------------------------------
+// depthwise 7x7 + LayerNorm for the WIDE stages (round 5: c = 256 / 384 / 512), pre-norm values in registers.
+// The 128-channel form above keeps 16 values per channel block and thread; at 512 channels that would be 256 registers.
+// Here the channel blocks are dealt to NG thread GROUPS of 256 threads (four waves each) inside one workgroup: group G runs
+// the 8 x 16-tile / 1 x 4-strip depthwise conv of dwconv7_tiled_kernel over the blocks b = G, G + NG, ... (its own halo tile
+// and taps in its own LDS area), so a thread holds NB = blocks / NG blocks x 4 pixels x 4 channels = 16 NB registers
+// (128 at c = 512).  LayerNorm then runs on the registers.  A pixel's channels sit in blocks x the 8 lanes t & 7; the row
+// sums are arranged as the xor butterfly of wd_layernorm_rows over the quad index Q = 8 b + q with g = 64 lanes and
+// NV = ceil(blocks / 8) quads per lane: lane sum L(b') = p(b') + p(b' + 8) + ..., then b' ^ 4, b' ^ 2, b' ^ 1, then the lane
+// exchanges 4, 2, 1.  With NG = 2 a group owns the blocks of ONE parity, so the steps b' ^ 4 and b' ^ 2 are register adds and
+// only b' ^ 1 crosses the groups — one float per (pixel, lane) through the LDS, twice (sum, centred sum of squares).  Same
+// operations in the same order as dwconv -> LayerNorm run as two kernels: the same bits, and the 4 c bytes per pixel of
+// pre-norm values (105 MB per stage-3 block at B = 32) neither written nor read back.
+// ---------------------------------------------------------------------------------------
+template <int NBLK, int NG, bool SPLIT>
+__global__ void __launch_bounds__(256 * NG) dwconv7_ln_wide_kernel(const float* __restrict__ x, const float* __restrict__ w7,
+                                                                  const float* __restrict__ bias, float* __restrict__ y,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  int h, int w, int tiles_h, int tiles_w, float eps) {
+  static_assert(NG == 1 || NG == 2, "one or two thread groups");
+  static_assert(NBLK % NG == 0 && NBLK <= 16, "blocks must split evenly; at most two quads per lane of the 64-lane LayerNorm");
+  constexpr int C = NBLK * DT_CB, NB = NBLK / NG;
+  constexpr int NL = NG == 2 ? 4 : 8;                    // lane-sum slots of a thread: b' values it owns
+  extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+  const int G = NG == 2 ? (int)(threadIdx.x >> 8) : 0;   // wave-uniform
+  const int t = threadIdx.x & 255;
+  float* tin = lds_dyn + G * DT_LDS_FLOATS;
+  float* tw = tin + DT_IH * DT_IWP * DT_CP;
+  int bid = wd_xcd_contiguous(blockIdx.x, gridDim.x);
+  const int tx = bid % tiles_w; bid /= tiles_w;
+  const int ty = bid % tiles_h;
+  const long long b = bid / tiles_h;
+  const int h0 = ty * DT_TH, w0 = tx * DT_TW;
+  const int q = t & 7;
+  int wg, oy;
+  dt_lane_map(t, wg, oy);
+  const float* xb = x + (b * h) * (long long)w * C;
+  constexpr int NST = (DT_IH * DT_IW * 8 + 255) / 256;
+  f32x4 acc[NB][4];
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    const int cb = G + NG * k;                           // this group's k-th channel block
+    // the halo tile goes global -> registers -> LDS in HALVES rounds of NST / HALVES float4 per thread: beside 128 accumulator
+    // registers (NB = 8) the ten staging registers of the one-round form, their addresses and the taps' ten inputs spill
+    constexpr int HALVES = NB >= 8 ? 2 : 1, NSH = (NST + HALVES - 1) / HALVES;
+    if (k > 0) __syncthreads();                          // everyone is done reading the previous channel block's tile
+#pragma unroll
+    for (int hf = 0; hf < HALVES; ++hf) {
+      f32x4 stage[NSH];
+#pragma unroll
+      for (int i = 0; i < NSH; ++i) {
+        const int e = t + (hf * NSH + i) * 256;
+        const int pix = e >> 3;
+        const int py = pix / DT_IW, px = pix - py * DT_IW;
+        const int hi = h0 + py - 3, wi = w0 + px - 3;
+        const bool ok = hf * NSH + i < NST && e < DT_IH * DT_IW * 8 && (unsigned)hi < (unsigned)h && (unsigned)wi < (unsigned)w;
+        stage[i] = *reinterpret_cast<const f32x4*>(ok ? xb + ((long long)hi * w + wi) * C + cb * DT_CB + (e & 7) * 4 : g_zero4e);
+      }
+#pragma unroll
+      for (int i = 0; i < NSH; ++i) {
+        const int e = t + (hf * NSH + i) * 256;
+        if (hf * NSH + i < NST && e < DT_IH * DT_IW * 8)
+          *reinterpret_cast<f32x4*>(tin + (((e >> 3) / DT_IW) * DT_IWP + (e >> 3) % DT_IW) * DT_CP + (e & 7) * 4) = stage[i];
+      }
+    }
+    {
+      f32x4 wst[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int e = t + i * 256;
+        wst[i] = *reinterpret_cast<const f32x4*>(e < 49 * 8 ? w7 + (e >> 3) * C + cb * DT_CB + (e & 7) * 4 : g_zero4e);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int e = t + i * 256;
+        if (e < 49 * 8) *reinterpret_cast<f32x4*>(tw + (e >> 3) * DT_CB + (e & 7) * 4) = wst[i];
+      }
+    }
+    __syncthreads();
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + cb * DT_CB + q * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[k][j] = bv;
+#pragma unroll 1
+    for (int kh = 0; kh < 7; ++kh) {
+      const float* row = tin + ((oy + kh) * DT_IWP + wg * 4) * DT_CP + q * 4;
+      f32x4 in[10];
+#pragma unroll
+      for (int j = 0; j < 10; ++j) in[j] = *reinterpret_cast<const f32x4*>(row + j * DT_CP);
+#pragma unroll
+      for (int kw = 0; kw < 7; ++kw) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(tw + (kh * 7 + kw) * DT_CB + q * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[k][j] += in[j + kw] * wv;
+      }
+    }
+  }
+  // ---- LayerNorm on the registers
+  // the b' ^ 1 step of the butterfly: the partner value lives in the other group (NG = 2) or in this thread (NG = 1)
+  float* exch = lds_dyn;                                 // [2 rounds][NG][4 pixels][256 threads], over group 0's halo tile
+  if (NG == 2) __syncthreads();                          // both groups are done with their last halo tile
+  const int ho = h0 + oy;
+  const bool row_ok = ho < h;
+  const long long pix_row0 = (b * h + (row_ok ? ho : h0)) * (long long)w;
+  {
+#pragma clang fp contract(off)
+    // tree of the 64-lane butterfly over the block index: slots l = b' (NG = 1) or l = (b' - G) / 2 (NG = 2)
+    auto tree = [&](const float (&ps)[NB]) -> float {
+      float L[NL];
+#pragma unroll
+      for (int l = 0; l < NL; ++l) {
+        L[l] = 0.f;
+        if (l < NB) L[l] = 0.f + ps[l];                  // lane sum: 0 + p(b') [+ p(b' + 8)]
+        if (l + NL < NB) L[l] = L[l] + ps[l + NL];
+      }
+      if (NG == 2) return (L[0] + L[2]) + (L[1] + L[3]);               // b' ^ 4 (slots l ^ 2), b' ^ 2 (l ^ 1); b' ^ 1 = the other group
+      return ((L[0] + L[4]) + (L[2] + L[6])) + ((L[1] + L[5]) + (L[3] + L[7]));   // b' ^ 4, b' ^ 2, b' ^ 1
+    };
+    float mean[4], rstd[4];
+    float part[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float ps[NB];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) ps[k] = (acc[k][j][0] + acc[k][j][1]) + (acc[k][j][2] + acc[k][j][3]);
+      part[j] = tree(ps);
+    }
+    if (NG == 2) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) exch[(G * 4 + j) * 256 + t] = part[j];
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) part[j] = part[j] + exch[((G ^ 1) * 4 + j) * 256 + t];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float s = part[j];
+      s += __shfl_xor(s, 4, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 1, 64);
+      mean[j] = s / (float)C;
+      float ps[NB];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const f32x4 d = acc[k][j] - mean[j];
+        ps[k] = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+      }
+      part[j] = tree(ps);
+    }
+    if (NG == 2) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) exch[2048 + (G * 4 + j) * 256 + t] = part[j];
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) part[j] = part[j] + exch[2048 + ((G ^ 1) * 4 + j) * 256 + t];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float sq = part[j];
+      sq += __shfl_xor(sq, 4, 64);
+      sq += __shfl_xor(sq, 2, 64);
+      sq += __shfl_xor(sq, 1, 64);
+      rstd[j] = 1.0f / sqrtf(sq / (float)C + eps);
+    }
+    const int wo0 = w0 + wg * 4;
+    int Ge = __builtin_amdgcn_readfirstlane(G), qe = q;  // the output addresses are computed HERE: hipcc otherwise forms them per
+    asm volatile("" : "+s"(Ge), "+v"(qe));               // block next to the bias address, 40 lines in, and spills them
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      __builtin_amdgcn_sched_barrier(0);                 // one block's gamma / beta at a time
+      const int cb = Ge + NG * k;
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + cb * DT_CB + qe * 4);
+      const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + cb * DT_CB + qe * 4);
+      const int qg = cb * 8 + qe;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (!row_ok || wo0 + j >= w) continue;
+        float* yr = y + (pix_row0 + wo0 + j) * C;
+        const f32x4 tn = (acc[k][j] - mean[j]) * rstd[j];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = fmaf(tn[e], gm[e], bt[e]);
+        if (SPLIT) {
+          typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+          typedef float f32x2 __attribute__((ext_vector_type(2)));
+          typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+          const f32x2 a = {o[0], o[1]}, b2 = {o[2], o[3]};
+          const h2 ha = __builtin_convertvector(a, h2), hb = __builtin_convertvector(b2, h2);
+          const h2 la = __builtin_convertvector(a - __builtin_convertvector(ha, f32x2), h2);
+          const h2 lb = __builtin_convertvector(b2 - __builtin_convertvector(hb, f32x2), h2);
+          unsigned char* gp = reinterpret_cast<unsigned char*>(yr) + (size_t)(qg >> 1) * 32 + (qg & 1) * 8;
+          *reinterpret_cast<u32x2*>(gp) = u32x2{__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)};
+          *reinterpret_cast<u32x2*>(gp + 16) = u32x2{__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)};
+        } else {
+          *reinterpret_cast<f32x4*>(yr + qg * 4) = o;
+        }
+      }
+    }
+  }
+}
+
+template <int NBLK, int NG>
+static int launch_dwln_wide(const float* x, const float* w7, const float* bias, float* y, const float* gamma, const float* beta,
+                            int batch, int h, int w, float eps, int split, hipStream_t st) {
+  const int th = (h + DT_TH - 1) / DT_TH, tw = (w + DT_TW - 1) / DT_TW;
+  const long long nblk = (long long)batch * th * tw;
+  if (nblk > 0x7fffffffLL) return WD_ERR_BAD_ARG;
+  constexpr int LDS = NG * DT_LDS_FLOATS * 4;
+  static_assert(NG == 1 || LDS >= 2 * 2048 * 4 + 0, "exchange area lies inside the halo tiles");
+  if (split) {
+    static WdAttrOnce attr;
+    if (wd_set_max_lds(attr, reinterpret_cast<const void*>(dwconv7_ln_wide_kernel<NBLK, NG, true>), LDS) != WD_OK) return WD_ERR_LAUNCH;
+    hipLaunchKernelGGL((dwconv7_ln_wide_kernel<NBLK, NG, true>), dim3((unsigned)nblk), dim3(256 * NG), LDS, st, x, w7, bias, y, gamma,
+                       beta, h, w, th, tw, eps);
+  } else {
+    static WdAttrOnce attr;
+    if (wd_set_max_lds(attr, reinterpret_cast<const void*>(dwconv7_ln_wide_kernel<NBLK, NG, false>), LDS) != WD_OK) return WD_ERR_LAUNCH;
+    hipLaunchKernelGGL((dwconv7_ln_wide_kernel<NBLK, NG, false>), dim3((unsigned)nblk), dim3(256 * NG), LDS, st, x, w7, bias, y, gamma,
+                       beta, h, w, th, tw, eps);
+  }
+  return wd_launch_status();
+}
+
 // L2 row normalisation, one wave per row (rows are few: the text bank).
 __global__ void __launch_bounds__(256) l2norm_rows_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                           long long rows, int c) {
@@ -930,6 +1153,16 @@ extern "C" int wd_dwconv7_ln(const float* x, const float* w7, const float* bias,
     switch (c / DT_CB) { WD_DWLN_REG(1) WD_DWLN_REG(2) WD_DWLN_REG(3) WD_DWLN_REG(4) }
 #undef WD_DWLN_REG
     return wd_launch_status();
+  }
+  // round 5: 256 / 384 / 512 channels in registers, the blocks dealt to one or two thread groups ($WEDETECT_DWLN_WIDE=0: the
+  // round-2 form below, which passes the pre-norm values through L2 and loses to the two-kernel pair)
+  {
+    const char* e = getenv("WEDETECT_DWLN_WIDE");
+    if (!(e && e[0] == '0')) {
+      if (c == 256) return launch_dwln_wide<8, 1>(x, w7, bias, y, gamma, beta, batch, h, w, eps, split, st);
+      if (c == 384) return launch_dwln_wide<12, 2>(x, w7, bias, y, gamma, beta, batch, h, w, eps, split, st);
+      if (c == 512) return launch_dwln_wide<16, 2>(x, w7, bias, y, gamma, beta, batch, h, w, eps, split, st);
+    }
   }
   const int th = (h + DT_TH - 1) / DT_TH, tw = (w + DT_TW - 1) / DT_TW;
   const long long nblk = (long long)batch * th * tw;

@@ -252,7 +252,7 @@ static int conv_gemm_split_impl(const WdConvGemm* pp, const void* w_split, float
     if (production && plain && !special && p.k % 16 == 0)
       cfg = pick_presplit_cfg(p.m, p.n, p.k, ws != nullptr && force_splits == 0 && ws_bytes / 4 >= wd_p8_workspace_floats() &&
                                                  p.lda % 8 == 0 && !(flags & ~(WD_SPLIT_A | WD_SPLIT_C)));
-    if (cfg != 50 && cfg != 51 && cfg != 55 && cfg != 60 && cfg != 63 && cfg != 64 && cfg != 65 && cfg != 66 && !(cfg >= 640 && cfg < 672)) cfg = 51;
+    if (cfg != 50 && cfg != 51 && cfg != 55 && cfg != 60 && cfg != 63 && cfg != 64 && cfg != 65 && cfg != 66 && !(cfg >= 640 && cfg < 768)) cfg = 51;
     if ((flags & WD_SPLIT_C) && cfg == 55) cfg = 50;
   }
   const long long ws_floats = ws ? ws_bytes / 4 : 0;

@@ -209,7 +209,8 @@ __device__ __forceinline__ void epi_lds_tile(const WdConvGemm& p, const EpiVec& 
 // The same tile written as fp16 hi/lo groups ([hi x8 | lo x8] per 8 channels, the layout an
 // ASPLIT consumer and wd_split_weights use): a lane takes 8 consecutive channels of a row, 4 lanes
 // cover the 128 bytes the fp32 row segment would occupy.  Plain row-major outputs only.
-template <int I, int J, int TM, int TN, int ACT>
+// EABL (timing-only, -DWD_DEBUG_ABLATIONS builds): 32 = all the arithmetic, no stores; 64 = the stores, no arithmetic
+template <int I, int J, int TM, int TN, int ACT, int EABL = 0>
 __device__ __forceinline__ void epi_lds_tile_csplit(const WdConvGemm& p, const EpiVec& ev, int mw, int nw, int lane,
                                                     const f32x16 (&acc)[TM][TN], float* patch) {
 #pragma unroll
@@ -236,6 +237,13 @@ __device__ __forceinline__ void epi_lds_tile_csplit(const WdConvGemm& p, const E
         b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
       }
       f32x4 o0, o1;
+      if constexpr ((EABL & 64) != 0) {
+        const u32x4 r0 = __builtin_bit_cast(u32x4, v0), r1 = __builtin_bit_cast(u32x4, v1);
+        unsigned char* cq = reinterpret_cast<unsigned char*>(p.c + (size_t)m * p.ldc) + (size_t)(n >> 3) * 32;
+        __builtin_nontemporal_store(r0, reinterpret_cast<u32x4*>(cq));
+        __builtin_nontemporal_store(r1, reinterpret_cast<u32x4*>(cq + 16));
+        continue;
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         o0[r] = sact<ACT>(fmaf(v0[r], ev.unscale, b0[r]));
@@ -251,6 +259,10 @@ __device__ __forceinline__ void epi_lds_tile_csplit(const WdConvGemm& p, const E
       split4(o0, h0, l0);
       split4(o1, h1, l1);
       unsigned char* cp = reinterpret_cast<unsigned char*>(p.c + (size_t)m * p.ldc) + (size_t)(n >> 3) * 32;
+      if constexpr ((EABL & 32) != 0) {                       // keep the arithmetic alive, store (almost) nothing
+        if ((h0[0] ^ l0[0] ^ h1[1] ^ l1[1]) == 0x12345678u) *reinterpret_cast<u32x4*>(cp) = u32x4{h0[0], h0[1], h1[0], h1[1]};
+        continue;
+      }
       // non-temporal: the hi/lo output of a C-split layer is a write-once stream (1.7 GB per stage-1 pwconv1) that its consumer
       // re-reads only after this launch is over: keep it from displacing the operand panels in L2 (-0.3 ms per step, same box)
 #ifdef WD_CSPLIT_PLAIN_STORE
@@ -273,16 +285,16 @@ __device__ __forceinline__ void epi_lds_tile_csplit(const WdConvGemm& p, const E
 // transpose — was 5-10 % SLOWER on the 51200 x 2048 x 512 pwconv1 launch (450-470 us against 404-426 us): beside 128
 // live accumulators the 16-value GELU batches spill, and the transposed form already overlaps its VALU work with the
 // stores of the previous 32 x 32 tile.
-template <int IJ, int TM, int TN, int ACT>
+template <int IJ, int TM, int TN, int ACT, int EABL = 0>
 struct EpiCsplitWalk {
   static __device__ __forceinline__ void run(const WdConvGemm& p, const EpiVec& ev, int mw, int nw, int lane,
                                              const f32x16 (&acc)[TM][TN], float* patch) {
-    epi_lds_tile_csplit<IJ / TN, IJ % TN, TM, TN, ACT>(p, ev, mw, nw, lane, acc, patch);
-    EpiCsplitWalk<IJ + 1, TM, TN, ACT>::run(p, ev, mw, nw, lane, acc, patch);
+    epi_lds_tile_csplit<IJ / TN, IJ % TN, TM, TN, ACT, EABL>(p, ev, mw, nw, lane, acc, patch);
+    EpiCsplitWalk<IJ + 1, TM, TN, ACT, EABL>::run(p, ev, mw, nw, lane, acc, patch);
   }
 };
-template <int TM, int TN, int ACT>
-struct EpiCsplitWalk<TM * TN, TM, TN, ACT> {
+template <int TM, int TN, int ACT, int EABL>
+struct EpiCsplitWalk<TM * TN, TM, TN, ACT, EABL> {
   static __device__ __forceinline__ void run(const WdConvGemm&, const EpiVec&, int, int, int,
                                              const f32x16 (&)[TM][TN], float*) {}
 };

@@ -46,6 +46,7 @@
 // position of the same stream, their read / DMA-issue bursts (an LDS-DMA instruction costs 60-185 issue cycles)
 // coincide instead of hiding behind the partner's MFMAs.  The staggered two-barrier form below keeps one wave of
 // every SIMD in its MFMA run while the other issues memory work, which is what the matrix pipe needs.
+#include <stdlib.h>
 #include "split_gemm_impl.h"
 
 long long wd_p8_workspace_floats();
@@ -195,7 +196,7 @@ __device__ __forceinline__ void p8_retr_epilogue(const WdConvGemm& p, const P8Re
 template <int VAR, int ABL = 0, bool PERSIST = false>
 __global__ void __launch_bounds__(512, 2)
 split_gemm_p8_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, int k16, float unscale, int nbn,
-                     int vec_c, int vec_res, int vec_bias, int ngrp, int nbm, const P8Persist ps, const P8Retr rt) {
+                     int vec_c, int vec_res, int vec_bias, int ngrp, int nbm, const P8Persist ps, const P8Retr rt, int stagger) {
   constexpr int TM = 4, TN = 2, BM = 256, BN = 256, ROWB = P8_ROWB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int t = threadIdx.x, lane = t & 63;
@@ -204,6 +205,11 @@ split_gemm_p8_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, 
   const int nk = p.k >> 5;
   const int gsz = ngrp * nbm;
 
+  // Experiment ($WD_P8_STAGGER, tile form): every tile costs the same, so all CUs reach their epilogues — 256 KB of stores each —
+  // in the same microseconds of every round.  Delaying the first tile of every other CU by `stagger` x ~4 us takes the two
+  // halves of the chip out of phase for the whole launch.
+  if (!PERSIST && stagger > 0 && blockIdx.x < 256u && ((blockIdx.x >> 3) & 1))
+    for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
   // ---- work assignment
   int seg_first_tile, seg_o, seg_last_tile, seg_e;   // units [first_tile * nk + o, last_tile * nk + e)
   if (PERSIST) {
@@ -513,7 +519,7 @@ split_gemm_p8_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, 
       switch (p.act) {
         case WD_ACT_RELU: EpiCsplitWalk<0, TM, TN, WD_ACT_RELU>::run(p, ev, mw, nw, lane_e, acc, patch); break;
         case WD_ACT_SILU: EpiCsplitWalk<0, TM, TN, WD_ACT_SILU>::run(p, ev, mw, nw, lane_e, acc, patch); break;
-        case WD_ACT_GELU: EpiCsplitWalk<0, TM, TN, WD_ACT_GELU>::run(p, ev, mw, nw, lane_e, acc, patch); break;
+        case WD_ACT_GELU: EpiCsplitWalk<0, TM, TN, WD_ACT_GELU, (ABL & 96)>::run(p, ev, mw, nw, lane_e, acc, patch); break;
         default: EpiCsplitWalk<0, TM, TN, WD_ACT_NONE>::run(p, ev, mw, nw, lane_e, acc, patch); break;
       }
     } else if (epi_res_prefetch_ok(p, ev, nw, 64) && mw < p.m) {
@@ -543,6 +549,11 @@ int p8_workgroups() {
     slot = prop.multiProcessorCount / 8 * 8;
   }
   return slot;
+}
+
+int p8_stagger() {
+  const char* e = getenv("WD_P8_STAGGER");
+  return e ? atoi(e) : 0;
 }
 
 // gang size of the persistent form for nbn column tiles: the largest of 8 / 4 / 2 / 1 that divides nbn (and the 32
@@ -586,7 +597,7 @@ int launch_p8(const WdConvGemm& p, const void* wsp, float unscale, hipStream_t s
   static WdAttrOnce attr;
   if (wd_set_max_lds(attr, reinterpret_cast<const void*>(k), P8_LDS) != WD_OK) return WD_ERR_LAUNCH;
   WD_LAUNCH_GEMM(k, dim3((unsigned)grid), dim3(512), P8_LDS, st, p, static_cast<const unsigned char*>(wsp), k16, unscale, nbn,
-                 vec_c, vec_res, vec_bias, ngrp, nbm, ps, P8Retr{});
+                 vec_c, vec_res, vec_bias, ngrp, nbm, ps, P8Retr{}, p8_stagger());
   return wd_launch_status();
 }
 
@@ -602,7 +613,7 @@ int launch_p8_retr(const WdConvGemm& p, const void* wsp, float unscale, const P8
   static WdAttrOnce attr;
   if (wd_set_max_lds(attr, reinterpret_cast<const void*>(k), P8_LDS) != WD_OK) return WD_ERR_LAUNCH;
   WD_LAUNCH_GEMM(k, dim3((unsigned)nblk), dim3(512), P8_LDS, st, p, static_cast<const unsigned char*>(wsp), k16, unscale, nbn,
-                 0, 0, 0, 8, nbm, P8Persist{nullptr, nullptr, nullptr, (int)nblk}, rt);
+                 0, 0, 0, 8, nbm, P8Persist{nullptr, nullptr, nullptr, (int)nblk}, rt, 0);
   return wd_launch_status();
 }
 
@@ -630,7 +641,8 @@ int wd_launch_p8(const WdConvGemm& p, const void* w, float unscale, bool csplit,
                  float* ws, long long ws_floats) {
 #ifdef WD_DEBUG_ABLATIONS
   if (abl && !persist) {
-    if (csplit) return abl == 4 ? launch_p8<SVAR_CSPLIT, 4>(p, w, unscale, st) : WD_ERR_UNSUPPORTED;
+    if (csplit) return abl == 4 ? launch_p8<SVAR_CSPLIT, 4>(p, w, unscale, st) : abl == 32 ? launch_p8<SVAR_CSPLIT, 32>(p, w, unscale, st)
+                     : abl == 64 ? launch_p8<SVAR_CSPLIT, 64>(p, w, unscale, st) : WD_ERR_UNSUPPORTED;
     switch (abl) {
       case 1: return launch_p8<0, 1>(p, w, unscale, st);
       case 2: return launch_p8<0, 2>(p, w, unscale, st);

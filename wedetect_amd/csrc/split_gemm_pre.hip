@@ -530,7 +530,7 @@ int wd_launch_presplit(const WdConvGemm& p, const void* w, float unscale, int cf
     if (!glds_ok(p, 16)) return WD_ERR_UNSUPPORTED;
     return wd_launch_p4(p, w, unscale, csplit, st);
   }
-  if (cfg == 64 || cfg == 65 || (cfg >= 640 && cfg < 672)) {   // 256 x 256 tiles, four phases per K tile of 32, counted DMA waits (split_gemm_p8.hip)
+  if (cfg == 64 || cfg == 65 || (cfg >= 640 && cfg < 768)) {   // 256 x 256 tiles, four phases per K tile of 32, counted DMA waits (split_gemm_p8.hip)
     if (!glds_ok(p, 32)) return WD_ERR_UNSUPPORTED;
     // 65: persistent work-unit form (needs the workspace); 640 + ablation mask: debug builds only
     return wd_launch_p8(p, w, unscale, csplit, st, cfg >= 640 ? cfg - 640 : 0, cfg == 65, ws, ws_floats);

@@ -112,6 +112,9 @@ class ImageTower:
         # dwconv -> LayerNorm in one kernel: "auto" = the stages of <= 128 channels, where the pre-norm values stay in registers
         # (profiles/r03_dwln_reg.txt); "1" = every stage (the wide ones through L2: slower, profiles/r02_dwln_ab.txt); "0" = never
         self.fuse_dwln = os.environ.get("WEDETECT_FUSE_DWLN", "auto")
+        # round 5: the same for 256 / 384 / 512 channels (dwconv7_ln_wide_kernel: the channel blocks dealt to one or two thread
+        # groups of a workgroup, pre-norm values in registers, bit-identical to the pair); comma-separated widths, "" = none
+        self.fuse_dwln_wide = tuple(int(v) for v in os.environ.get("WEDETECT_FUSE_DWLN_WIDE", "").split(",") if v.strip())
         self.overflowed = False
         # sticky range flag of the fp16x3 GEMMs (WdConvGemm.range_flag): set by a launch whose accumulators are inf / NaN
         self.range_flags = torch.zeros(2, dtype=torch.int32, device=torch.device(device))
@@ -447,7 +450,7 @@ class ImageTower:
             for j in range(a.depths[i]):
                 q = f"s{i}.{j}."
                 g_, b_ = self._ln_params(q + "ln_w", q + "ln_b", q + "ln" if pre else None)
-                if c % 32 == 0 and (self.fuse_dwln == "1" or (self.fuse_dwln == "auto" and c <= 128)):   # bit-identical to the pair
+                if c % 32 == 0 and (self.fuse_dwln == "1" or (self.fuse_dwln == "auto" and (c <= 128 or c in self.fuse_dwln_wide))):   # bit-identical to the pair
                     L.dwconv7_ln(self.x[i], self.P[q + "dw_w"], self.P[q + "dw_b"], self.tmp, g_, b_, B, h, w, c, split=pre)
                 else:
                     L.dwconv7(self.x[i], self.P[q + "dw_w"], self.P[q + "dw_b"], self.tmp, B, h, w, c)
