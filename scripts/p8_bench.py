@@ -37,7 +37,7 @@ for name, sh in SHAPES.items():
     x = torch.randn(m, k, device=dev) * 1.5
     xs = torch.empty(L.LIB.wd_split_weights_bytes(m, k), dtype=torch.uint8, device=dev)      # [hi x8 | lo x8] groups, scale 1
     L.check(L.LIB.wd_split_weights(x.data_ptr(), m, k, 1.0, xs.data_ptr(), L.stream_ptr()), "wd_split_weights")
-    xs = xs.view(torch.float32).view(m, k)
+    xs = xs.view(torch.float32).view(-1, k)[:m]
     del x
     w = torch.randn(n, k, device=dev) * k ** -0.5
     b = torch.randn(n, device=dev)

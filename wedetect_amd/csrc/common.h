@@ -81,7 +81,7 @@ __device__ __forceinline__ float wd_gelu(float x) {
   const float one_plus_erf = x >= 0.f ? 2.0f - erfc_abs : erfc_abs;
   return 0.5f * x * one_plus_erf;
 }
-#else
+#elif defined(WD_GELU_R4)   // the 13-instruction Abramowitz-Stegun form of round 4, for A/B builds only (profiles/r05_gelu_ab.txt)
 __device__ __forceinline__ float wd_gelu(float x) {
   // Every fused multiply-add of this function is written as fmaf; nothing else may be contracted.  The GEMM epilogues of
   // different kernels must produce the SAME bits for the same accumulator (pre-split and loader-split paths are compared bit
@@ -97,6 +97,27 @@ __device__ __forceinline__ float wd_gelu(float x) {
   const float e = __builtin_amdgcn_exp2f(-(xs * xs));                           // exp(-x^2 / 2)
   const float half_erfc = (y * t) * e;                                          // erfc(|x| / sqrt2) / 2
   return fmaf(-ax, half_erfc, fmaxf(x, 0.0f));
+}
+#else
+// Round 5: 8 instructions, ONE transcendental.  GELU(x) = max(x, 0) - |x| Phi(-|x|), and log2 Phi(-a) is so nearly a parabola
+// that a degree-5 polynomial in a reproduces a Phi(-a) to 5.5e-7 ABSOLUTE over the whole line (weighted minimax fit,
+// scripts/fit_gelu.py; the A-S form: 3.3e-7; the parity budget: 1e-3):  Phi(-a) = exp2(P5(a)),  P5(0) = -1 exactly, so
+// GELU(x) -> x / 2 with a RELATIVE error below 1e-6 as x -> 0.  Five FMAs, v_exp_f32, v_max, one FMA — the reciprocal, the second
+// polynomial and four multiplies of the round-4 form are gone (19 -> 11 issue slots per value with the transcendentals at
+// quarter rate; the GELU + split epilogue of a pwconv1 tile is VALU-bound, the fused block MLP of stage 1 too).  The leading
+// coefficient is negative: P5 -> -inf for large |x|, exp2 -> 0, and GELU(x) = max(x, 0) exactly there; x = +-inf gives NaN
+// (inf * 0), NaN stays NaN: non-finite inputs stay non-finite for the fp16x3 range guard, as before.
+__device__ __forceinline__ float wd_gelu(float x) {
+  // every operation written out (fmaf, no optional contraction): all kernels must produce the SAME bits for the same accumulator
+#pragma clang fp contract(off)
+  const float ax = fabsf(x);
+  float p = fmaf(-4.8865197459e-04f, ax, 7.2031705640e-03f);
+  p = fmaf(p, ax, -5.2158899605e-02f);
+  p = fmaf(p, ax, -4.5958217978e-01f);
+  p = fmaf(p, ax, -1.1510057449e+00f);
+  p = fmaf(p, ax, -1.0f);
+  const float phi = __builtin_amdgcn_exp2f(p);                                  // Phi(-|x|)
+  return fmaf(-ax, phi, fmaxf(x, 0.0f));
 }
 #endif
 
