@@ -43,7 +43,7 @@ def build(b, k):
 
 
 main = torch.cuda.current_stream()
-for rep in range(2):
+for rep in range(3):
     ts, xs = build(32, 1)
     dt = run(ts, xs, [main], steps)
     print(f"one tower  B=32, one stream : {32 / dt:8.1f} images/s  {1e3 * dt:.2f} ms per 32 images", flush=True)
