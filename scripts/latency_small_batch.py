@@ -25,8 +25,13 @@ for arch in ("tiny", "base"):
         x = torch.from_numpy(W.make_images(b, 640, 640, seed=5)).cuda()
         meta = tower.identity_meta(); meta[:, 7] = 1.0
         kw = dict(normalize_text=True, score_thr=0.001, with_embed=False)
-        te = timeit(lambda: tower.detect(x, text, meta, **kw))
-        g = GraphedDetect(tower, 80, **kw)
-        tg = timeit(lambda: g(x, text, meta))
-        print(f"{arch:5s} batch {b}: eager {te:7.2f} ms/step ({b / te * 1e3:7.1f} images/s)   hipGraph {tg:7.2f} ms/step ({b / tg * 1e3:7.1f} images/s)", flush=True)
-        del tower, g
+        res = {}
+        for dag in (False, True):                      # round 5: the neck / head DAG on side streams, eager and captured
+            tower.dag = tower._dag_in_capture = dag
+            res[("eager", dag)] = timeit(lambda: tower.detect(x, text, meta, **kw))
+            g = GraphedDetect(tower, 80, **kw)
+            res[("graph", dag)] = timeit(lambda: g(x, text, meta))
+            del g
+        print(f"{arch:5s} batch {b}: eager {res[('eager', False)]:6.2f} ms  eager+DAG {res[('eager', True)]:6.2f} ms  hipGraph {res[('graph', False)]:6.2f} ms  "
+              f"hipGraph+DAG {res[('graph', True)]:6.2f} ms   (best {b / min(res.values()) * 1e3:7.1f} images/s)", flush=True)
+        del tower

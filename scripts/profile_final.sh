@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 TAG=${1:-final}; shift
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
-CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fp32-reference --no-host-fed --no-calibrate $*"
+CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fp32-reference --no-host-fed --no-other-configs --no-calibrate $*"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o p -- $CMD > $OUT/trace_bench.json 2> $OUT/trace.err
 if [ -n "$TRACE_ONLY" ]; then     # kernel trace only (TRACE_ONLY=1): no counter passes
   python scripts/rocpd_summary.py $(ls $OUT/trace/*.db | head -1) > $OUT/summary.txt 2>&1

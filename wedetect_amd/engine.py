@@ -75,15 +75,19 @@ class ImageTower:
         # (the round-1 128 x 128 / ping-pong kernels, for A/B runs).
         self.p8_mode = os.environ.get("WEDETECT_P8", "persist")
         self.post_stream, self._post_ready, self._post_done = None, None, None      # detect(overlap_post=True)
-        # Neck / head as a DAG on side streams (round 5; $WEDETECT_DAG = "auto" (default): batches of >= 8 x 640 x 640 pixels,
-        # "1": always, "0": never = the serial chain of rounds 1-4).  The neck + head are ~110 launches of which the 20 x 20 /
+        # Neck / head as a DAG on side streams (round 5; $WEDETECT_DAG = "auto" (default, see below), "1": always, "0": never = the
+        # serial chain of rounds 1-4).  The neck + head are ~110 launches of which the 20 x 20 /
         # 40 x 40 ones fill 50 - 200 of 256 CUs, issued as ONE dependent chain although the graph is not one: the BiFusion
         # input branches only read backbone outputs, a BepC3's cv2 is independent of its 3 x 3 chain, head level 0 (the largest
         # head convs) needs only P3, which exists before downsample2 -> Rep_n3 -> downsample1 -> Rep_n4 run, and the cls / reg
         # branches of a level are independent (yolo_world_pafpn.py:1114-1137, yolo_world_head.py:271-294).  Same kernels, same
         # arguments, same buffers (disjoint channel slices where two lanes write one buffer): bit-identical results.
+        # Measured at Base / Tiny, batches 1 ... 32 (profiles/r05_small_batch.txt): eager launches gain at EVERY batch size (Tiny batch
+        # 1: 4.34 -> 3.93 ms, Base batch 32: +1.3 %), a captured hipGraph gains from 8 x 640 x 640 pixels and is neutral below — so
+        # "auto" = always when launching eagerly, from that size under capture.
         dag = os.environ.get("WEDETECT_DAG", "auto")
-        self.dag = dag == "1" or (dag == "auto" and batch * height * width >= 8 * 640 * 640)
+        self.dag = dag != "0"
+        self._dag_in_capture = dag == "1" or batch * height * width >= 8 * 640 * 640
         self._side: List[torch.cuda.Stream] = []
         self._events: List[torch.cuda.Event] = []
         self._ev_i = 0
@@ -356,7 +360,8 @@ class ImageTower:
     def _dag_on(self) -> bool:
         """Side streams are used for a step only outside the calibration pass (its recorders are torch ops on the current
         stream) and without the opt-in latency split-K (one shared workspace)."""
-        return self.dag and self._calib is None and self.kws is None
+        return (self.dag and self._calib is None and self.kws is None
+                and (self._dag_in_capture or not torch.cuda.is_current_stream_capturing()))
 
     def _lane_fws(self) -> torch.Tensor:
         """Fixed split-K workspace of the lane that is launching: two lanes may run split-K convs at the same time."""
