@@ -220,8 +220,8 @@ def test_fp16x3_range_guard_falls_back_to_fp32():
 
 
 def test_small_batches_replay_a_hipgraph_and_match_the_eager_step():
-    """batches of at most ``graph_max_batch`` images (4 by default; the reference runs batch 1)
-    go through a hipGraph captured on first use.  Same buffers, same kernels: bit-identical to the eager step, on the
+    """batches of at most ``graph_max_batch`` images ($WEDETECT_GRAPH_MAX_BATCH; 4 in rounds 2-4, 0 = eager by
+    default since round 5, when the eager step with the neck / head DAG became as fast) go through a hipGraph captured on first use.  Same buffers, same kernels: bit-identical to the eager step, on the
     first call (capture + replay) and on later ones (replay with new inputs); a larger batch stays eager."""
     from wedetect_amd import weights as W
     from wedetect_amd.detector import SimpleYOLOWorldDetector
@@ -232,7 +232,7 @@ def test_small_batches_replay_a_hipgraph_and_match_the_eager_step():
         return m.cuda().eval()
     graphed, eager = make(), make()
     eager._h.graph_max_batch = 0
-    assert graphed._h.graph_max_batch >= 3
+    graphed._h.graph_max_batch = 4
     imgs = _images()
     for batch in (imgs, imgs[::-1], imgs[:1], imgs[1:2]):
         a, b = graphed(batch), eager(batch)

@@ -116,9 +116,11 @@ class _TowerHolder:
         self._packed = None
         self._towers = {}
         self._graphs = {}
-        # batches up to this size replay the step from a captured hipGraph (launch-bound: ~380 launches per step);
-        # 0 = always eager
-        self.graph_max_batch = int(os.environ.get("WEDETECT_GRAPH_MAX_BATCH", "4"))
+        # batches up to this size replay the step from a captured hipGraph; 0 = always eager.  Default 0 since round 5: with the
+        # neck / head issued as a DAG on side streams the eager step is as fast as the replay or faster at every small batch
+        # (Tiny batch 1: 3.93 ms eager against 4.35 replayed, Base batch 1: 8.18 against 8.25 — profiles/r05_small_batch.txt; the
+        # replay was worth 6.6 -> 5.4 ms in round 2, before the step's launch count and host cost came down)
+        self.graph_max_batch = int(os.environ.get("WEDETECT_GRAPH_MAX_BATCH", "0"))
         # fp16x3 split scales are chosen from the first batch a tower sees (engine.ImageTower.calibrate); "0": never
         self.auto_calibrate = os.environ.get("WEDETECT_CALIBRATE", "1") != "0"
         # ONE set of split scales per checkpoint, shared by every (B, H, W) tower: an image gets the same bits whatever batch
