@@ -561,12 +561,31 @@ def retrieval_leg(L, n_img, regions, K, rank, world, steps, warmup, dist=None):
     us = rt.avg_us()
     tf = flops / (us * 1e-6) / 1e12 if us > 0 else 0.0
     peak = round(F16_MFMA_PEAK_TFLOPS / SPLIT_PASSES, 1) if scorer.precision == "fp16x3" else F32_MFMA_PEAK_TFLOPS
+    traffic, traffic_src = None, None
+    if (world, n_img, regions, K, scorer.precision) == (1, 32, 300, 1_000_000, "fp16x3"):
+        # fabric-side bytes per launch of THIS configuration from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+        # over `bench.py --mode retrieval --steps 2 --warmup 1`): L2 misses, Infinity-Cache hits included — 5 passes over the
+        # 3.07 GB bank (one per gang of eight row tiles) + the 29 MB of region rows re-fetched per four bank blocks; the kernel is
+        # bound by its K loop, not by this traffic (1.25 TB/s)
+        try:
+            from wedetect_amd.build import source_hash
+            doc = json.load(open(os.path.join(ROOT, "profiles", "r05_traffic_retrieval.json")))
+            rec = doc["kernels"]["split_gemm_p8_kernel<4096, 0, false>"]
+            traffic = round(rec["hbm_bytes_per_launch"])
+            now = source_hash()
+            traffic_src = {"file": "profiles/r05_traffic_retrieval.json", "commit": doc.get("commit"),
+                           "kernel_source_sha256": doc.get("kernel_source_sha256"), "running_kernel_source_sha256": now,
+                           "taken_on_these_sources": doc.get("kernel_source_sha256") == now,
+                           "note": "FETCH_SIZE / WRITE_SIZE are fabric-side counters: Infinity-Cache hits are in them"}
+        except Exception:
+            traffic, traffic_src = None, None
     return dict(dt=dt, precision=scorer.precision, tripped=scorer.tripped(), checksum=float(out[:, :: max(1, K // 4096)].double().sum().item()),
                 roofline={"kernel": ("split_gemm_p8_kernel<retrieval: bank rows x region rows, fp16x3 256x256x32/8w, in-register max over "
                                      "regions + one sigmoid per (image, class)> (3 x v_mfma_f32_32x32x16_f16 per product)"
                                      if scorer.precision == "fp16x3" else "retrieval_max_kernel (fp32 MFMA 16x16x4)"),
                           "bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
-                          "traffic": None, "timing": f"HIP events stamped by the kernel's own dispatch, last {n_inst} of the {steps} timed steps",
+                          "traffic": traffic, "traffic_provenance": traffic_src,
+                          "timing": f"HIP events stamped by the kernel's own dispatch, last {n_inst} of the {steps} timed steps",
                           "avg_launch_us": round(us, 1), "launches_per_step": 1,
                           "algorithmic_gflop_per_launch": round(flops / 1e9, 2), "algorithmic_bytes_per_launch": int(nbytes),
                           "peak_note": (f"fp16 dense MFMA peak {F16_MFMA_PEAK_TFLOPS} / {SPLIT_PASSES} passes per product"

@@ -126,12 +126,17 @@ int wd_conv_gemm_tuned(const WdConvGemm* p, int32_t cfg, void* stream);
  * Activations must be finite with |x| < 65504 (an fp16 hi half overflows to inf beyond): p->range_flag, when set,
  * receives 1 if a launch produced non-finite accumulators, so the host can re-run with wd_conv_gemm (fp32).
  * Weights are prepared once:
- *   wd_split_weights_bytes(n, k)  -> size of the split buffer (rows padded to 16 k)
+ *   wd_split_weights_bytes(n, k)  -> size of the split buffer (rows padded to 16 k; since ABI 13 also to a whole
+ *     group of 8 ROWS, i.e. >= the n * k16 * 4 bytes wd_split_weights writes)
  *   wd_split_weights(w, n, k, scale, out): out <- halves of w * scale, scale a power of two
- *     chosen by the caller so that max|w| * scale <= 2^14; pass w_unscale = 1 / scale below.
+ *     chosen by the caller so that max|w| * scale <= 2^14; pass w_unscale = 1 / scale below.  Writes exactly n rows.
+ *   wd_split_weights_padded(...) (ABI 13): the same, then ZERO rows up to the next multiple of 8 — all of
+ *     wd_split_weights_bytes(n, k).  Required for both operands of wd_retrieval_max_split, whose 256 x 256
+ *     kernel fetches whole 8-row groups; harmless everywhere else.
  * cfg < 0 picks the production tile; cfg >= 0 selects a tile for A/B runs (split_gemm.hip). */
 int64_t wd_split_weights_bytes(int32_t n, int32_t k);
 int wd_split_weights(const float* w, int32_t n, int32_t k, float scale, void* out, void* stream);
+int wd_split_weights_padded(const float* w, int32_t n, int32_t k, float scale, void* out, void* stream);
 int wd_conv_gemm_split(const WdConvGemm* p, const void* w_split, float w_unscale, int32_t flags, int32_t cfg,
                        void* stream);
 /* flags: operands that are stored as fp16 (hi, lo) groups instead of fp32 — per row, per 8
@@ -238,8 +243,8 @@ int wd_letterbox_u8(const uint8_t* src, int32_t h, int32_t w, const int32_t* bou
                     int32_t fill_r, int32_t fill_g, int32_t fill_b, void* stream);
 
 /* wd_retrieval_max in fp16x3 arithmetic (2-4x the fp32 kernel at large banks): both operands as fp16
- * (hi, lo) groups from wd_split_weights (whose buffers are padded to whole groups of 8 rows: the kernel fetches
- * 8-row groups) — e_split: the [n_img * rows_per_img, dim] region rows with scale 1, t_split: the [n_cls, dim]
+ * (hi, lo) groups from wd_split_weights_padded (buffers padded with zero rows to whole groups of 8: the kernel
+ * fetches 8-row groups) — e_split: the [n_img * rows_per_img, dim] region rows with scale 1, t_split: the [n_cls, dim]
  * bank with a power-of-two scale = 1 / t_unscale.  Same result definition as wd_retrieval_max
  * (retrieval_metric.py:367-377; sigmoid is applied to the maximum of the affine logits — it is monotone); out is
  * zeroed, then max-reduced with atomics (deterministic: max is order independent).  dim % 16 == 0; with

@@ -29,10 +29,12 @@ namespace {
 // weight preparation: fp32 [n][k] -> per row, per 8 k: [8 x fp16 hi | 8 x fp16 lo] of w*scale,
 // rows zero-padded to a multiple of 16 k.
 // ---------------------------------------------------------------------------------------
+// n_out >= n rows are written: rows [n, n_out) are zeros (wd_split_weights_padded: whole groups of eight rows for the DMA-fed
+// kernels that fetch 8-row groups)
 __global__ void split_weights_kernel(const float* __restrict__ w, int n, int k, int k16, float scale,
-                                     unsigned short* __restrict__ out) {
+                                     unsigned short* __restrict__ out, int n_out) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long long)((n + 7) & ~7) * k16) return;              // rows zero-padded to a whole group of eight (round 5)
+  if (idx >= (long long)n_out * k16) return;
   const int row = (int)(idx / k16), kk = (int)(idx % k16);
   const float x = (kk < k && row < n) ? w[(size_t)row * k + kk] * scale : 0.0f;
   const _Float16 hi = (_Float16)x;
@@ -81,13 +83,24 @@ extern "C" int64_t wd_split_weights_bytes(int32_t n, int32_t k) {
   return (int64_t)((n + 7) & ~7) * ((k + 15) / 16 * 16) * 4;          // rows padded to 8: DMA-fed kernels fetch whole 8-row groups
 }
 
-extern "C" int wd_split_weights(const float* w, int32_t n, int32_t k, float scale, void* out, void* stream) {
+static int split_weights_launch(const float* w, int32_t n, int32_t k, float scale, void* out, void* stream, int n_out) {
   if (!w || !out || n <= 0 || k <= 0 || !(scale > 0.0f) || !wd_aligned16(out)) return WD_ERR_BAD_ARG;
   const int k16 = (k + 15) / 16 * 16;
-  const long long total = (long long)((n + 7) & ~7) * k16;
+  const long long total = (long long)n_out * k16;
   hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), w, n, k, k16, scale, static_cast<unsigned short*>(out));
+                     static_cast<hipStream_t>(stream), w, n, k, k16, scale, static_cast<unsigned short*>(out), n_out);
   return wd_launch_status();
+}
+
+// writes exactly n rows (n * k16 * 4 bytes): the contract of ABI <= 12 — callers that size their own buffers stay correct
+extern "C" int wd_split_weights(const float* w, int32_t n, int32_t k, float scale, void* out, void* stream) {
+  return split_weights_launch(w, n, k, scale, out, stream, n);
+}
+
+// ABI 13: the same, then zero rows up to the next multiple of eight — wd_split_weights_bytes(n, k) bytes in all.  What
+// wd_retrieval_max_split wants for both operands (its 256 x 256 kernel fetches whole 8-row groups).
+extern "C" int wd_split_weights_padded(const float* w, int32_t n, int32_t k, float scale, void* out, void* stream) {
+  return split_weights_launch(w, n, k, scale, out, stream, (n + 7) & ~7);
 }
 
 // Production tile choice (profiles/r01_split_gemm_ab.txt): 128 x 128 x 16 (4 waves, four

@@ -32,7 +32,7 @@ EXPORTS = (
     "wd_abi_version", "wd_strerror", "wd_sizeof_conv_gemm", "wd_conv_gemm", "wd_conv_gemm_tuned", "wd_conv_gemm_config", "wd_stem_patchify", "wd_dwconv7", "wd_dwconv7_variant",
     "wd_layernorm_rows", "wd_l2norm_rows", "wd_dfl_decode", "wd_topk_workspace_bytes", "wd_topk_capacity",
     "wd_topk_candidates", "wd_nms_workspace_bytes", "wd_nms_gather", "wd_retrieval_max",
-    "wd_split_weights_bytes", "wd_split_weights", "wd_conv_gemm_split", "wd_conv_gemm_split_ws", "wd_conv_gemm_split_config", "wd_layernorm_rows_split", "wd_layernorm_rows_split_s2d", "wd_letterbox_u8", "wd_retrieval_max_split", "wd_text_embed", "wd_attention_small", "wd_recall_scratch_floats", "wd_recall_match",
+    "wd_split_weights_bytes", "wd_split_weights", "wd_split_weights_padded", "wd_conv_gemm_split", "wd_conv_gemm_split_ws", "wd_conv_gemm_split_config", "wd_layernorm_rows_split", "wd_layernorm_rows_split_s2d", "wd_letterbox_u8", "wd_retrieval_max_split", "wd_text_embed", "wd_attention_small", "wd_recall_scratch_floats", "wd_recall_match",
     "wd_max_sigmoid_attn", "wd_adaptive_maxpool_nhwc", "wd_cross_attention_small", "wd_time_next_gemm",
     "wd_cv_resize_paste_u8", "wd_chw_to_hwc_u8", "wd_p8_workspace_bytes", "wd_dwconv7_ln", "wd_probe_lds_dma", "wd_probe_issue", "wd_mlp_fused_split", "wd_mlp_fused_wide", "wd_stem_fused",
 )
@@ -102,6 +102,7 @@ def _load():
     lib.wd_split_weights_bytes.restype = i64
     lib.wd_split_weights_bytes.argtypes = [i32, i32]
     lib.wd_split_weights.argtypes = [vp, i32, i32, f32, vp, vp]
+    lib.wd_split_weights_padded.argtypes = [vp, i32, i32, f32, vp, vp]
     lib.wd_conv_gemm_split.argtypes = [C.POINTER(ConvGemm), vp, f32, i32, i32, vp]
     lib.wd_conv_gemm_split_ws.argtypes = [C.POINTER(ConvGemm), vp, f32, i32, i32, vp, i64, i32, vp]
     lib.wd_layernorm_rows_split.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, f32, vp]
@@ -247,7 +248,7 @@ def split_weights(w: torch.Tensor):
     amax = float(w.abs().max())
     scale = 1.0 if amax == 0.0 else 2.0 ** (13 - math.floor(math.log2(amax)))
     out = torch.empty(LIB.wd_split_weights_bytes(n, k), dtype=torch.uint8, device=w.device)
-    check(LIB.wd_split_weights(_p(w), n, k, scale, _p(out), stream_ptr()), "wd_split_weights")
+    check(LIB.wd_split_weights_padded(_p(w), n, k, scale, _p(out), stream_ptr()), "wd_split_weights_padded")   # zero rows up to a multiple of 8
     return out, 1.0 / scale
 
 
@@ -402,7 +403,7 @@ def retrieval_max_split(e, t_split, scale, bias, count, out, n_img, rows_per_img
     _f32(e, "e")
     rows = e.reshape(-1, dim).contiguous()
     es = torch.empty(LIB.wd_split_weights_bytes(rows.shape[0], dim), dtype=torch.uint8, device=e.device)
-    check(LIB.wd_split_weights(_p(rows), rows.shape[0], dim, 1.0, _p(es), stream_ptr()), "wd_split_weights")
+    check(LIB.wd_split_weights_padded(_p(rows), rows.shape[0], dim, 1.0, _p(es), stream_ptr()), "wd_split_weights_padded")
     check(LIB.wd_retrieval_max_split(_p(es), _p(t_split[0]), float(t_split[1]), _p(scale), _p(bias), _p(count), _p(out),
                                      n_img, rows_per_img, n_cls, dim, _p(range_flag), stream_ptr()), "wd_retrieval_max_split")
 
