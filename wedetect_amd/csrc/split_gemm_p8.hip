@@ -205,7 +205,7 @@ split_gemm_p8_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, 
   const int nk = p.k >> 5;
   const int gsz = ngrp * nbm;
 
-  // Experiment ($WD_P8_STAGGER, tile form): every tile costs the same, so all CUs reach their epilogues — 256 KB of stores each —
+  // Experiment ($WD_P8_STAGGER, tile form, -DWD_DEBUG_ABLATIONS builds; measured: no gain, profiles/r05_p8_epilogue_ablation.txt): every tile costs the same, so all CUs reach their epilogues — 256 KB of stores each —
   // in the same microseconds of every round.  Delaying the first tile of every other CU by `stagger` x ~4 us takes the two
   // halves of the chip out of phase for the whole launch.
   if (!PERSIST && stagger > 0 && blockIdx.x < 256u && ((blockIdx.x >> 3) & 1))
@@ -552,8 +552,12 @@ int p8_workgroups() {
 }
 
 int p8_stagger() {
+#ifdef WD_DEBUG_ABLATIONS                               // the CU-phase experiment of profiles/r05_p8_epilogue_ablation.txt: ablation builds only
   const char* e = getenv("WD_P8_STAGGER");
   return e ? atoi(e) : 0;
+#else
+  return 0;
+#endif
 }
 
 // gang size of the persistent form for nbn column tiles: the largest of 8 / 4 / 2 / 1 that divides nbn (and the 32

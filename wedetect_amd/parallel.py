@@ -361,7 +361,7 @@ class BankScorer:
         return bool(int(self.flag.item()))
 
 
-_SCORERS: list = []      # small cache of (key, BankScorer): the split of a 1M-class bank is a pass over 3 GB, done once per bank
+_SCORERS: list = []      # small cache of (weakref to the bank, version, precision, BankScorer): splitting a 1M-class bank is a pass over 3 GB
 
 
 def device_retrieval_scores(embeddings: torch.Tensor, count: torch.Tensor, scales: torch.Tensor, bias: torch.Tensor,
@@ -369,12 +369,14 @@ def device_retrieval_scores(embeddings: torch.Tensor, count: torch.Tensor, scale
     """[N, K] fp32: max over an image's kept regions of sigmoid(<e, t_k> exp(scale) + bias) on the device
     (retrieval_metric.py:369-375).  ``embeddings`` [N, R, D], ``scales`` / ``bias`` [N, R], ``count`` [N].  Runs the fp16x3
     kernel under its range guard by default (:class:`BankScorer`); the bank's split form is cached per bank tensor."""
-    key = (bank.data_ptr(), tuple(bank.shape), bank._version, str(bank.device), precision)
-    for k_, sc in _SCORERS:
-        if k_ == key:
+    import weakref
+    # keyed by the tensor OBJECT (weak reference) and its version counter — never by address: a freed bank's address can be
+    # handed to the next one, which would then be scored against the old split
+    for ref, ver, prec, sc in _SCORERS:
+        if ref() is bank and ver == bank._version and prec == precision:
             return sc(embeddings, count, scales, bias)
     sc = BankScorer(bank, precision)
-    _SCORERS.append((key, sc))
+    _SCORERS.append((weakref.ref(bank), bank._version, precision, sc))
     del _SCORERS[:-2]
     return sc(embeddings, count, scales, bias)
 
