@@ -405,9 +405,15 @@ def test_hipgraph_replay_equals_eager_and_is_faster_at_batch1():
             fn()
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n
+    # like for like: the graph was captured without the side-stream DAG (batch 1), so it is held against the SERIAL eager step.
+    # (Round 5: the eager step WITH the neck / head DAG is faster than either — 3.9 vs 4.35 ms — which is why the detectors
+    # launch eagerly by default now; printed, not asserted: it is a property of the host, not of the kernels.)
+    te_dag = timeit(lambda: tower.detect(x1, text, meta, normalize_text=True, score_thr=0.001, with_embed=True))
+    tower.dag = False
     te = timeit(lambda: tower.detect(x1, text, meta, normalize_text=True, score_thr=0.001, with_embed=True))
+    tower.dag = True
     tg = timeit(lambda: g(x1, text, meta))
-    print(f"[tiny b1 640] eager {te*1e3:.2f} ms/step, hipGraph {tg*1e3:.2f} ms/step")
+    print(f"[tiny b1 640] eager {te*1e3:.2f} ms/step, eager + DAG {te_dag*1e3:.2f} ms/step, hipGraph {tg*1e3:.2f} ms/step")
     assert tg < te * 1.05
 
 

@@ -294,7 +294,7 @@ def test_retrieval_max_split_matches_fp32_kernel_and_shards():
 
 
 @pytest.mark.parametrize("n_img,rows,k,dim", [(5, 300, 10_000, 768), (3, 300, 1203, 768), (7, 20, 515, 64), (33, 7, 264, 96),
-                                              (2, 301, 81, 768), (1, 64, 8, 32), (4, 129, 2049, 256)])
+                                              (2, 301, 81, 768), (1, 64, 8, 32), (4, 129, 2049, 256), (100, 1, 40, 64), (1, 300, 1, 768)])
 def test_retrieval_on_the_256_tile_kernel(n_img, rows, k, dim, monkeypatch):
     """Round 5: wd_retrieval_max_split on the 256 x 256 kernel with the operand roles swapped (bank = lane axis, region rows =
     register axis, in-register max, ONE sigmoid per (image, class)) against (a) fp64 torch on the definition of
