@@ -334,7 +334,8 @@ def test_retrieval_on_the_256_tile_kernel(n_img, rows, k, dim, monkeypatch):
     for r in range(3):
         sr = shard_range(k, 3, r)
         o = torch.empty(n_img, len(sr), device="cuda")
-        L.retrieval_max_split(e, L.split_weights(t[sr.start:sr.stop].contiguous()), scale, bias, cnt, o, n_img, rows, len(sr), dim)
+        if len(sr):                                                    # a bank of fewer classes than ranks leaves shards empty
+            L.retrieval_max_split(e, L.split_weights(t[sr.start:sr.stop].contiguous()), scale, bias, cnt, o, n_img, rows, len(sr), dim)
         parts.append(o)
     assert torch.equal(torch.cat(parts, dim=1), out)
     # the range guard: one embedding beyond the fp16 maximum raises the flag
