@@ -279,6 +279,63 @@ __device__ __forceinline__ void epi_lds_tile_csplit(const WdConvGemm& p, const E
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Round 5 experiment ($WEDETECT_CSPLIT_DIRECT=1, 256 x 256 kernel only): the same hi/lo output WITHOUT the LDS transpose.  In the
+// accumulator a lane (row m, half h) holds channels 8 g + 4 h + 0..3 of every 8-channel group g, its partner lane (m, 1 - h) the
+// other four: two v_permlane32_swap per group hand the low half the eight hi values and the high half the eight lo values —
+// 16 bytes each, adjacent in memory — and a group is stored with one instruction (32 rows x 32 contiguous bytes).  Same
+// arithmetic per element as epi_lds_tile_csplit: bit-identical.  The through-LDS form exists because whole 128-byte row segments
+// were worth 13-27 % on the round-1 kernels; round 5 measured that full-line fp32 rows and 16-byte pieces at a 32-byte stride cost
+// this kernel the same (profiles/r05_gelu_ab.txt), so the transpose (4 ds_write_b128 + 4 ds_read_b128 + two wave barriers per
+// 32 x 32 tile) might have been pure cost.  It is not: MEASURED 516 vs 336 us on the stage-3 pwconv1 launch, 2 088 vs 695 us at stage 1,
+// the step 782 vs 881 images/s (profiles/r05_csplit_direct.txt) — a store instruction that touches 32 lines with 32 bytes each costs
+// about three times one that touches 16 with 64; from 16 lines to 8 whole ones nothing more is gained.  Reachable in
+// -DWD_DEBUG_ABLATIONS builds only ($WEDETECT_CSPLIT_DIRECT=1).  (The round-2 "compute-first" form did the swaps AND the transpose.)
+template <int I, int J, int TM, int TN, int ACT>
+__device__ __forceinline__ void epi_direct_tile_csplit(const WdConvGemm& p, const EpiVec& ev, int mw, int nw, int lane,
+                                                       const f32x16 (&acc)[TM][TN]) {
+  const int m = mw + I * 32 + (lane & 31);
+  const int h = lane >> 5;
+  const float cs = p.c_split_scale != 0.f ? p.c_split_scale : 1.0f;
+  unsigned char* rowp = reinterpret_cast<unsigned char*>(p.c + (size_t)(m < p.m ? m : 0) * p.ldc) + 16 * h;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int n = nw + J * 32 + 8 * g;                              // wave-uniform: the swaps below need every lane
+    if (n >= p.n) continue;
+    const f32x4 v = {acc[I][J][4 * g], acc[I][J][4 * g + 1], acc[I][J][4 * g + 2], acc[I][J][4 * g + 3]};
+    if (p.range_flag) {
+      if (wd_any_nonfinite4(v[0], v[1], v[2], v[3])) *p.range_flag = 1u;
+    }
+    f32x4 b = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) b = *reinterpret_cast<const f32x4*>(p.bias + n + 4 * h);
+    f32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = sact<ACT>(fmaf(v[r], ev.unscale, b[r]));
+    o = o * cs;
+    u32x2 hh, ll;
+    split4(o, hh, ll);
+    u32x4 out;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const auto sw = __builtin_amdgcn_permlane32_swap(hh[d], ll[d], false, false);   // low half: [hi own | hi partner]; high half: [lo partner | lo own]
+      out[d] = sw[0];
+      out[2 + d] = sw[1];
+    }
+    if (m < p.m) __builtin_nontemporal_store(out, reinterpret_cast<u32x4*>(rowp + (size_t)(n >> 3) * 32));
+  }
+}
+template <int IJ, int TM, int TN, int ACT>
+struct EpiCsplitDirectWalk {
+  static __device__ __forceinline__ void run(const WdConvGemm& p, const EpiVec& ev, int mw, int nw, int lane,
+                                             const f32x16 (&acc)[TM][TN]) {
+    epi_direct_tile_csplit<IJ / TN, IJ % TN, TM, TN, ACT>(p, ev, mw, nw, lane, acc);
+    EpiCsplitDirectWalk<IJ + 1, TM, TN, ACT>::run(p, ev, mw, nw, lane, acc);
+  }
+};
+template <int TM, int TN, int ACT>
+struct EpiCsplitDirectWalk<TM * TN, TM, TN, ACT> {
+  static __device__ __forceinline__ void run(const WdConvGemm&, const EpiVec&, int, int, int, const f32x16 (&)[TM][TN]) {}
+};
+
 // Tried and dropped (round 2, profiles/r02_p8_ablations.txt): a compute-first form of this epilogue — bias + GELU +
 // fp16 split on the accumulators where they lie, 8-byte pieces swapped between the lane halves with
 // v_permlane32_swap so that every lane owns a final 16-byte [hi x 8] / [lo x 8] chunk, and only then the LDS

@@ -116,6 +116,7 @@ struct P8Persist {
 // order of the MLP launches): per 32 tiles an L2 fetches 12 operand panels instead of 33, the bank streams from HBM once per
 // row-tile group (five times for 32 images x 300 regions), the region rows (29 MB) stay in the Infinity Cache.
 constexpr int P8VAR_RETR = 4096;
+constexpr int P8VAR_DIRECT = 8192;      // with SVAR_CSPLIT: the direct (no LDS transpose) hi/lo epilogue; GELU / no activation only
 struct P8Retr {
   const float* scale;    // [region rows]: logit scale of a row, applied as exp(scale)
   const float* bias;     // [region rows]
@@ -515,7 +516,10 @@ split_gemm_p8_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, 
     int lane_e = lane;
     asm volatile("" : "+v"(lane_e));          // epilogue address arithmetic starts HERE (hipcc otherwise computes it before the K loop and keeps ~50 registers alive across it)
     static_assert(P8_LDS >= 8 * 32 * EPI_LDT * 4, "operand LDS must hold one patch per wave");
-    if (VAR & SVAR_CSPLIT) {
+    if constexpr ((VAR & P8VAR_DIRECT) != 0) {                      // hi/lo output without the LDS transpose (experiment, see split_gemm_impl.h)
+      if (p.act == WD_ACT_GELU) EpiCsplitDirectWalk<0, TM, TN, WD_ACT_GELU>::run(p, ev, mw, nw, lane_e, acc);
+      else EpiCsplitDirectWalk<0, TM, TN, WD_ACT_NONE>::run(p, ev, mw, nw, lane_e, acc);
+    } else if (VAR & SVAR_CSPLIT) {
       switch (p.act) {
         case WD_ACT_RELU: EpiCsplitWalk<0, TM, TN, WD_ACT_RELU>::run(p, ev, mw, nw, lane_e, acc, patch); break;
         case WD_ACT_SILU: EpiCsplitWalk<0, TM, TN, WD_ACT_SILU>::run(p, ev, mw, nw, lane_e, acc, patch); break;
@@ -664,6 +668,12 @@ int wd_launch_p8(const WdConvGemm& p, const void* w, float unscale, bool csplit,
     return WD_ERR_UNSUPPORTED;                                     // DMA row groups of 8 are clamped as a whole
   if (csplit) {
     if (p.res || p.n % 8 || p.ldc % 8 || (p.bias && !wd_aligned16(p.bias)) || !wd_aligned16(p.c)) return WD_ERR_BAD_ARG;
+#ifdef WD_DEBUG_ABLATIONS       // the direct hi/lo epilogue (no LDS transpose): measured 1.5 - 3 x slower, profiles/r05_csplit_direct.txt; ablation builds only
+    const char* e = getenv("WEDETECT_CSPLIT_DIRECT");
+    if (e && e[0] == '1' && (p.act == WD_ACT_GELU || p.act == WD_ACT_NONE))
+      return persist ? launch_p8<SVAR_CSPLIT | P8VAR_DIRECT, 0, true>(p, w, unscale, st, ws, ws_floats)
+                     : launch_p8<SVAR_CSPLIT | P8VAR_DIRECT>(p, w, unscale, st);
+#endif
     return persist ? launch_p8<SVAR_CSPLIT, 0, true>(p, w, unscale, st, ws, ws_floats) : launch_p8<SVAR_CSPLIT>(p, w, unscale, st);
   }
   return persist ? launch_p8<0, 0, true>(p, w, unscale, st, ws, ws_floats) : launch_p8<0>(p, w, unscale, st);
