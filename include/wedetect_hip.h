@@ -109,6 +109,13 @@ typedef struct WdConvGemm {
    * it is split (the fp32 copy c2 is not).  The CONSUMER of a scaled operand divides it out by passing
    * w_unscale / scale — exact, powers of two.  wedetect_amd.engine.ImageTower.calibrate() chooses them. */
   float a_scale, c_split_scale;
+  /* LayerNorm FOLDED into the GEMM (ABI 13; fp16x3, WD_SPLIT_A | WD_SPLIT_C layers only; both NULL = off).  The operand a is the
+   * raw pre-norm tensor d (wd_dwconv7_stats), the weights carry the LayerNorm's gamma (W' = W * gamma), and the epilogue
+   * computes  act( rstd_m * (acc - mean_m * ln_u[n]) + bias[n] )  with  ln_stats[m] = (mean_m, rstd_m)  from
+   * wd_ln_stats_finalize,  ln_u[n] = sum_k W'[n][k],  bias[n] = (W beta + b)[n]  — which is  W LN(d) + b  term for term
+   * (mm_backbone.py:114-117) without the normalised tensor ever being written. */
+  const float* ln_stats;       /* [m][2] */
+  const float* ln_u;           /* [n], 16-byte aligned */
 } WdConvGemm;
 
 int wd_conv_gemm(const WdConvGemm* p, void* stream);
@@ -251,6 +258,13 @@ int wd_letterbox_u8(const uint8_t* src, int32_t h, int32_t w, const int32_t* bou
  * dim % 32 == 0 and 16-byte aligned scale / bias the 256 x 256 kernel runs (ABI 13).
  * range_flag (may be NULL; ABI 13): set to 1 (sticky) when an accumulator is inf / NaN, i.e. an operand left
  * the fp16 range — the caller repeats the step with wd_retrieval_max (fp32). */
+/* LayerNorm fold (ABI 13), see WdConvGemm.ln_stats: the depthwise 7x7 of a ConvNeXt block writing its output as fp16 hi/lo groups
+ * of d * scale plus per-(pixel, 32-channel block) statistics part [c/32][batch*h*w][2]; the finalize pass -> stats [rows][2] =
+ * (mean, 1 / sqrt(var + eps)) over all c channels.  c % 32 == 0.  Replaces mm_backbone.py:113-116 (dwconv, permute, norm). */
+int wd_dwconv7_stats(const float* x, const float* w7, const float* bias, void* y_split, float* part, int32_t batch, int32_t h,
+                     int32_t w, int32_t c, float scale, void* stream);
+int wd_ln_stats_finalize(const float* part, float* stats, int64_t rows, int32_t c, float eps, void* stream);
+
 int wd_retrieval_max_split(const void* e_split, const void* t_split, float t_unscale, const float* scale,
                            const float* bias, const int32_t* count, float* out, int32_t n_img, int32_t rows_per_img,
                            int32_t n_cls, int32_t dim, uint32_t* range_flag, void* stream);

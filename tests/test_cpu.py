@@ -542,7 +542,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     from wedetect_amd import lib as L
     assert set(L.EXPORTS) == declared
     assert L.LIB.wd_abi_version() == L.ABI_VERSION
-    assert ctypes.sizeof(L.ConvGemm) == L.LIB.wd_sizeof_conv_gemm() == 200
+    assert ctypes.sizeof(L.ConvGemm) == L.LIB.wd_sizeof_conv_gemm() == 216
     assert L.topk_capacity(30000) == 32768 and L.topk_workspace_bytes(2, 8400 * 80, 30000) > 2 * 32768 * 8
     assert L.gemm_config(1000, 80, 768).startswith("64x80") and L.gemm_config(100000, 2048, 512).startswith("128x128") and L.gemm_config(1000, 2048, 512).startswith("64x128")
 

@@ -518,3 +518,32 @@ def test_fused_stem_matches_the_three_launch_path(arch, b, hw, monkeypatch, prec
         assert torch.equal(c0, t_new.x[0]) and torch.equal(e0, e1) and torch.equal(b0, b1)
     else:
         assert float((e0 - e1).abs().max()) < 2e-5 and float((b0 - b1).abs().max()) < 2e-4
+
+
+@pytest.mark.parametrize("arch,b,hw", [("base", 2, 320), ("large", 1, 192)])
+def test_layernorm_fold_tower_matches_the_layernorm_kernel_tower(arch, b, hw):
+    """ImageTower with the block LayerNorms of the two-launch stages folded into pwconv1 ($WEDETECT_LN_FOLD=1) against the tower
+    that runs the LayerNorm kernel ($WEDETECT_LN_FOLD=0): another rounding order in 30 layers, the same network — embeddings, boxes and
+    scores within 5e-5 / 1e-3 px / 1e-5, with and without calibrated split scales; fp32 mode ignores the switch."""
+    if PRECISION["value"] != "fp16x3":
+        pytest.skip("the fold exists in the fp16x3 C-split epilogue")
+    _, t0, imgs = build(arch, b, hw, num_prompts=48)
+    _, t1, _ = build(arch, b, hw, num_prompts=48)
+    t0.ln_fold, t1.ln_fold = False, True
+    assert any(t1._fold_ok(i, True) for i in range(4)) and not any(t0._fold_ok(i, True) for i in range(4))
+    x = torch.from_numpy(imgs).cuda()
+    for calibrate in (False, True):
+        if calibrate:
+            t0.calibrate(x)
+            t1.calibrate(x)
+            assert any(k.endswith(".dw") for k in t1.sscale) or all(v == 1.0 for v in t1.sscale.values())
+        outs = []
+        for t in (t0, t1):
+            e, bx = t.features(x)
+            s = t.similarity(t.P["prompts"], normalize=False)
+            torch.cuda.synchronize()
+            assert not bool(t.range_flags.any())
+            outs.append((e.clone(), bx.clone(), s.clone()))
+        assert_close(f"fold embeddings (calibrated={calibrate})", outs[1][0], outs[0][0], 5e-5, 1e-5)
+        assert_close(f"fold boxes (calibrated={calibrate})", outs[1][1], outs[0][1], 1e-3)
+        assert_close(f"fold scores (calibrated={calibrate})", outs[1][2], outs[0][2], 1e-5)

@@ -774,3 +774,62 @@ def test_fused_mlp_refuses_other_shapes_and_flags_overflow():
     L.mlp_fused(xs, m, c, h, ws1, b1big, ws2, b2, x, range_flag=flag)
     torch.cuda.synchronize()
     assert int(flag.item()) == 1
+
+
+@pytest.mark.parametrize("b,h,w,c", [(2, 40, 40, 512), (1, 20, 20, 1024), (3, 13, 21, 256), (1, 9, 7, 64)])
+def test_layernorm_folded_into_the_gemm(b, h, w, c):
+    """Round 5: dwconv -> LayerNorm -> pwconv1 (mm_backbone.py:113-118) with the LayerNorm FOLDED into the GEMM.  (a)
+    wd_dwconv7_stats writes the depthwise output bit-identically to wd_dwconv7 followed by a split, and its per-block partials
+    finalise to the row mean / rstd of an fp64 LayerNorm; (b) the GEMM on W' = W gamma with the (mean, rstd, u, v) epilogue equals
+    fp64 GELU(W LN(d) + b) to the accuracy of the fp16x3 kernels, and the LayerNorm-kernel path to 2e-5 of the output's scale."""
+    from wedetect_amd import lib as L
+    g = torch.Generator(device="cuda").manual_seed(c + h)
+    rows, n = b * h * w, 4 * c
+    x = torch.randn(rows, c, device="cuda", generator=g) * 2.0 + 0.7
+    w7 = torch.randn(49, c, device="cuda", generator=g) * 0.15
+    bdw = torch.randn(c, device="cuda", generator=g) * 0.1
+    gam = torch.rand(c, device="cuda", generator=g) + 0.5
+    bet = torch.randn(c, device="cuda", generator=g) * 0.1
+    w1 = torch.randn(n, c, device="cuda", generator=g) * c ** -0.5
+    b1 = torch.randn(n, device="cuda", generator=g) * 0.1
+    # ---- (a) the depthwise kernel with statistics
+    d = torch.empty_like(x)
+    L.dwconv7(x, w7, bdw, d, b, h, w, c)
+    ds = torch.empty_like(x)
+    part = torch.empty(c // 32, rows, 2, device="cuda")
+    L.dwconv7_stats(x, w7, bdw, ds, part, b, h, w, c, scale=4.0)
+    assert torch.equal(ds.view(torch.int32), _to_split(d * 4.0).view(torch.int32)), "split depthwise output differs from dwconv + split"
+    stats = torch.empty(rows, 2, device="cuda")
+    L.ln_stats_finalize(part, stats, rows, c)
+    d64 = d.double()
+    mu, var = d64.mean(dim=1), d64.var(dim=1, unbiased=False)
+    assert_close("row mean", stats[:, 0], mu, 1e-6, 2e-6)
+    assert_close("row rstd", stats[:, 1], 1.0 / torch.sqrt(var + 1e-6), 0, 3e-6)
+    # ---- (b) the folded GEMM
+    w1g = (w1.double() * gam.double()[None, :]).float()
+    u = w1g.double().sum(dim=1).float()
+    v = (w1.double() @ bet.double() + b1.double()).float()
+    ws = L.split_weights(w1g)
+    ws = (ws[0], ws[1] / 4.0)                                         # the operand carries d * 4
+    got = torch.empty(rows, n, device="cuda")
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    L.conv_gemm(ds, None, v, got, w_split=ws, batch=1, hin=1, win=rows, cin=c, lda=c, n=n, ldc=n, act=L.ACT_GELU,
+                split_flags=L.SPLIT_A | L.SPLIT_C, ln_stats=stats, ln_u=u, range_flag=flag)
+    y64 = torch.nn.functional.layer_norm(d64, (c,), gam.double(), bet.double(), 1e-6)
+    ref = torch.nn.functional.gelu(y64 @ w1.double().T + b1.double())
+    out = _from_split(got)
+    scale = float(ref.abs().max())
+    assert int(flag.item()) == 0
+    assert_close("folded LayerNorm + pwconv1 + GELU vs fp64", out, ref, 1e-5 * scale)
+    # the path it replaces: LayerNorm kernel (split output) -> GEMM
+    ys = torch.empty_like(x)
+    L.layernorm_rows(d, ys, gam, bet, rows, c, split=True)
+    old = torch.empty(rows, n, device="cuda")
+    L.conv_gemm(ys, None, b1, old, w_split=L.split_weights(w1), batch=1, hin=1, win=rows, cin=c, lda=c, n=n, ldc=n, act=L.ACT_GELU,
+                split_flags=L.SPLIT_A | L.SPLIT_C)
+    assert_close("folded vs LayerNorm-kernel path", out, _from_split(old), 2e-5 * scale)
+    # refusals: the fold exists in the plain pre-split C-split epilogue only
+    with pytest.raises(L.WedetectHipError):
+        L.conv_gemm(ds, None, v, got, w_split=ws, batch=1, hin=1, win=rows, cin=c, lda=c, n=n, ldc=n, split_flags=L.SPLIT_A, ln_stats=stats, ln_u=u)
+    with pytest.raises(L.WedetectHipError):
+        L.conv_gemm(d, w1g, v, got, batch=1, hin=1, win=rows, cin=c, lda=c, n=n, ldc=n, ln_stats=stats, ln_u=u)

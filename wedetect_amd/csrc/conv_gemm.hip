@@ -495,6 +495,7 @@ extern "C" int wd_conv_gemm(const WdConvGemm* pp, void* stream) {
   if (!pp) return WD_ERR_BAD_ARG;
   const WdConvGemm& p = *pp;
   if (!p.a || !p.w || !p.c) return WD_ERR_BAD_ARG;
+  if (p.ln_stats || p.ln_u) return WD_ERR_UNSUPPORTED;              // the LayerNorm fold exists in the fp16x3 C-split epilogue only
   if (p.m <= 0 || p.n <= 0 || p.k <= 0) return WD_ERR_BAD_ARG;
   if (p.cin <= 0 || p.cin % 4 || p.lda % 4 || p.lda < p.cin) return WD_ERR_BAD_ARG;
   if (p.kh <= 0 || p.kw <= 0 || p.stride <= 0 || p.pad < 0) return WD_ERR_BAD_ARG;

@@ -119,9 +119,14 @@ __device__ __forceinline__ void dt_lane_map(int t, int& wg, int& oy) {
   oy = ((t >> 4) & 1) + 2 * (t >> 6);
 }
 
+// STATS (round 5, the LayerNorm fold of wd_dwconv7_stats): the output is written as fp16 hi/lo groups of d * scale (the operand
+// format of the fp16x3 GEMMs) and, per pixel and 32-channel block, the block's mean and centred sum of squares go to
+// part[pixel][block] — the LayerNorm that follows is then applied INSIDE the consuming GEMM's epilogue.
+template <bool STATS>
 __global__ void __launch_bounds__(256) dwconv7_tiled_kernel(const float* __restrict__ x, const float* __restrict__ w7,
                                                             const float* __restrict__ bias, float* __restrict__ y,
-                                                            int h, int w, int c, int tiles_h, int tiles_w) {
+                                                            int h, int w, int c, int tiles_h, int tiles_w,
+                                                            float* __restrict__ part, float scale, long long rows_total) {
   __shared__ __attribute__((aligned(16))) float lds[DT_LDS_FLOATS];
   float* tin = lds;
   float* tw = lds + DT_IH * DT_IWP * DT_CP;
@@ -188,6 +193,53 @@ __global__ void __launch_bounds__(256) dwconv7_tiled_kernel(const float* __restr
     }
   }
   const int ho = h0 + oy;
+  if (STATS) {
+#pragma clang fp contract(off)
+    // every lane takes part in the exchanges (pixels past the map's edge carry bias-only values and are not written)
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    // sums over the 8 lanes of a pixel (q = t & 7) by DPP — quad_perm xor 1, xor 2, then row_half_mirror (lane i <- lane 7 - i: the
+    // other quad's total) — not by __shfl_xor: that is ds_bpermute, i.e. the LDS pipe this kernel is already bound by
+    auto sum8 = [](float v) -> float {
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));
+      return v;
+    };
+    const int g8 = cb * 4 + (q >> 1);                                // 8-channel group of this lane pair
+    const bool odd = q & 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float sm = sum8((acc[j][0] + acc[j][1]) + (acc[j][2] + acc[j][3]));
+      const float mean = sm * 0.03125f;                              // the block's 32 channels
+      const f32x4 dv = acc[j] - mean;
+      const float m2 = sum8((dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3]));
+      const int wo = w0 + wg * 4 + j;
+      const bool ok = ho < h && wo < w;
+      const long long pix = ok ? (b * h + ho) * (long long)w + wo : 0;
+      const f32x4 o = acc[j] * scale;                               // a power of two: exact
+      const f32x2 a2 = {o[0], o[1]}, b2 = {o[2], o[3]};
+      const h2 ha = __builtin_convertvector(a2, h2), hb = __builtin_convertvector(b2, h2);
+      const h2 la = __builtin_convertvector(a2 - __builtin_convertvector(ha, f32x2), h2);
+      const h2 lb = __builtin_convertvector(b2 - __builtin_convertvector(hb, f32x2), h2);
+      const unsigned hi0 = __builtin_bit_cast(unsigned, ha), hi1 = __builtin_bit_cast(unsigned, hb);
+      const unsigned lo0 = __builtin_bit_cast(unsigned, la), lo1 = __builtin_bit_cast(unsigned, lb);
+      // lanes q and q ^ 1 hold the two halves of an 8-channel group: the even lane ends with [hi x 8], the odd one with [lo x 8] —
+      // ONE 16-byte store per lane instead of two 8-byte ones.  Each lane gives away the half it does not store.
+      const unsigned g0 = odd ? hi0 : lo0, g1 = odd ? hi1 : lo1;
+      const unsigned r0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)g0, 0xB1, 0xF, 0xF, false);
+      const unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)g1, 0xB1, 0xF, 0xF, false);
+      typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+      const u32x4_ out = odd ? u32x4_{r0, r1, lo0, lo1} : u32x4_{hi0, hi1, r0, r1};
+      if (ok) {
+        // block-major [block][pixel]: a workgroup writes whole 128-byte runs (16 pixels of a tile row); pixel-major put the 16
+        // blocks of a pixel — written by 16 workgroups on different XCDs — into ONE cache line
+        if (q == 0) *reinterpret_cast<f32x2*>(part + ((long long)cb * rows_total + pix) * 2) = f32x2{mean, m2};
+        *reinterpret_cast<u32x4_*>(reinterpret_cast<unsigned char*>(y + pix * c) + (size_t)g8 * 32 + (odd ? 16 : 0)) = out;
+      }
+    }
+    return;
+  }
   if (ho < h) {
     float* yr = y + ((b * h + ho) * (long long)w) * c + c0 + q * 4;
 #pragma unroll
@@ -196,6 +248,36 @@ __global__ void __launch_bounds__(256) dwconv7_tiled_kernel(const float* __restr
       if (wo < w) *reinterpret_cast<f32x4*>(yr + (long long)wo * c) = acc[j];
     }
   }
+}
+
+// LayerNorm statistics of a row from its per-block partials (wd_dwconv7_stats): the blocks' (mean, centred sum of squares) are
+// merged one after the other with the pairwise update of Chan et al. (as accurate as the two-pass form, one pass over the
+// partials), in index order: deterministic.  stats[row] = (mean, 1 / sqrt(M2 / c + eps)).  The partials are fetched eight at a
+// time before they are merged (a rolled loop of dependent 8-byte loads ran 10 us per launch: one load latency per block).
+__global__ void __launch_bounds__(256) ln_stats_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats,
+                                                                long long rows, int nblk, float eps) {
+#pragma clang fp contract(off)
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2* pr = reinterpret_cast<const f32x2*>(part) + r;       // part [block][row][2]
+  float mean = 0.f, m2 = 0.f;
+  for (int k0 = 0; k0 < nblk; k0 += 8) {
+    f32x2 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = k0 + i < nblk ? pr[(long long)(k0 + i) * rows] : f32x2{0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (k0 + i < nblk) {                                           // merge block k (32 values) into the first k blocks (32 k values)
+        const float k = (float)(k0 + i);
+        const float delta = v[i][0] - mean;
+        mean = mean + delta / (k + 1.0f);
+        m2 = m2 + (v[i][1] + delta * delta * (32.0f * k / (k + 1.0f)));
+      }
+    }
+  }
+  const float var = m2 / (float)(32 * nblk);
+  *reinterpret_cast<f32x2*>(stats + 2 * r) = f32x2{mean, 1.0f / sqrtf(var + eps)};
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1093,8 +1175,8 @@ static int launch_dwconv7(const float* x, const float* w7, const float* bias, fl
     const int th = (h + DT_TH - 1) / DT_TH, tw = (w + DT_TW - 1) / DT_TW;
     const long long nblk = (long long)batch * th * tw * (c / DT_CB);
     if (nblk > 0x7fffffffLL) return WD_ERR_BAD_ARG;
-    hipLaunchKernelGGL(dwconv7_tiled_kernel, dim3((unsigned)nblk), dim3(256), 0, static_cast<hipStream_t>(stream), x,
-                       w7, bias, y, h, w, c, th, tw);
+    hipLaunchKernelGGL(dwconv7_tiled_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                       w7, bias, y, h, w, c, th, tw, static_cast<float*>(nullptr), 1.0f, 0ll);
     return wd_launch_status();
   }
   const int nstrip = (w + DW_TW - 1) / DW_TW;
@@ -1113,6 +1195,34 @@ extern "C" int wd_dwconv7(const float* x, const float* w7, const float* bias, fl
 extern "C" int wd_dwconv7_variant(const float* x, const float* w7, const float* bias, float* y, int32_t batch, int32_t h,
                                   int32_t w, int32_t c, int32_t variant, void* stream) {
   return launch_dwconv7(x, w7, bias, y, batch, h, w, c, variant, stream);
+}
+
+// wd_dwconv7_stats (ABI 13): depthwise 7x7 + bias for a block whose LayerNorm is FOLDED into the following GEMM
+// (mm_backbone.py:113-117: dwconv -> norm -> pwconv1).  y receives d * scale as fp16 hi/lo groups (the pre-split operand format),
+// part [c / 32][batch*h*w][2] the per-block (mean, centred sum of squares) of d; wd_ln_stats_finalize turns them into the
+// per-row (mean, rstd) the GEMM epilogue applies (WdConvGemm.ln_stats / ln_u).
+extern "C" int wd_dwconv7_stats(const float* x, const float* w7, const float* bias, void* y_split, float* part, int32_t batch,
+                                int32_t h, int32_t w, int32_t c, float scale, void* stream) {
+  if (!x || !w7 || !bias || !y_split || !part || x == y_split) return WD_ERR_BAD_ARG;
+  if (batch <= 0 || h <= 0 || w <= 0 || c <= 0 || c % DT_CB || !(scale > 0.f)) return WD_ERR_BAD_ARG;
+  if (!wd_aligned16(x) || !wd_aligned16(w7) || !wd_aligned16(bias) || !wd_aligned16(y_split) || (reinterpret_cast<uintptr_t>(part) & 7u))
+    return WD_ERR_BAD_ARG;
+  const int th = (h + DT_TH - 1) / DT_TH, tw = (w + DT_TW - 1) / DT_TW;
+  const long long nblk = (long long)batch * th * tw * (c / DT_CB);
+  if (nblk > 0x7fffffffLL) return WD_ERR_BAD_ARG;
+  hipLaunchKernelGGL(dwconv7_tiled_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, static_cast<hipStream_t>(stream), x, w7, bias,
+                     static_cast<float*>(y_split), h, w, c, th, tw, part, scale, (long long)batch * h * w);
+  return wd_launch_status();
+}
+
+extern "C" int wd_ln_stats_finalize(const float* part, float* stats, int64_t rows, int32_t c, float eps, void* stream) {
+  if (!part || !stats || rows <= 0 || c <= 0 || c % DT_CB || (reinterpret_cast<uintptr_t>(part) & 7u) ||
+      (reinterpret_cast<uintptr_t>(stats) & 7u)) return WD_ERR_BAD_ARG;
+  const long long grid = (rows + 255) / 256;
+  if (grid > 0x7fffffffLL) return WD_ERR_BAD_ARG;
+  hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((unsigned)grid), dim3(256), 0, static_cast<hipStream_t>(stream), part, stats,
+                     (long long)rows, c / DT_CB, eps);
+  return wd_launch_status();
 }
 
 // wd_dwconv7_ln: depthwise 7x7 + bias, then LayerNorm over the channels of every pixel, one kernel (c % 32 == 0).

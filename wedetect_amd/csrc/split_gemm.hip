@@ -213,6 +213,13 @@ static int conv_gemm_split_impl(const WdConvGemm* pp, const void* w_split, float
   const bool plain = p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0;
   const bool special = p.out_mode != WD_OUT_ROWS || p.c_batch_stride > 0 || p.seg_rows > 0 || p.sigmoid ||
                        p.out_scale != 1.0f || p.out_bias != 0.0f;
+  if (p.ln_stats || p.ln_u) {
+    // LayerNorm fold: only the epilogue of the plain pre-split C-split GEMM kernels applies it (epi_lds_tile_csplit)
+    if (!p.ln_stats || !p.ln_u || flags != (WD_SPLIT_A | WD_SPLIT_C) || !plain || special || p.res || p.c2 || force_splits > 1 ||
+        !wd_aligned16(p.ln_u) || (reinterpret_cast<uintptr_t>(p.ln_stats) & 7u))
+      return WD_ERR_BAD_ARG;
+    if (cfg == 70 || cfg == 73 || cfg == 74 || cfg == 75 || cfg == 76 || (cfg >= 700 && cfg < 716)) return WD_ERR_UNSUPPORTED;
+  }
   if (flags & WD_SPLIT_A) {
     // Pre-split activations.  Plain row-output 1x1 layers keep the GEMM kernels tuned for the ConvNeXt MLPs (below);
     // everything else — k x k / strided convolutions, scatter / batch-stride outputs, residual or dual-format outputs of a

@@ -244,10 +244,20 @@ __device__ __forceinline__ void epi_lds_tile_csplit(const WdConvGemm& p, const E
         __builtin_nontemporal_store(r1, reinterpret_cast<u32x4*>(cq + 16));
         continue;
       }
+      if (p.ln_stats) {                                            // LayerNorm folded into this GEMM (WdConvGemm.ln_stats): wave-uniform
+        const f32x2 st = *reinterpret_cast<const f32x2*>(p.ln_stats + 2 * (size_t)m);
+        const f32x4 u0 = *reinterpret_cast<const f32x4*>(p.ln_u + n), u1 = *reinterpret_cast<const f32x4*>(p.ln_u + n + 4);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        o0[r] = sact<ACT>(fmaf(v0[r], ev.unscale, b0[r]));
-        o1[r] = sact<ACT>(fmaf(v1[r], ev.unscale, b1[r]));
+        for (int r = 0; r < 4; ++r) {
+          o0[r] = sact<ACT>(fmaf(st[1], fmaf(-st[0], u0[r], v0[r] * ev.unscale), b0[r]));
+          o1[r] = sact<ACT>(fmaf(st[1], fmaf(-st[0], u1[r], v1[r] * ev.unscale), b1[r]));
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          o0[r] = sact<ACT>(fmaf(v0[r], ev.unscale, b0[r]));
+          o1[r] = sact<ACT>(fmaf(v1[r], ev.unscale, b1[r]));
+        }
       }
       u32x2 h0, l0, h1, l1;
       // c_split_scale: a power of two (exact); 0 = none.  Always multiplied — x * 1.0f is x, bit for bit, so the unscaled path

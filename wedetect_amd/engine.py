@@ -119,6 +119,15 @@ class ImageTower:
         # round 5: the same for 256 / 384 / 512 channels (dwconv7_ln_wide_kernel: the channel blocks dealt to one or two thread
         # groups of a workgroup, pre-norm values in registers, bit-identical to the pair); comma-separated widths, "" = none
         self.fuse_dwln_wide = tuple(int(v) for v in os.environ.get("WEDETECT_FUSE_DWLN_WIDE", "").split(",") if v.strip())
+        # round 5: the block LayerNorm of the stages that run pwconv1 / pwconv2 as two launches FOLDED into pwconv1 (no LayerNorm
+        # kernel, the normalised tensor is never written): wd_dwconv7_stats writes the raw depthwise output d as fp16 hi/lo groups
+        # plus per-(pixel, 32-channel block) statistics, wd_ln_stats_finalize turns them into (mean, rstd) per row, and the GEMM's
+        # epilogue computes rstd (W' d - mean u) + v with W' = W gamma, u = W' 1, v = W beta + b  ==  W LN(d) + b.  Not
+        # bit-identical to the LayerNorm kernel (the centring happens after the contraction, in fp32; within 5e-5 / 1e-5 of it on
+        # embeddings / scores, every golden and index-parity test green with it): $WEDETECT_LN_FOLD, default on — 30 LayerNorm
+        # launches and 6 GB of HBM traffic per Base step less, +1.2 % (profiles/r05_ln_fold.txt).
+        self.ln_fold = os.environ.get("WEDETECT_LN_FOLD", "1") == "1"
+        self.ln_part = self.ln_stats = None
         self.overflowed = False
         # sticky range flag of the fp16x3 GEMMs (WdConvGemm.range_flag): set by a launch whose accumulators are inf / NaN
         self.range_flags = torch.zeros(2, dtype=torch.int32, device=torch.device(device))
@@ -297,6 +306,26 @@ class ImageTower:
                 else:
                     self._record(c_key, c[..., : n // 4] if kw.get("out_mode", 0) == L.OUT_DECONV2X2 else c[..., :n])
 
+    def _fold_weights(self, q: str) -> None:
+        """W' = W1 gamma, u = W' 1, v = W1 beta + b1 of one block, in float64 on the device, once (shared through the packed set)."""
+        if q + "w1g" in self.P.t:
+            return
+        w1, g = self.P[q + "w1"].double(), self.P[q + "ln_w"].double()
+        w1g = (w1 * g[None, :]).float()
+        self.P.t[q + "w1g"] = w1g.contiguous()
+        self.P.t[q + "u"] = w1g.double().sum(dim=1).float().contiguous()         # of the fp32 W' the GEMM multiplies
+        self.P.t[q + "v"] = (w1 @ self.P[q + "ln_b"].double() + self.P[q + "b1"].double()).float().contiguous()
+
+    def _fold_ok(self, i: int, pre: bool) -> bool:
+        c = self.a.dims[i]
+        if not (self.ln_fold and pre and self.precision == "fp16x3" and c % 32 == 0):
+            return False
+        if self.fuse_dwln == "1" or (self.fuse_dwln == "auto" and (c <= 128 or c in self.fuse_dwln_wide)):
+            return False                        # dwconv + LayerNorm run as one kernel there
+        if (self.fuse_mlp and L.mlp_fused_supported(self.M[i], c, 4 * c)) or (c in self.fuse_mlp_wide and L.mlp_wide_supported(self.M[i], c, 4 * c)):
+            return False                        # the one-kernel block MLPs take LayerNorm rows
+        return True
+
     def _mlp_fused(self, q: str, i: int, wide: bool = False) -> None:
         """One ConvNeXt block MLP as a single launch: the 4c hidden activation never leaves the CU (wd_mlp_fused_split for the
         128-channel stage, hidden chunk in registers; ``wide``: wd_mlp_fused_wide for 256 / 512 channels, hidden chunks through
@@ -454,11 +483,30 @@ class ImageTower:
                                stride=2, pad=0, n=c, ldc=c, split_flags=fa, a_key=f"down{i}.ln" if pre else None)
             for j in range(a.depths[i]):
                 q = f"s{i}.{j}."
+                if self._fold_ok(i, pre):
+                    # LayerNorm folded into pwconv1: dwconv -> (split d, block statistics) -> row statistics -> GEMM
+                    if self.ln_stats is None:
+                        rows = max(self.M[k] for k in range(4))
+                        blk = max(self.M[k] * (a.dims[k] // 32) for k in range(4) if a.dims[k] % 32 == 0)
+                        self.ln_part = torch.empty(2 * blk, dtype=torch.float32, device=self.dev)
+                        self.ln_stats = torch.empty(2 * rows, dtype=torch.float32, device=self.dev)
+                    self._fold_weights(q)
+                    L.dwconv7_stats(self.x[i], self.P[q + "dw_w"], self.P[q + "dw_b"], self.tmp, self.ln_part, B, h, w, c,
+                                    scale=self.sscale.get(q + "dw", 1.0))
+                    L.ln_stats_finalize(self.ln_part, self.ln_stats, self.M[i], c)
+                    self._conv(self.tmp, q + "w1g", q + "v", self.hid, hin=h, win=w, cin=c, lda=c, n=4 * c, ldc=4 * c,
+                               act=L.ACT_GELU, split_flags=L.SPLIT_A | L.SPLIT_C, a_key=q + "dw", c_key=q + "hid",
+                               ln_stats=self.ln_stats, ln_u=self.P[q + "u"])
+                    self._conv(self.hid, q + "w2", q + "b2", self.x[i], hin=h, win=w, cin=4 * c, lda=4 * c, n=c, ldc=c,
+                               res=self.x[i], ldres=c, split_flags=fa, a_key=q + "hid")
+                    continue
                 g_, b_ = self._ln_params(q + "ln_w", q + "ln_b", q + "ln" if pre else None)
                 if c % 32 == 0 and (self.fuse_dwln == "1" or (self.fuse_dwln == "auto" and (c <= 128 or c in self.fuse_dwln_wide))):   # bit-identical to the pair
                     L.dwconv7_ln(self.x[i], self.P[q + "dw_w"], self.P[q + "dw_b"], self.tmp, g_, b_, B, h, w, c, split=pre)
                 else:
                     L.dwconv7(self.x[i], self.P[q + "dw_w"], self.P[q + "dw_b"], self.tmp, B, h, w, c)
+                    if self._calib is not None and self.ln_fold:
+                        self._record(q + "dw", self.tmp[: self.M[i] * c])      # the folded path splits the pre-norm tensor itself
                     L.layernorm_rows(self.tmp, self.tmp, g_, b_, self.M[i], c, split=pre)
                 self._record(q + "ln", self.tmp[: self.M[i] * c])
                 if pre and self.fuse_mlp and L.mlp_fused_supported(self.M[i], c, 4 * c):

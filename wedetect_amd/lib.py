@@ -32,7 +32,7 @@ EXPORTS = (
     "wd_abi_version", "wd_strerror", "wd_sizeof_conv_gemm", "wd_conv_gemm", "wd_conv_gemm_tuned", "wd_conv_gemm_config", "wd_stem_patchify", "wd_dwconv7", "wd_dwconv7_variant",
     "wd_layernorm_rows", "wd_l2norm_rows", "wd_dfl_decode", "wd_topk_workspace_bytes", "wd_topk_capacity",
     "wd_topk_candidates", "wd_nms_workspace_bytes", "wd_nms_gather", "wd_retrieval_max",
-    "wd_split_weights_bytes", "wd_split_weights", "wd_split_weights_padded", "wd_conv_gemm_split", "wd_conv_gemm_split_ws", "wd_conv_gemm_split_config", "wd_layernorm_rows_split", "wd_layernorm_rows_split_s2d", "wd_letterbox_u8", "wd_retrieval_max_split", "wd_text_embed", "wd_attention_small", "wd_recall_scratch_floats", "wd_recall_match",
+    "wd_split_weights_bytes", "wd_split_weights", "wd_split_weights_padded", "wd_dwconv7_stats", "wd_ln_stats_finalize", "wd_conv_gemm_split", "wd_conv_gemm_split_ws", "wd_conv_gemm_split_config", "wd_layernorm_rows_split", "wd_layernorm_rows_split_s2d", "wd_letterbox_u8", "wd_retrieval_max_split", "wd_text_embed", "wd_attention_small", "wd_recall_scratch_floats", "wd_recall_match",
     "wd_max_sigmoid_attn", "wd_adaptive_maxpool_nhwc", "wd_cross_attention_small", "wd_time_next_gemm",
     "wd_cv_resize_paste_u8", "wd_chw_to_hwc_u8", "wd_p8_workspace_bytes", "wd_dwconv7_ln", "wd_probe_lds_dma", "wd_probe_issue", "wd_mlp_fused_split", "wd_mlp_fused_wide", "wd_stem_fused",
 )
@@ -64,6 +64,7 @@ class ConvGemm(C.Structure):
         ("range_flag", C.c_void_p),
         ("c2", C.c_void_p), ("ldc2", C.c_int32),
         ("a_scale", C.c_float), ("c_split_scale", C.c_float),
+        ("ln_stats", C.c_void_p), ("ln_u", C.c_void_p),
     ]
 
 
@@ -103,6 +104,8 @@ def _load():
     lib.wd_split_weights_bytes.argtypes = [i32, i32]
     lib.wd_split_weights.argtypes = [vp, i32, i32, f32, vp, vp]
     lib.wd_split_weights_padded.argtypes = [vp, i32, i32, f32, vp, vp]
+    lib.wd_dwconv7_stats.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]
+    lib.wd_ln_stats_finalize.argtypes = [vp, vp, i64, i32, f32, vp]
     lib.wd_conv_gemm_split.argtypes = [C.POINTER(ConvGemm), vp, f32, i32, i32, vp]
     lib.wd_conv_gemm_split_ws.argtypes = [C.POINTER(ConvGemm), vp, f32, i32, i32, vp, i64, i32, vp]
     lib.wd_layernorm_rows_split.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, f32, vp]
@@ -165,7 +168,8 @@ def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
 def conv_gemm(a, w, bias, c, *, batch, hin, win, cin, lda, kh=1, kw=1, stride=1, pad=0, hout=None, wout=None,
               n, ldc, act=ACT_NONE, res=None, ldres=0, res_alpha=1.0, out_mode=OUT_ROWS,
               out_scale=1.0, out_bias=0.0, sigmoid=False, c_batch_stride=0, seg=None, tuned_cfg=None,
-              w_split=None, split_cfg=-1, split_flags=0, workspace=None, k_splits=0, range_flag=None, c2=None, ldc2=0, a_scale=1.0, c_split_scale=1.0) -> None:
+              w_split=None, split_cfg=-1, split_flags=0, workspace=None, k_splits=0, range_flag=None, c2=None, ldc2=0, a_scale=1.0, c_split_scale=1.0,
+              ln_stats=None, ln_u=None) -> None:
     """``seg`` = (seg_rows, seg_end0, seg_end1, (s0, s1, s2), (b0, b1, b2)) or None.
     ``w_split`` = (split weight buffer, unscale) from :func:`split_weights` selects the fp16x3 kernel;
     ``split_flags`` = SPLIT_A / SPLIT_C: activations / output stored as fp16 hi/lo groups; ``workspace`` (a device
@@ -176,7 +180,8 @@ def conv_gemm(a, w, bias, c, *, batch, hin, win, cin, lda, kh=1, kw=1, stride=1,
                  lda=lda, kh=kh, kw=kw, stride=stride, pad=pad, hout=hout, wout=wout,
                  m=batch * hout * wout, n=n, k=kh * kw * cin, ldc=ldc, ldres=ldres, act=act, out_mode=out_mode,
                  res_alpha=res_alpha, out_scale=out_scale, out_bias=out_bias, sigmoid=int(bool(sigmoid)),
-                 c_batch_stride=c_batch_stride, range_flag=_p(range_flag), c2=_p(c2), ldc2=ldc2, a_scale=a_scale, c_split_scale=c_split_scale)
+                 c_batch_stride=c_batch_stride, range_flag=_p(range_flag), c2=_p(c2), ldc2=ldc2, a_scale=a_scale, c_split_scale=c_split_scale,
+                 ln_stats=_p(ln_stats), ln_u=_p(ln_u))
     if seg is not None:
         p.seg_rows, p.seg_end0, p.seg_end1 = int(seg[0]), int(seg[1]), int(seg[2])
         p.seg_scale = (C.c_float * 3)(*[float(v) for v in seg[3]])
@@ -289,6 +294,17 @@ def dwconv7(x, w7, bias, y, batch, h, w, c, variant: int = 0) -> None:
         check(LIB.wd_dwconv7_variant(_p(x), _p(w7), _p(bias), _p(y), batch, h, w, c, variant, stream_ptr()), "wd_dwconv7_variant")
         return
     check(LIB.wd_dwconv7(_p(x), _p(w7), _p(bias), _p(y), batch, h, w, c, stream_ptr()), "wd_dwconv7")
+
+
+def dwconv7_stats(x, w7, bias, y_split, part, batch, h, w, c, scale=1.0) -> None:
+    """Depthwise 7 x 7 of a block whose LayerNorm is folded into the following GEMM: ``y_split`` <- d * scale as fp16 hi/lo groups,
+    ``part`` [c/32, batch*h*w, 2] <- per-block (mean, centred sum of squares) of d (wd_dwconv7_stats)."""
+    check(LIB.wd_dwconv7_stats(_p(x), _p(w7), _p(bias), _p(y_split), _p(part), batch, h, w, c, float(scale), stream_ptr()), "wd_dwconv7_stats")
+
+
+def ln_stats_finalize(part, stats, rows, c, eps=1e-6) -> None:
+    """``stats`` [rows, 2] <- (mean, 1 / sqrt(var + eps)) over all c channels from the per-block partials."""
+    check(LIB.wd_ln_stats_finalize(_p(part), _p(stats), rows, c, float(eps), stream_ptr()), "wd_ln_stats_finalize")
 
 
 def layernorm_rows(x, y, gamma, beta, rows, c, ldx=None, ldy=None, eps=1e-6, split=False) -> None:
