@@ -547,12 +547,15 @@ def retrieval_leg(L, n_img, regions, K, rank, world, steps, warmup, dist=None):
         out = class_sharded_retrieval(e, cnt, sc, bi, shard, K, score_fn=score_fn)
     sync()
     n_inst = min(steps, 2)
+    clock = ClockSampler(dev.index)
+    clock.start()
     t0 = time.perf_counter()
     for i in range(steps):
         rt.on = i >= steps - n_inst
         out = class_sharded_retrieval(e, cnt, sc, bi, shard, K, score_fn=score_fn)
     sync()
     dt = time.perf_counter() - t0
+    clk = clock.stop()
     rt.on = False
     rt.restore()
     rows = world * n_img * regions
@@ -584,6 +587,12 @@ def retrieval_leg(L, n_img, regions, K, rank, world, steps, warmup, dist=None):
                                      "regions + one sigmoid per (image, class)> (3 x v_mfma_f32_32x32x16_f16 per product)"
                                      if scorer.precision == "fp16x3" else "retrieval_max_kernel (fp32 MFMA 16x16x4)"),
                           "bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+                          **({"effective_mhz": clk["mean_mhz"], "effective_mhz_min_max": [clk["min_mhz"], clk["max_mhz"]],
+                              "peak_quoted_at_mhz": PEAK_CLOCK_MHZ,
+                              "frac_at_effective_clock": round(tf / peak * PEAK_CLOCK_MHZ / clk["mean_mhz"], 4),
+                              "clock_note": "shader clock from sysfs during the timed steps: this launch is power-limited "
+                                            "(SQ counters: profiles/r05_rocprofv3_retrieval_sq.txt); frac stays against the spec peak"}
+                             if clk else {"effective_mhz": None}),
                           "traffic": traffic, "traffic_provenance": traffic_src,
                           "timing": f"HIP events stamped by the kernel's own dispatch, last {n_inst} of the {steps} timed steps",
                           "avg_launch_us": round(us, 1), "launches_per_step": 1,
@@ -636,6 +645,17 @@ def launch_ranks(n: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def claim_stdout():
+    """fd 1 carries the ONE JSON line and nothing else.  RCCL writes its version banner and its warnings to stdout, from its own
+    threads: beside the line they break the driver's parse, and since the line is longer than PIPE_BUF a write of theirs can land
+    in the MIDDLE of it (seen on the one-rank RCCL run of the GPU suite).  So the process's fd 1 is pointed at stderr for everybody
+    and the line goes out through a private duplicate of the original."""
+    sys.stdout.flush()
+    keep = os.dup(1)
+    os.dup2(2, 1)
+    return os.fdopen(keep, "w")
+
+
 def main():
     args = parse()
     if args.gpus < 1:
@@ -648,6 +668,7 @@ def main():
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE {world}: the job must have exactly the asked number of ranks")
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    json_out = claim_stdout()
     # dry-run hooks for a single-GPU box: WEDETECT_BENCH_SHARE_GPU=1 puts every rank on device 0 and
     # WEDETECT_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device)
     if os.environ.get("WEDETECT_BENCH_SHARE_GPU") == "1":
@@ -660,10 +681,14 @@ def main():
     # a hung rank names itself instead of leaving seven others waiting in a collective forever
     dog = PhaseWatchdog(rank, float(os.environ.get("WEDETECT_BENCH_TIMEOUT", "300")))
     dog.phase("process-group initialisation")
-    if world > 1:
+    # WEDETECT_BENCH_FORCE_DIST=1: join a process group even as the only rank — the one way to run the step's collectives
+    # (region all-gathers, closing all-reduces, barriers) on RCCL itself on a one-GPU box (tests/test_gpu_entry.py)
+    dist_on = world > 1 or os.environ.get("WEDETECT_BENCH_FORCE_DIST") == "1"
+    if dist_on:
         import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         # the image exports NCCL_DEBUG=VERSION, which makes RCCL print a version banner on STDOUT
         # (next to the one JSON line this script owes the driver): keep warnings, drop the banner
         if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
@@ -712,12 +737,12 @@ def main():
                               "parallelism": f"image-shard x{world} + class-shard x{world}" if world > 1 else "one GPU, whole bank",
                               "precision": r["precision"], "fp16x3_range_guard_tripped": r["tripped"], "score_checksum": r["checksum"]},
                    "roofline": r["roofline"]}
-            if world > 1:
+            if dist_on:
                 out["ranks_seen"], out["collective_backend"] = ranks_seen, backend_name
             if world == 1 and not args.no_cpu_baseline:
                 dog.phase("cpu baseline")
                 out["cpu_baseline"] = retrieval_cpu_baseline(args.regions, K)
-            print(json.dumps(out), flush=True)
+            print(json.dumps(out), file=json_out, flush=True)
         if dist is not None:
             dog.phase("final barrier")
             dist.barrier()
@@ -736,7 +761,7 @@ def main():
     timer = GemmTimer(L)
     timer.install()
 
-    gatherer = RegionGatherer(timeout_s=dog.timeout_s) if world > 1 else None
+    gatherer = RegionGatherer(timeout_s=dog.timeout_s) if dist_on else None
     lvl_scale = torch.tensor(tower.lvl_logit_scale, dtype=torch.float32, device="cuda")
     lvl_bias = torch.tensor(tower.lvl_bias, dtype=torch.float32, device="cuda")
     image_ids = torch.arange(rank * B, (rank + 1) * B, dtype=torch.int64, device="cuda")
@@ -791,7 +816,7 @@ def main():
     for i in range(args.steps):
         if i == args.steps - n_inst:
             timer.mode = "time"
-        res = step(measure_stall=world > 1)
+        res = step(measure_stall=dist_on)
     sync()
     dt = time.perf_counter() - t0
     clk = clock.stop()
@@ -910,7 +935,7 @@ def main():
             out["other_configs"] = other
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.arch, S, K, args.cpu_runs)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     if dist is not None:
         dog.phase("final barrier")
         dist.barrier()

@@ -13,6 +13,7 @@ are index helpers over that file) and prints AR@100 / AR@300 over IoU 0.5:0.05:0
 
 ``--ann-path`` / ``--image-path`` default to the reference's ``ds_collections`` for coco / lvis / paco."""
 import argparse
+import datetime
 import itertools
 import json
 import os
@@ -86,11 +87,15 @@ def fast_eval_recall(dataset: str, annotations, proposals):
 def run(args):
     import torch.distributed as dist
     own_group = False
+    local = int(os.getenv("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
     if not dist.is_initialized():
-        dist.init_process_group(backend=args.backend, world_size=int(os.getenv("WORLD_SIZE", "1")), rank=int(os.getenv("RANK", "0")))
+        # the communicator is bound to this rank's device up front (a barrier otherwise guesses it from the current context)
+        kw = dict(device_id=torch.device("cuda", local)) if args.backend == "nccl" else {}
+        dist.init_process_group(backend=args.backend, world_size=int(os.getenv("WORLD_SIZE", "1")), rank=int(os.getenv("RANK", "0")),
+                                timeout=datetime.timedelta(seconds=float(os.getenv("WEDETECT_COLLECTIVE_TIMEOUT", "600"))), **kw)
         own_group = True
     rank, world = dist.get_rank(), dist.get_world_size()
-    torch.cuda.set_device(int(os.getenv("LOCAL_RANK", 0)))
     if "base" not in args.wedetect_uni_checkpoint and "large" not in args.wedetect_uni_checkpoint:
         raise NotImplementedError("Please name the ckpt properly")               # eval_recall.py:1514-1522
     model = load_uni_detector(args.wedetect_uni_checkpoint, num_prompts=256, precision=args.precision)

@@ -21,6 +21,7 @@ JSON list of names or of name lists, first name used — the ``data/texts/*_clas
 default ``data/texts/{dataset}_zh_class_texts.json`` (``lvis`` -> ``lvis_v1``).  ``--text-bank`` replaces the text
 tower by a precomputed ``[K, 768]`` bank."""
 import argparse
+import datetime
 import json
 import os
 import random
@@ -104,12 +105,15 @@ def read_class_names(path: str):
 def run(args, tokenizer=None):
     import torch.distributed as dist
     own_group = False
+    local = int(os.getenv("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
     if not dist.is_initialized():
-        dist.init_process_group(backend=args.backend, world_size=int(os.getenv("WORLD_SIZE", "1")),
-                                rank=int(os.getenv("RANK", "0")))
+        # the communicator is bound to this rank's device up front (a barrier otherwise guesses it from the current context)
+        kw = dict(device_id=torch.device("cuda", local)) if args.backend == "nccl" else {}
+        dist.init_process_group(backend=args.backend, world_size=int(os.getenv("WORLD_SIZE", "1")), rank=int(os.getenv("RANK", "0")),
+                                timeout=datetime.timedelta(seconds=float(os.getenv("WEDETECT_COLLECTIVE_TIMEOUT", "600"))), **kw)
         own_group = True
     rank, world = dist.get_rank(), dist.get_world_size()
-    torch.cuda.set_device(int(os.getenv("LOCAL_RANK", 0)))
     dev = torch.device("cuda", torch.cuda.current_device())
     if "base" not in args.wedetect_uni_checkpoint and "large" not in args.wedetect_uni_checkpoint:
         raise NotImplementedError("Please name the ckpt properly")                    # extract_embedding.py:1679-1681

@@ -302,3 +302,31 @@ def test_eval_recall_entry(tmp_path, monkeypatch):
     assert 0.4 <= ar300 <= 1.0                                                 # the planted boxes are recalled at every IoU
     lv = er.ground_truth_boxes(anns, [images[0]["id"]], drop_crowd=False)      # LVIS / PACO keep crowd boxes (eval_recall.py:95-99)
     assert lv[0].shape[0] == 3
+
+
+@pytest.mark.parametrize("mode", ["detect", "retrieval"])
+def test_bench_collectives_on_rccl_with_one_rank(mode):
+    """The N > 1 code of bench.py — communicator bound to the rank's device, the per-step region all-gathers behind the next
+    batch (detect) or the region / score-block all-gathers of the class-sharded bank (retrieval), the closing all-reduces and
+    barriers — on RCCL itself, as far as a one-GPU box allows: one rank that joins a real process group
+    (WEDETECT_BENCH_FORCE_DIST=1).  The collective library must report itself and the one rank it saw."""
+    import subprocess
+    import sys
+    env = dict(os.environ, WEDETECT_BENCH_FORCE_DIST="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29547", WEDETECT_BENCH_TIMEOUT="240", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    if mode == "detect":
+        cmd += ["--batch", "4", "--no-fp32-reference", "--no-host-fed", "--no-other-configs"]
+    else:
+        cmd += ["--mode", "retrieval", "--batch", "4", "--regions", "300", "--classes", "20000"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = p.stdout.splitlines()
+    # ONE JSON line on stdout and nothing else: RCCL's banner / warnings (it prints them to stdout, from its own threads) go to stderr
+    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["collective_backend"] == "nccl" and out["ranks_seen"] == 1 and out["n_gpus"] == 1
+    assert out["value"] > 0 and not out["config"]["fp16x3_range_guard_tripped"]
+    if mode == "detect":
+        assert out["per_rank"][0]["rank"] == 0 and out["per_rank"][0]["gather_handover_ms_per_step"] >= 0.0
+        assert "all-gather" not in out["config"]["parallelism"]               # the line still describes a one-GPU job
