@@ -219,6 +219,31 @@ def test_pack_folds_match_unfolded_math():
     assert P["s0.0.dw_w"].shape == (49, 32) and P["Bifusion0.up.w"].shape == (4 * 64, 64)
 
 
+def test_layernorm_fold_is_the_references_norm_then_pwconv1():
+    """engine.fold_layernorm_into_linear (round 5: the block LayerNorm applied INSIDE pwconv1's epilogue): with the row statistics
+    taken from the un-normalised depthwise output d, rstd (W' d - mean u) + v is the reference's pwconv1(norm(d))
+    (mm_backbone.py:114-118) — checked in float64 against torch's layer_norm + linear, on rows with a large common offset (the
+    case the centring-after-the-contraction form is sensitive to) and on a constant row (u must cancel W' d exactly)."""
+    from wedetect_amd.engine import fold_layernorm_into_linear
+    g = torch.Generator().manual_seed(11)
+    c, n, rows = 96, 384, 50
+    w1 = torch.randn(n, c, generator=g) * c ** -0.5
+    b1 = torch.randn(n, generator=g) * 0.1
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.2
+    d = torch.randn(rows, c, generator=g) * 1.7 + torch.linspace(-30.0, 30.0, rows)[:, None]
+    w1g, u, v = fold_layernorm_into_linear(w1, b1, gamma, beta)
+    assert w1g.dtype == u.dtype == v.dtype == torch.float32 and w1g.shape == (n, c) and u.shape == v.shape == (n,)
+    d64 = d.double()
+    mean, var = d64.mean(dim=1, keepdim=True), d64.var(dim=1, unbiased=False, keepdim=True)
+    rstd = 1.0 / torch.sqrt(var + 1e-6)
+    got = rstd * (d64 @ w1g.double().T - mean * u.double()[None, :]) + v.double()[None, :]
+    ref = torch.nn.functional.linear(torch.nn.functional.layer_norm(d64, (c,), gamma.double(), beta.double(), 1e-6), w1.double(), b1.double())
+    assert_close("folded LayerNorm + linear (float64 evaluation of the fp32 fold)", got, ref, 2e-5, 0)
+    const = torch.full((1, c), 123.456, dtype=torch.float64)
+    resid = const @ w1g.double().T - 123.456 * u.double()[None, :]
+    assert float(resid.abs().max()) < 1e-4 * 123.456 * 1e-3, "u is not the row sum of the W' the GEMM multiplies"
+
+
 def test_letterbox_matches_reference_arithmetic():
     from PIL import Image
     from wedetect_amd.detector import letterbox

@@ -29,6 +29,20 @@ from .pack import Packed
 DEFAULT_PRECISION = "fp16x3"
 
 
+def fold_layernorm_into_linear(w1: torch.Tensor, b1: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
+    """LayerNorm (affine gamma, beta) followed by a linear layer (w1 [n, c], b1 [n]) as ONE contraction of the un-normalised row d:
+
+        W1 LN(d) + b1 = rstd (W' d - mean u) + v,    W' = W1 diag(gamma),  u = W' 1,  v = W1 beta + b1
+
+    (mm_backbone.py:114-118: norm -> pwconv1).  Returns fp32 (W', u, v), computed in float64; u is the row sum of the fp32 W' the
+    GEMM actually multiplies, so that a constant row d = c 1 cancels to rounding."""
+    w64, g64 = w1.double(), gamma.double()
+    w1g = (w64 * g64[None, :]).float().contiguous()
+    u = w1g.double().sum(dim=1).float().contiguous()
+    v = (w64 @ beta.double() + b1.double()).float().contiguous()
+    return w1g, u, v
+
+
 class ImageTower:
     PRECISIONS = ("fp32", "fp16x3")
 
@@ -307,14 +321,11 @@ class ImageTower:
                     self._record(c_key, c[..., : n // 4] if kw.get("out_mode", 0) == L.OUT_DECONV2X2 else c[..., :n])
 
     def _fold_weights(self, q: str) -> None:
-        """W' = W1 gamma, u = W' 1, v = W1 beta + b1 of one block, in float64 on the device, once (shared through the packed set)."""
+        """W', u, v of one block (fold_layernorm_into_linear), on the device, once (shared through the packed set)."""
         if q + "w1g" in self.P.t:
             return
-        w1, g = self.P[q + "w1"].double(), self.P[q + "ln_w"].double()
-        w1g = (w1 * g[None, :]).float()
-        self.P.t[q + "w1g"] = w1g.contiguous()
-        self.P.t[q + "u"] = w1g.double().sum(dim=1).float().contiguous()         # of the fp32 W' the GEMM multiplies
-        self.P.t[q + "v"] = (w1 @ self.P[q + "ln_b"].double() + self.P[q + "b1"].double()).float().contiguous()
+        self.P.t[q + "w1g"], self.P.t[q + "u"], self.P.t[q + "v"] = fold_layernorm_into_linear(
+            self.P[q + "w1"], self.P[q + "b1"], self.P[q + "ln_w"], self.P[q + "ln_b"])
 
     def _fold_ok(self, i: int, pre: bool) -> bool:
         c = self.a.dims[i]
