@@ -390,7 +390,8 @@ int wd_dwconv7(const float* x, const float* w7, const float* bias, float* y,
                int32_t batch, int32_t h, int32_t w, int32_t c, void* stream);
 /* The same with the kernel form chosen by the caller (A/B measurements and the identity test; every form gives the same
  * bits): 0 = wd_dwconv7's own choice, 1 = generic strips from global memory, 2 = LDS tile / 1 x 4 strips, 3 = LDS tile /
- * 1 x 8 strips (h % 16 == 0).  2-3 need c % 32 == 0 (WD_ERR_UNSUPPORTED otherwise). */
+ * 1 x 8 strips (h % 16 == 0), 4 = the 1 x 4-strip tile staged by LDS-DMA (round 6; the production form wherever c % 32 == 0).
+ * 2-4 need c % 32 == 0 (WD_ERR_UNSUPPORTED otherwise). */
 int wd_dwconv7_variant(const float* x, const float* w7, const float* bias, float* y,
                        int32_t batch, int32_t h, int32_t w, int32_t c, int32_t variant, void* stream);
 /* wd_dwconv7_ln — the same depthwise conv followed by LayerNorm over the channels of each pixel (eps, affine

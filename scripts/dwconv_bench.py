@@ -14,10 +14,10 @@ for name, (b, h, w, c) in {"s1 160x160x128": (32, 160, 160, 128), "s2 80x80x256"
     bias = torch.randn(c, device=dev)
     y = torch.empty_like(x)
     ref = None
-    for variant in (2, 3, 0):
+    for variant in [int(v) for v in os.environ.get("VARIANTS", "2,3,4,0").split(",")]:
         if variant == 3 and h % 16:
             continue
-        if variant in (2, 3) and c % 32:
+        if variant in (2, 3, 4) and c % 32:
             continue
         y.zero_()
         for _ in range(3):
@@ -36,3 +36,20 @@ for name, (b, h, w, c) in {"s1 160x160x128": (32, 160, 160, 128), "s2 80x80x256"
         same = "bit-identical" if torch.equal(ref, y) else f"DIFFERS max|d| {float((ref - y).abs().max()):.3e}"
         nbytes = 2.0 * x.numel() * 4
         print(f"{name:16s} form {variant}: {min(ts):8.1f} us ({nbytes / min(ts) / 1e6:5.2f} TB/s)  {same}", flush=True)
+    if c % 32 == 0:                      # the LayerNorm-fold producer: hi/lo output + per-block statistics (wd_dwconv7_stats)
+        ys = torch.empty_like(x)
+        part = torch.empty(2 * b * h * w * (c // 32), device=dev)
+        for _ in range(3):
+            L.dwconv7_stats(x, w7, bias, ys, part, b, h, w, c)
+        ts = []
+        for _ in range(5):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(10):
+                L.dwconv7_stats(x, w7, bias, ys, part, b, h, w, c)
+            e.record()
+            torch.cuda.synchronize()
+            ts.append(1e3 * s.elapsed_time(e) / 10)
+        hv = ys.view(torch.float16).view(-1, c // 8, 2, 8)
+        err = float(((hv[:, :, 0].float() + hv[:, :, 1].float()).reshape(-1, c) - ref).abs().max())
+        print(f"{name:16s} stats  : {min(ts):8.1f} us ({2.0 * x.numel() * 4 / min(ts) / 1e6:5.2f} TB/s)  max|hi+lo - form 2| {err:.2e}", flush=True)

@@ -1,0 +1,69 @@
+# round-6 GPU driver script: `gpurun -- bash scripts/r06_gpu.sh <step> [args]`; every step writes under gpurun_out/r06/<step>/
+set -u
+STEP=${1:-baseline}; shift || true
+OUT=gpurun_out/r06/$STEP; mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+Q="--steps 30 --warmup 8 --no-cpu-baseline --no-fp32-reference --no-host-fed --no-other-configs"
+line() { python - "$@" <<'PY'
+import json,sys
+for f in sys.argv[1:]:
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1])
+        r=d['roofline']
+        print(f.split('/')[-1], d['value'], d['unit'], d['ms_per_step'], 'dom', r['frac'], r.get('avg_launch_us'), 'sim', d.get('sim_gemm',{}).get('frac'))
+    except Exception as e:
+        print(f, 'FAILED', e)
+PY
+}
+case $STEP in
+baseline)
+  python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+  WEDETECT_DAG=0 python bench.py $Q > $OUT/bench_dag0.json 2> $OUT/bench_dag0.err
+  OUT=$OUT/layers.json python scripts/neck_layer_times.py > $OUT/layers.txt 2>&1
+  line $OUT/bench_default.json $OUT/bench_dag0.json
+  grep -v amdgpu.ids $OUT/layers.txt
+  ;;
+dwpmc)
+  # what the depthwise 7x7 kernels ARE bound by: SQ / TCC counters over scripts/dwconv_bench.py
+  export TMPDIR=/tmp
+  python scripts/dwconv_bench.py > $OUT/dwconv_bench.txt 2>&1
+  python scripts/hbm_bw_probe.py > $OUT/hbm_probe.txt 2>&1
+  rocprofv3 --kernel-trace --stats -d $OUT/trace -o p -- python scripts/dwconv_bench.py > /dev/null 2> $OUT/trace.err
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE -d $OUT/pmc1 -o p -- python scripts/dwconv_bench.py > /dev/null 2> $OUT/pmc1.err
+  rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU -d $OUT/pmc2 -o p -- python scripts/dwconv_bench.py > /dev/null 2> $OUT/pmc2.err
+  rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum -d $OUT/pmc3 -o p -- python scripts/dwconv_bench.py > /dev/null 2> $OUT/pmc3.err
+  python scripts/rocpd_summary.py $(ls $OUT/trace/*.db | head -1) --pmc $(ls $OUT/pmc1/*.db | head -1) --pmc $(ls $OUT/pmc2/*.db | head -1) --pmc $(ls $OUT/pmc3/*.db | head -1) > $OUT/summary.txt 2>&1
+  rm -rf $OUT/trace $OUT/pmc1 $OUT/pmc2 $OUT/pmc3
+  grep -v amdgpu.ids $OUT/dwconv_bench.txt; tail -5 $OUT/hbm_probe.txt; grep -i "dwconv\|kernel  \|## PMC" $OUT/summary.txt | cut -c1-330; tail -3 $OUT/pmc*.err
+  ;;
+dwdma)
+  # the LDS-DMA staged depthwise kernel: identity tests, isolated A/B (channel blocks per workgroup 1 / 2 / 4), step A/B
+  ( timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_split.py -q -m gpu -k "dwconv or stats or fold or layernorm" -x 2>&1 | tail -8 ) > $OUT/tests.log
+  for n in 1 2 4; do echo "== WD_DWCONV_NCB=$n"; WD_DWCONV_NCB=$n python scripts/dwconv_bench.py; done > $OUT/dwconv_bench.txt 2>&1
+  for i in 1 2; do
+    WEDETECT_DWCONV_DMA=0 python bench.py $Q > $OUT/bench_dma0_$i.json 2> $OUT/bench_dma0_$i.err
+    python bench.py $Q > $OUT/bench_dma1_$i.json 2> $OUT/bench_dma1_$i.err
+  done
+  cat $OUT/tests.log; grep -v amdgpu.ids $OUT/dwconv_bench.txt; line $OUT/bench_dma*.json
+  ;;
+dwdma2)
+  export TMPDIR=/tmp
+  ( timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_split.py -q -m gpu -k "dwconv or stats or fold" -x 2>&1 | tail -5 ) > $OUT/tests.log
+  python scripts/dwconv_bench.py > $OUT/dwconv_bench.txt 2>&1
+  VARIANTS=4 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE -d $OUT/pmc1 -o p -- python scripts/dwconv_bench.py > /dev/null 2> $OUT/pmc1.err
+  VARIANTS=4 rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU -d $OUT/pmc2 -o p -- python scripts/dwconv_bench.py > /dev/null 2> $OUT/pmc2.err
+  VARIANTS=4 rocprofv3 --kernel-trace --stats -d $OUT/trace -o p -- python scripts/dwconv_bench.py > /dev/null 2> $OUT/trace.err
+  python scripts/rocpd_summary.py $(ls $OUT/trace/*.db | head -1) --pmc $(ls $OUT/pmc1/*.db | head -1) --pmc $(ls $OUT/pmc2/*.db | head -1) > $OUT/summary.txt 2>&1
+  rm -rf $OUT/trace $OUT/pmc1 $OUT/pmc2
+  for i in 1 2; do
+    WEDETECT_DWCONV_DMA=0 python bench.py $Q > $OUT/bench_dma0_$i.json 2> $OUT/bench_dma0_$i.err
+    python bench.py $Q > $OUT/bench_dma1_$i.json 2> $OUT/bench_dma1_$i.err
+  done
+  cat $OUT/tests.log; grep -v amdgpu.ids $OUT/dwconv_bench.txt; grep -i "dwconv\|kernel  \|## PMC" $OUT/summary.txt | cut -c1-330; line $OUT/bench_dma*.json
+  ;;
+ceiling)
+  WEDETECT_LIB=$GRAFT_REPO_ROOT/wedetect_amd/libwedetect_hip_abl.so python scripts/p8_ceiling.py > $OUT/p8_ceiling.jsonl 2> $OUT/p8_ceiling.err
+  cat $OUT/p8_ceiling.jsonl; tail -3 $OUT/p8_ceiling.err
+  ;;
+*) echo "unknown step $STEP"; exit 2;;
+esac

@@ -194,14 +194,14 @@ def test_dwconv7(L, c, h, w):
 
 @pytest.mark.parametrize("c,h,w", [(32, 16, 16), (128, 20, 20), (512, 40, 40), (64, 64, 48), (32, 80, 37), (96, 9, 11), (1024, 7, 21), (256, 33, 18)])
 def test_dwconv7_kernel_forms_are_bit_identical(L, c, h, w):
-    """The generic kernel (form 1), the 1 x 4-strip tile kernel (2) and the 1 x 8-strip tile kernel (3, h % 16 == 0) accumulate
-    every output in the same order (bias, taps kh-major, kw ascending): identical bits, ragged tiles and map borders included;
-    unsupported forms are refused (wd_dwconv7_variant, round 4)."""
+    """The generic kernel (form 1), the 1 x 4-strip tile kernel (2), the 1 x 8-strip tile kernel (3, h % 16 == 0) and the
+    LDS-DMA staged tile kernel (4, round 6) accumulate every output in the same order (bias, taps kh-major, kw ascending):
+    identical bits, ragged tiles and map borders included; unsupported forms are refused (wd_dwconv7_variant)."""
     b_ = 3
     x, wt, bias = rnd(61, b_, h, w, c), rnd(62, 49, c, scale=1 / 7), rnd(63, c)
     xd, wd_, bd = dev(x), dev(wt), dev(bias)
     outs = {}
-    for variant in (1, 2, 3, 0):
+    for variant in (1, 2, 3, 4, 0):
         if variant == 3 and h % 16:
             with pytest.raises(L.WedetectHipError):
                 L.dwconv7(xd, wd_, bd, torch.empty(b_, h, w, c, device="cuda"), b_, h, w, c, variant=variant)
