@@ -61,6 +61,25 @@ dwdma2)
   done
   cat $OUT/tests.log; grep -v amdgpu.ids $OUT/dwconv_bench.txt; grep -i "dwconv\|kernel  \|## PMC" $OUT/summary.txt | cut -c1-330; line $OUT/bench_dma*.json
   ;;
+dwln)
+  ( timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_split.py -q -m gpu -k "dwconv or stats or fold" -x 2>&1 | tail -5 ) > $OUT/tests.log
+  { echo "== WEDETECT_DWCONV_DMA=0"; WEDETECT_DWCONV_DMA=0 python scripts/dwln_bench.py; echo "== WEDETECT_DWCONV_DMA=1"; python scripts/dwln_bench.py; } > $OUT/dwln_bench.txt 2>&1
+  for i in 1 2; do
+    WEDETECT_DWCONV_DMA=0 python bench.py $Q > $OUT/bench_dma0_$i.json 2> $OUT/bench_dma0_$i.err
+    python bench.py $Q > $OUT/bench_dma1_$i.json 2> $OUT/bench_dma1_$i.err
+  done
+  cat $OUT/tests.log; grep -v amdgpu.ids $OUT/dwln_bench.txt; line $OUT/bench_dma*.json
+  ;;
+bstride)
+  ( timeout 1200 python -m pytest tests/test_gpu_split.py -q -m gpu -k "batch_stride or p8_kernel or special" -x 2>&1 | tail -5 ) > $OUT/tests.log
+  ( timeout 1200 python -m pytest tests/test_gpu_network.py tests/test_gpu_configs.py -q -m gpu -x 2>&1 | tail -5 ) > $OUT/tests_net.log
+  OUT=$OUT/layers.json python scripts/neck_layer_times.py > $OUT/layers.txt 2>&1
+  for i in 1 2; do
+    WEDETECT_P8_BSTRIDE=0 python bench.py $Q > $OUT/bench_off_$i.json 2> $OUT/bench_off_$i.err
+    python bench.py $Q > $OUT/bench_on_$i.json 2> $OUT/bench_on_$i.err
+  done
+  cat $OUT/tests.log $OUT/tests_net.log; grep "embed\|total" $OUT/layers.txt; line $OUT/bench_o*.json
+  ;;
 ceiling)
   WEDETECT_LIB=$GRAFT_REPO_ROOT/wedetect_amd/libwedetect_hip_abl.so python scripts/p8_ceiling.py > $OUT/p8_ceiling.jsonl 2> $OUT/p8_ceiling.err
   cat $OUT/p8_ceiling.jsonl; tail -3 $OUT/p8_ceiling.err

@@ -51,7 +51,7 @@ NO_SCRATCH = {"stem.hip": ["stem_fused_kernel"], "split_gemm_mlpw.hip": ["fused_
               "split_gemm_p4.hip": ["split_gemm_p4_kernel"], "split_gemm_conv.hip": ["split_conv_pp_kernel"],
               "split_gemm_conv3.hip": ["split_conv3_kernel"],
               "split_gemm_pre.hip": ["split_gemm_pingpong_kernel", "split_gemm_glds_kernel"],
-              "elementwise.hip": ["dwconv7_dma_kernel"]}
+              "elementwise.hip": ["dwconv7_dma_kernel", "dwconv7_ln_reg4_dma_kernel"]}
 ASM_VMEM_SOURCES = {"split_gemm_mlpw.hip": ["fused_mlp_wide_kernel"], "split_gemm_mlp.hip": [], "split_gemm_p8.hip": [],
                     "split_gemm_p4.hip": [], "split_gemm_pre.hip": [], "split_gemm_conv.hip": [], "split_gemm_conv3.hip": [], "stem.hip": [], "elementwise.hip": []}
 

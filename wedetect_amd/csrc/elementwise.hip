@@ -277,6 +277,48 @@ __device__ __forceinline__ void dm_dma(unsigned lds_addr, const void* src) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(src) : "memory", "m0");
 }
 
+// One thread's share of the tile's LDS-DMA: instruction i of wave v fills slots [8 (v + 4 i), + 8) (lane = (slot in the group,
+// channel quad)); init() once per spatial tile, issue() once per channel block (waits for the wave's own requests; the caller's
+// barrier makes everybody's visible).
+struct DmStage {
+  unsigned voff[DM_NI], woff[2], okm, la;
+  int wave;
+  __device__ __forceinline__ void init(float* lds, int t, int h, int w, int c, int h0, int w0) {
+    wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int lane = t & 63, r8 = lane >> 3, qd = lane & 7;
+    const unsigned rowb = (unsigned)c * 4u, wrowb = (unsigned)w * rowb;
+    okm = 0;
+    const int s0 = wave * 8 + r8;
+    int py = s0 >= DT_IWP ? 1 : 0, px = s0 - py * DT_IWP;
+#pragma unroll
+    for (int i = 0; i < DM_NI; ++i) {
+      const int hi = h0 + py - 3, wi = w0 + px - 3;
+      const bool ok = px < DT_IW && py < DT_IH && (unsigned)hi < (unsigned)h && (unsigned)wi < (unsigned)w;
+      voff[i] = (unsigned)__mul24(hi, (int)wrowb) + (unsigned)__mul24(wi, (int)rowb) + (unsigned)qd * 16u;
+      okm |= ok ? (1u << i) : 0u;
+      px += 9; py += 1;
+      if (px >= DT_IWP) { px -= DT_IWP; py += 1; }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int tap = (wave + 4 * j) * 8 + r8;
+      okm |= tap < 49 ? (1u << (16 + j)) : 0u;
+      woff[j] = (unsigned)__mul24(tap, (int)rowb) + (unsigned)qd * 16u;
+    }
+    la = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)lds + wave * 1024);
+  }
+  // xq / wq: the image's / the taps' first byte of this channel block; zp: 16 readable bytes of zeros
+  __device__ __forceinline__ void issue(const unsigned char* xq, const unsigned char* wq, const unsigned char* zp) const {
+    static_assert(DM_AG == 4 * (DM_NI - 1) + 1 && DM_WG == 7, "groups 0..39 by all four waves, group 40 by wave 0; tap groups 0..3 by all, 4..6 by waves 0..2");
+#pragma unroll
+    for (int i = 0; i < DM_NI - 1; ++i) dm_dma(la + i * 4096, ((okm >> i) & 1u) ? xq + voff[i] : zp);
+    dm_dma(la + DM_TIN * 4, ((okm >> 16) & 1u) ? wq + woff[0] : zp);
+    if (wave == 0) dm_dma(la + (DM_NI - 1) * 4096, ((okm >> (DM_NI - 1)) & 1u) ? xq + voff[DM_NI - 1] : zp);     // wave-uniform
+    if (wave < 3) dm_dma(la + DM_TIN * 4 + 4096, ((okm >> 17) & 1u) ? wq + woff[1] : zp);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+};
+
 template <bool STATS, int NCB>
 __global__ void __launch_bounds__(256) dwconv7_dma_kernel(const float* __restrict__ x, const float* __restrict__ w7,
                                                           const float* __restrict__ bias, float* __restrict__ y,
@@ -292,34 +334,9 @@ __global__ void __launch_bounds__(256) dwconv7_dma_kernel(const float* __restric
   const unsigned char* xi = reinterpret_cast<const unsigned char*>(x + (b * h) * (long long)w * c);
   const unsigned char* zp = reinterpret_cast<const unsigned char*>(zero);   // a kernel argument: the symbol's address would be re-derived per use
 
-  // ---- this thread's DMA slots: instruction i of wave v fills slots [8 (v + 4 i), + 8); lane = (slot in the group, channel quad)
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
-  const int r8 = lane >> 3, qd = lane & 7;
-  const unsigned rowb = (unsigned)c * 4u, wrowb = (unsigned)w * rowb;
-  unsigned voff[DM_NI], okm = 0;
-  {
-    const int s0 = wave * 8 + r8;
-    int py = s0 >= DT_IWP ? 1 : 0, px = s0 - py * DT_IWP;
-#pragma unroll
-    for (int i = 0; i < DM_NI; ++i) {
-      const int hi = h0 + py - 3, wi = w0 + px - 3;
-      const bool ok = px < DT_IW && py < DT_IH && (unsigned)hi < (unsigned)h && (unsigned)wi < (unsigned)w;
-      voff[i] = (unsigned)__mul24(hi, (int)wrowb) + (unsigned)__mul24(wi, (int)rowb) + (unsigned)qd * 16u;
-      okm |= ok ? (1u << i) : 0u;
-      px += 9; py += 1;
-      if (px >= DT_IWP) { px -= DT_IWP; py += 1; }
-    }
-  }
-  unsigned woff[2];
-  bool wok[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int tap = (wave + 4 * j) * 8 + r8;
-    wok[j] = tap < 49;
-    woff[j] = (unsigned)__mul24(tap, (int)rowb) + (unsigned)qd * 16u;
-  }
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds;
-
+  DmStage stg;
+  stg.init(lds, t, h, w, c, h0, w0);
+  const int wave = stg.wave;
   const int q = t & 7;                   // channel quad
   // 4-pixel strip / output row inside the tile.  Bits 3 and 4 of the thread index mean what they mean in dt_lane_map (the
   // only bits that differ inside a 16-lane ds_read_b128 group: same conflict-free reads); the strip PAIR and the row QUAD are
@@ -333,18 +350,7 @@ __global__ void __launch_bounds__(256) dwconv7_dma_kernel(const float* __restric
   for (int k = 0; k < NCB; ++k) {
     const int cb = cbg * NCB + k, c0 = cb * DT_CB;
     if (k > 0) __syncthreads();          // everyone is done reading the previous channel block's tile
-    {
-      const unsigned char* xq = xi + (size_t)c0 * 4;
-      const unsigned char* wq = reinterpret_cast<const unsigned char*>(w7 + c0);
-      static_assert(DM_AG == 4 * (DM_NI - 1) + 1 && DM_WG == 7, "groups 0..39 by all four waves, group 40 by wave 0; tap groups 0..3 by all, 4..6 by waves 0..2");
-      const unsigned la = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
-#pragma unroll
-      for (int i = 0; i < DM_NI - 1; ++i) dm_dma(la + i * 4096, ((okm >> i) & 1u) ? xq + voff[i] : zp);
-      dm_dma(la + DM_TIN * 4, wok[0] ? wq + woff[0] : zp);
-      if (wave == 0) dm_dma(la + (DM_NI - 1) * 4096, ((okm >> (DM_NI - 1)) & 1u) ? xq + voff[DM_NI - 1] : zp);     // wave-uniform
-      if (wave < 3) dm_dma(la + DM_TIN * 4 + 4096, wok[1] ? wq + woff[1] : zp);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    stg.issue(xi + (size_t)c0 * 4, reinterpret_cast<const unsigned char*>(w7 + c0), zp);
     __syncthreads();
     if (!live) continue;
 
@@ -1062,6 +1068,60 @@ __global__ void __launch_bounds__(256) dwconv7_ln_reg4_kernel(const float* __res
   dwln_reg_rows<NBLK, SPLIT, 4>(acc, y, gamma, beta, (b * h + (row_ok ? ho : h0)) * (long long)w, w, w0 + wg * 4, C, eps, q, row_ok);
 }
 
+// Round 6: the same kernel with the halo tiles staged by LDS-DMA (DmStage above; slot arithmetic once per spatial tile, twelve
+// DMA instructions per wave and channel block, no staging registers) and the wave-uniform strip / row ownership of
+// dwconv7_dma_kernel (a wave past the map's edge skips the taps and the LayerNorm).  Same accumulation order, same LayerNorm
+// tree (its lane exchanges stay inside the 8 lanes of a pixel): identical bits.
+template <int NBLK, bool SPLIT>
+__global__ void __launch_bounds__(256) dwconv7_ln_reg4_dma_kernel(const float* __restrict__ x, const float* __restrict__ w7,
+                                                                  const float* __restrict__ bias, float* __restrict__ y,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  int h, int w, float eps, const float* __restrict__ zero) {
+  constexpr int C = NBLK * DT_CB;
+  __shared__ __attribute__((aligned(16))) float lds[DM_LDS_FLOATS];
+  float* tin = lds;
+  float* tw = lds + DM_TIN;
+  const int t = threadIdx.x;
+  const long long b = blockIdx.z;
+  const int h0 = blockIdx.y * DT_TH, w0 = blockIdx.x * DT_TW;
+  const unsigned char* xi = reinterpret_cast<const unsigned char*>(x + (b * h) * (long long)w * C);
+  const unsigned char* zp = reinterpret_cast<const unsigned char*>(zero);
+  DmStage stg;
+  stg.init(lds, t, h, w, C, h0, w0);
+  const int wave = stg.wave;
+  const int q = t & 7;
+  const int wg = ((t >> 3) & 1) + 2 * (t >> 7), oy = (t >> 4) & 7;
+  const bool live = w0 + 8 * (wave >> 1) < w && h0 + 4 * (wave & 1) < h;      // wave-uniform
+  f32x4 acc[NBLK][4];
+#pragma unroll
+  for (int cb = 0; cb < NBLK; ++cb) {
+    if (cb > 0) __syncthreads();                       // everyone is done reading the previous channel block's tile
+    stg.issue(xi + cb * DT_CB * 4, reinterpret_cast<const unsigned char*>(w7 + cb * DT_CB), zp);
+    __syncthreads();
+    if (!live) continue;
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + cb * DT_CB + q * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[cb][j] = bv;
+#pragma unroll 1
+    for (int kh = 0; kh < 7; ++kh) {
+      const float* row = tin + ((oy + kh) * DT_IWP + wg * 4) * DT_CP + q * 4;
+      f32x4 in[10];
+#pragma unroll
+      for (int j = 0; j < 10; ++j) in[j] = *reinterpret_cast<const f32x4*>(row + j * DT_CP);
+#pragma unroll
+      for (int kw = 0; kw < 7; ++kw) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(tw + (kh * 7 + kw) * DT_CB + q * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[cb][j] += in[j + kw] * wv;
+      }
+    }
+  }
+  if (!live) return;
+  const int ho = h0 + oy;
+  const bool row_ok = ho < h;
+  dwln_reg_rows<NBLK, SPLIT, 4>(acc, y, gamma, beta, (b * h + (row_ok ? ho : h0)) * (long long)w, w, w0 + wg * 4, C, eps, q, row_ok);
+}
+
 // ---------------------------------------------------------------------------------------
 // depthwise 7x7 + LayerNorm for the WIDE stages (round 5: c = 256 / 384 / 512), pre-norm values in registers.
 // The 128-channel form above keeps 16 values per channel block and thread; at 512 channels that would be 256 registers.
@@ -1372,9 +1432,11 @@ static int launch_dwconv7(const float* x, const float* w7, const float* bias, fl
   if (variant == 4 && !dwconv7_dma_ok(h, w, c)) return WD_ERR_UNSUPPORTED;
   // round 6: the LDS-DMA staged tile kernel wherever it applies ($WEDETECT_DWCONV_DMA=0: the round-2..5 choice, for A/B runs)
   static const bool dma_on = [] { const char* e = getenv("WEDETECT_DWCONV_DMA"); return !(e && e[0] == '0'); }();
-  if (variant == 4 || (variant == 0 && dma_on && dwconv7_dma_ok(h, w, c)))
-    return launch_dwconv7_dma<false>(x, w7, bias, y, batch, h, w, c, nullptr, 1.0f, static_cast<hipStream_t>(stream));
   const bool strip16 = variant == 3 || (variant == 0 && c % DT_CB == 0 && h % 16 == 0 && h >= 64);
+  // (where 16-row tiles fit the map exactly the 1 x 8-strip kernel stays ahead: 160 x 160 x 128 228-243 vs 241-254 us, 80 x 80 x 256
+  // 114-118 vs 121-123 us; everywhere else the DMA form wins: 40 x 40 x 512 62 -> 52 us, 20 x 20 x 1024 49 -> 40 us — profiles/r06_dwconv_dma.txt)
+  if (variant == 4 || (variant == 0 && !strip16 && dma_on && dwconv7_dma_ok(h, w, c)))
+    return launch_dwconv7_dma<false>(x, w7, bias, y, batch, h, w, c, nullptr, 1.0f, static_cast<hipStream_t>(stream));
   if (strip16) {   // tall tiles only where they tile the map exactly: the 8-row form of this kernel (128 threads) lost to the 1 x 4 kernel on the 40 x 40 and 20 x 20 maps (76 vs 68 us, 58 vs 52 us)
     // 16 x 16 tiles of 1 x 8 strips: 160 x 160 map 264 -> 222-240 us, 80 x 80 128 -> 110 us (profiles/r02_dwconv_ab.txt)
     const int th = h / 16, tw = (w + DT_TW - 1) / DT_TW;
@@ -1472,6 +1534,15 @@ extern "C" int wd_dwconv7_ln(const float* x, const float* w7, const float* bias,
     else hipLaunchKernelGGL((dwconv7_ln_reg4_kernel<NB_, false>), dim3((unsigned)nb8), dim3(256), 0, st, x, w7, bias, y,       \
                             gamma, beta, h, w, th8, tw16, eps);                                                                 \
     break;
+      static const bool dma_on = [] { const char* e = getenv("WEDETECT_DWCONV_DMA"); return !(e && e[0] == '0'); }();
+      if (dma_on && dwconv7_dma_ok(h, w, c) && th8 <= 65535 && batch <= 65535) {       // round 6: halo tiles by LDS-DMA
+        const float* zero = dm_zero_block();
+        if (!zero) return WD_ERR_LAUNCH;
+        const dim3 grid((unsigned)tw16, (unsigned)th8, (unsigned)batch);
+        if (split) hipLaunchKernelGGL((dwconv7_ln_reg4_dma_kernel<4, true>), grid, dim3(256), 0, st, x, w7, bias, y, gamma, beta, h, w, eps, zero);
+        else hipLaunchKernelGGL((dwconv7_ln_reg4_dma_kernel<4, false>), grid, dim3(256), 0, st, x, w7, bias, y, gamma, beta, h, w, eps, zero);
+        return wd_launch_status();
+      }
       switch (c / DT_CB) { WD_DWLN_REG4(1) WD_DWLN_REG4(2) WD_DWLN_REG4(3) WD_DWLN_REG4(4) }
 #undef WD_DWLN_REG4
       return wd_launch_status();
