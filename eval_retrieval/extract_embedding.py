@@ -114,6 +114,9 @@ def run(args, tokenizer=None):
                                 timeout=datetime.timedelta(seconds=float(os.getenv("WEDETECT_COLLECTIVE_TIMEOUT", "600"))), **kw)
         own_group = True
     rank, world = dist.get_rank(), dist.get_world_size()
+    # the closing barrier sits behind rank 0 writing a multi-GB file: it gets a group of its own with a long deadline
+    # ($WEDETECT_SAVE_TIMEOUT, default 2 h) instead of the 600 s every data-path collective is held to
+    save_group = dist.new_group(timeout=datetime.timedelta(seconds=float(os.getenv("WEDETECT_SAVE_TIMEOUT", "7200")))) if world > 1 else None
     dev = torch.device("cuda", torch.cuda.current_device())
     if "base" not in args.wedetect_uni_checkpoint and "large" not in args.wedetect_uni_checkpoint:
         raise NotImplementedError("Please name the ckpt properly")                    # extract_embedding.py:1679-1681
@@ -168,7 +171,8 @@ def run(args, tokenizer=None):
         print(f"Evaluating {args.dataset} ...")
         save_retrieval_file(out_path, records, text_embeddings)
         print(f"wrote {out_path}: {len(records)} images, {tuple(text_embeddings.shape)} text bank")
-    dist.barrier()
+    if save_group is not None:
+        dist.barrier(group=save_group)
     if own_group:
         dist.destroy_process_group()
     return out_path

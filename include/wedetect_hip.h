@@ -101,7 +101,8 @@ typedef struct WdConvGemm {
                                 * of this launch is inf / NaN, i.e. an operand left the fp16 range; never cleared here */
   float* c2;                   /* fp16x3 + WD_SPLIT_C only, may be NULL: an fp32 copy of the output in plain rows (row
                                 * stride ldc2) next to the fp16 hi/lo output in c — for consumers that read fp32 (the
-                                * BottleRep residual, yolo_world_pafpn.py:602-605); plain-row outputs only */
+                                * BottleRep residual, yolo_world_pafpn.py:602-605); WD_OUT_ROWS outputs only; with
+                                * c_batch_stride (ABI 14) the copy takes the same per-image row mapping as c */
   int32_t ldc2;
   /* fp16x3 range management: power-of-two scales (0 is read as 1) that keep an operand's fp16 (hi, lo) halves inside the
    * fp16 normal range whatever the checkpoint's activation scale.  a_scale: fp32 activations are multiplied by it
@@ -268,6 +269,19 @@ int wd_ln_stats_finalize(const float* part, float* stats, int64_t rows, int32_t 
 int wd_retrieval_max_split(const void* e_split, const void* t_split, float t_unscale, const float* scale,
                            const float* bias, const int32_t* count, float* out, int32_t n_img, int32_t rows_per_img,
                            int32_t n_cls, int32_t dim, uint32_t* range_flag, void* stream);
+
+/* wd_similarity_split (ABI 14) — replaces, for large text banks, the `x = einsum('bchw,bkc->bkhw', x, w) * logit_scale.exp() + bias`
+ * (+ sigmoid) of BNContrastiveHead.forward (wedetect/models/dense_heads/yolo_world_head.py:90-108) and the Uni script's
+ * `(embeddings @ prompts.T) * exp(scale) + bias` (generate_proposal.py:1129-1131) — the same contraction as the fp32 similarity
+ * launch of wd_conv_gemm, computed on the fp16x3 256 x 256 kernel: e_split = the region embeddings [rows][dim] as fp16 hi/lo groups
+ * (what the embedding conv writes with WD_SPLIT_C; the BUFFER must hold a multiple of eight rows), t_split = the text rows
+ * [n_cls][dim] from wd_split_weights_padded, unscale = 1 / (text pre-scale * embedding split scale).
+ * out[row][cls] (row stride ldo) = (sigmoid)(<e, t> * unscale * seg_scale[l] + seg_bias[l]) with l = the pyramid level of
+ * row % seg_rows (boundaries seg_end0 / seg_end1), exactly the `seg` epilogue of wd_conv_gemm.  dim % 32 == 0; any n_cls / ldo.
+ * range_flag (optional): set to 1 when an accumulator is inf / NaN (an fp16 half overflowed). */
+int wd_similarity_split(const void* e_split, int64_t rows, const void* t_split, float unscale, float* out, int32_t n_cls,
+                        int32_t dim, int32_t ldo, int32_t seg_rows, int32_t seg_end0, int32_t seg_end1,
+                        const float* seg_scale, const float* seg_bias, int32_t sigmoid, uint32_t* range_flag, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Text tower pieces (mm_backbone.py:341-390, HF XLMRobertaModel): the embedding

@@ -80,6 +80,27 @@ bstride)
   done
   cat $OUT/tests.log $OUT/tests_net.log; grep "embed\|total" $OUT/layers.txt; line $OUT/bench_o*.json
   ;;
+simsplit)
+  ( timeout 1200 python -m pytest tests/test_gpu_split.py -q -m gpu -k "similarity or special or conv_pp or p8_kernel" -x 2>&1 | tail -8 ) > $OUT/tests.log
+  ( timeout 1500 python -m pytest tests/test_gpu_network.py tests/test_gpu_configs.py -q -m gpu -x 2>&1 | tail -8 ) > $OUT/tests_net.log
+  for i in 1 2; do
+    WEDETECT_SIM_SPLIT=0 python bench.py $Q --arch large --batch 16 --classes 1203 > $OUT/large_off_$i.json 2> $OUT/large_off_$i.err
+    python bench.py $Q --arch large --batch 16 --classes 1203 > $OUT/large_on_$i.json 2> $OUT/large_on_$i.err
+    WEDETECT_SIM_SPLIT=0 python bench.py $Q --mode uni --classes 256 > $OUT/uni_off_$i.json 2> $OUT/uni_off_$i.err
+    python bench.py $Q --mode uni --classes 256 > $OUT/uni_on_$i.json 2> $OUT/uni_on_$i.err
+  done
+  cat $OUT/tests.log $OUT/tests_net.log; line $OUT/large_o*.json $OUT/uni_o*.json
+  python - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/r06/simsplit/*_on_1.json')):
+    d=json.loads(open(f).read().strip().splitlines()[-1]); print(f.split('/')[-1], json.dumps(d.get('sim_gemm')))
+PY
+  ;;
+fullsuite)
+  ( timeout 3000 python -m pytest tests -q -m gpu 2>&1 | tail -25 ) > $OUT/tests_full.log
+  cp gpurun_out/parity_r05.jsonl $OUT/parity.jsonl 2>/dev/null
+  tail -25 $OUT/tests_full.log
+  ;;
 ceiling)
   WEDETECT_LIB=$GRAFT_REPO_ROOT/wedetect_amd/libwedetect_hip_abl.so python scripts/p8_ceiling.py > $OUT/p8_ceiling.jsonl 2> $OUT/p8_ceiling.err
   cat $OUT/p8_ceiling.jsonl; tail -3 $OUT/p8_ceiling.err

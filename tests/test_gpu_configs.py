@@ -10,15 +10,16 @@ net_*_b1_640_robust2_{mm,uni}.npz), and image 0 — the round-1 golden — is AS
 membership change fails): it reproduces exactly in every recorded run, so recording it without asserting only hid regressions.
 
 Each full batch is checked five ways.  Image 0 IS the image of the round-1 reference-generated B = 1 golden (tests/golden/
-net_*_b1_640.npz): its network checksums are asserted; its kept lists are compared and RECORDED, not asserted exact — the
-reference's own decisions on that image sit inside fp32 summation noise (round-3 review: exact "only because every kernel
-change so far kept the K order bit-identical").  Images 1 and 2 are the MARGIN-ROBUST goldens of round 4
-(net_*_b1_640_robust_{mm,uni}.npz: seeds searched for decision margins >= 2e-5 on everything that can reach the output,
-make_golden.py: search_robust): the mmdet-path list of image 1 and the Uni-path list of image 2 must equal the
-reference's position by position with ZERO relaxations — under any K order (the test is also run with WEDETECT_P8=0 /
-WEDETECT_FUSE_MLP_WIDE toggled, profiles/r04_parity.jsonl).  One image from the middle of the batch goes through the CPU
-oracle's whole network on the box and must agree on embeddings / scores / boxes, and exactly on both kept lists whenever
-its own effective margins exceed 2e-5 (recorded otherwise); the post-process of EVERY image must equal the oracle's
+net_*_b1_640.npz): its network checksums are asserted and its kept (anchor, label) lists must equal the reference's — the
+reference's own decisions on that image sit close to fp32 summation noise, so the ONE counted allowance is a permutation
+inside a run of reference scores closer than the score difference measured in the comparison (allow=("tie_run",)); a membership
+change fails.  Images 1 and 2 are the MARGIN-ROBUST goldens of round 4 (net_*_b1_640_robust_{mm,uni}.npz: seeds searched for
+decision margins >= 2e-5 on everything that can reach the output, make_golden.py: search_robust): the mmdet-path list of image 1
+and the Uni-path list of image 2 must equal the reference's position by position with ZERO relaxations — under any K order (the
+test is also run with WEDETECT_P8=0 / WEDETECT_FUSE_MLP_WIDE toggled, profiles/r04_parity.jsonl).  One image from the middle of
+the batch goes through the CPU oracle's whole network on the box and must agree on embeddings / scores / boxes; its two kept
+lists are compared with the oracle's and asserted exact whenever the oracle's own effective margins on that image exceed 2e-5 (logged, not
+asserted, otherwise: the oracle's decision is then itself inside the noise); the post-process of EVERY image must equal the oracle's
 post-process run on the device's own score / box tensors bit for bit; two other images must come out bit-identical alone."""
 import numpy as np
 import pytest
@@ -65,7 +66,7 @@ def _run_config(arch, b, k, fixture, precision):
     tower.neck()
     for i, t in enumerate(tower.pyramid()):
         check_checksum(f"{tag} p{i+3}", t[: tower.nl[i]], fx, f"p{i+3}", 1e-3, 1e-3)
-    embed, boxes = tower.head()
+    embed, boxes = tower.head(num_classes=k)       # as detect() does: from 256 classes the similarity runs on the fp16x3 kernel (round 6)
     for l in range(3):
         check_checksum(f"{tag} embed{l}", embed[0, tower.off[l]:tower.off[l] + tower.nl[l]], fx, f"embed{l}", 1e-3, 1e-3)
     # ---- mmdet path: K-class normalised bank, thr 0.001, rescale before NMS (the judged similarity GEMM)
@@ -164,7 +165,7 @@ def _run_config(arch, b, k, fixture, precision):
     # ---- batch independence: two images alone, bit for bit
     t1 = ImageTower(arch, packed, 1, 640, 640, max_classes=max(k, 256), precision=precision)
     for i in (b // 2, b - 1):
-        t1.features(x[i:i + 1].contiguous())
+        t1.features(x[i:i + 1].contiguous(), num_classes=k)       # the same similarity kernel as the batch (fp16x3 from 256 classes)
         s1 = t1.similarity(text, normalize=True)
         r1 = t1.postprocess(s1, 0.001, meta[:1], with_embed=False, nms="mmcv")
         torch.cuda.synchronize()

@@ -236,8 +236,28 @@ def test_generate_proposal_and_retrieval_entries(tmp_path, monkeypatch):
         direct = model([str(tmp_path / "imgs" / im["file_name"])])[0]
         assert rec["image_id"] == im["id"] and set(rec) == {"image_id", "embedding", "scale", "bias"}
         assert rec["embedding"].shape == direct["embeddings"].shape and rec["embedding"].shape[0] <= 300
-        assert_close("record embeddings (batch 2 vs batch 1)", rec["embedding"], direct["embeddings"], 1e-5)
-        assert torch.equal(rec["scale"], direct["scales"].cpu()) and torch.equal(rec["bias"], direct["bias"].cpu())
+        # `model` is a SECOND detector instance: it chose its fp16x3 split scales from its own first batch (image 0 alone, the
+        # script's from images 0 + 1), so the two runs agree to fp32 rounding noise, not bit for bit (one instance does: an image
+        # gets the same bits in any batch shape, tests/test_gpu_detector.py) — the same rows within 1e-5, and a row may change
+        # places only with a row whose score is within that noise
+        de, sc_d = direct["embeddings"].cpu(), direct["scores"].cpu()
+        differ = ((rec["embedding"] - de).abs().amax(dim=1) > 1e-5).nonzero().flatten().tolist()
+        k = 0
+        while k < len(differ):                             # maximal runs of consecutive positions whose rows do not match in place
+            e = k
+            while e + 1 < len(differ) and differ[e + 1] == differ[e] + 1:
+                e += 1
+            run = differ[k:e + 1]
+            assert float(sc_d[run].max() - sc_d[run].min()) < 2e-6 * len(run), f"rows {run} moved across a score gap above the noise"
+            a, b_ = rec["embedding"][run], de[run]
+            order_b = sorted(range(len(run)), key=lambda r: b_[r, :8].round(decimals=4).tolist())
+            order_a = sorted(range(len(run)), key=lambda r: a[r, :8].round(decimals=4).tolist())
+            assert_close(f"rows {run} as a set", a[order_a], b_[order_b], 1e-5)
+            assert torch.equal(rec["scale"][run][order_a], direct["scales"].cpu()[run][order_b])
+            assert torch.equal(rec["bias"][run][order_a], direct["bias"].cpu()[run][order_b])
+            k = e + 1
+        same = [i for i in range(de.shape[0]) if i not in set(differ)]
+        assert torch.equal(rec["scale"][same], direct["scales"].cpu()[same]) and torch.equal(rec["bias"][same], direct["bias"].cpu()[same])
     # the reference's scoring lines run on the file (retrieval_metric.py:367-375)
     r0 = pred["image_embedding"][0]
     lg = torch.einsum("bw,kw->bk", r0["embedding"], pred["text_embedding"])

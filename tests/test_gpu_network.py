@@ -547,3 +547,61 @@ def test_layernorm_fold_tower_matches_the_layernorm_kernel_tower(arch, b, hw):
         assert_close(f"fold embeddings (calibrated={calibrate})", outs[1][0], outs[0][0], 5e-5, 1e-5)
         assert_close(f"fold boxes (calibrated={calibrate})", outs[1][1], outs[0][1], 1e-3)
         assert_close(f"fold scores (calibrated={calibrate})", outs[1][2], outs[0][2], 1e-5)
+
+
+@pytest.mark.parametrize("arch,b,hw,k_cls", [("nano", 3, 96, 300), ("tiny", 2, 128, 1203)])
+def test_similarity_on_the_fp16x3_kernel_matches_the_fp32_similarity(arch, b, hw, k_cls):
+    """Round 6: for banks of at least 256 rows the head writes the region embeddings twice (fp16 hi/lo groups + fp32, same
+    per-image row map) and similarity() runs wd_similarity_split.  The fp32 twin is BIT-identical to the single-output embedding
+    conv, the split copy is the split of it, scores agree with the fp32-MFMA similarity launch to 2e-6, a detect() step keeps the
+    same (anchor, label) lists except where two scores tie to within that difference, and small banks keep the fp32 kernel."""
+    if PRECISION["value"] != "fp16x3":
+        pytest.skip("the fp16x3 similarity kernel belongs to the fp16x3 tower")
+    from wedetect_amd import weights as W
+    _, t0, imgs = build(arch, b, hw, num_prompts=48)
+    _, t1, _ = build(arch, b, hw, num_prompts=48)
+    t0.sim_split = "0"
+    x = torch.from_numpy(imgs).cuda()
+    text = torch.from_numpy(W.make_text_bank(k_cls)).cuda()
+    t0.calibrate(x)
+    t1.adopt_scales(t0.sscale)
+    assert t1.want_sim_split(k_cls) and not t1.want_sim_split(80) and not t0.want_sim_split(k_cls)
+    e0, b0 = t0.features(x, num_classes=k_cls)
+    s0 = t0.similarity(text, normalize=True).clone()
+    e1, b1 = t1.features(x, num_classes=k_cls)
+    assert t1._embed_split_valid and t1.embed_s is not None and t0.embed_s is None
+    s1 = t1.similarity(text, normalize=True).clone()
+    torch.cuda.synchronize()
+    assert not bool(t1.range_flags.any())
+    assert torch.equal(e0, e1) and torch.equal(b0, b1)
+    sc = t1.sscale.get("embed", 1.0)
+    rows = b * t1.ntot
+    assert torch.equal(ImageTowerUnsplit(t1.embed_s[:rows], sc), e1.view(rows, -1)) or float(
+        (ImageTowerUnsplit(t1.embed_s[:rows], sc) - e1.view(rows, -1)).abs().max()) <= 2.0 ** -21 * float(e1.abs().max())
+    assert_close("fp16x3 similarity vs fp32 similarity", s1, s0, 2e-6)
+    # the same bank object again: split once (cache hit), same scores; an in-place update of the bank is seen
+    assert len(t1._text_split) == 1
+    s1b = t1.similarity(text, normalize=True)
+    assert torch.equal(s1b, s1) and len(t1._text_split) == 1
+    text.mul_(1.0)
+    t1.similarity(text, normalize=True)
+    assert len(t1._text_split) == 2
+    # small banks: fp32 kernel, no split copy written
+    t1.features(x, num_classes=80)
+    assert not t1._embed_split_valid
+    # whole steps
+    meta = t1.identity_meta()
+    meta[:, 7] = 1.0
+    r0 = {k: v.clone() for k, v in t0.detect(x, text, meta, normalize_text=True, score_thr=0.001).items()}
+    r1 = t1.detect(x, text, meta, normalize_text=True, score_thr=0.001)
+    torch.cuda.synchronize()
+    for i in range(b):
+        n0, n1 = int(r0["count"][i]), int(r1["count"][i])
+        a0 = set(zip(r0["anchors"][i, :n0].tolist(), r0["labels"][i, :n0].tolist()))
+        a1 = set(zip(r1["anchors"][i, :n1].tolist(), r1["labels"][i, :n1].tolist()))
+        assert len(a0 ^ a1) <= max(2, n0 // 50), (i, n0, n1, len(a0 ^ a1))
+
+
+def ImageTowerUnsplit(t, scale):
+    from wedetect_amd.engine import ImageTower
+    return ImageTower.unsplit(t, scale)

@@ -242,3 +242,36 @@ def test_fp16x3_on_a_heavy_tailed_checkpoint_at_base_640():
     print(f"[range] heavy-tailed Base@640: stream max / median {['%.0f' % v for v in streams]}; embeddings rms {rms:.3g}, max err / rms "
           f"{err_e:.3g}; scores max |d| {err_s:.3g}; {len(t.sscale)} of {len(amax)} tensors rescaled; kept {counts}")
     assert err_e <= 1e-3 and err_s <= 1e-3
+
+
+def test_calibrate_keeps_the_layernorm_kernel_for_blocks_with_a_large_mean_over_std():
+    """a block whose pre-norm rows have |mean| / std above engine.FOLD_MAX_MEAN_OVER_STD is NOT folded (its LayerNorm
+    kernel runs, `s{i}.{j}.fold_off` travels with the split scales); the other blocks keep the fold; the tower stays within 5e-5 of
+    the tower that folds nothing."""
+    import numpy as np
+    from wedetect_amd import weights as W
+    from wedetect_amd.engine import ImageTower
+    from wedetect_amd.pack import pack
+    arch, b, hw = "base", 1, 320
+    sd = W.make_state_dict(arch, num_prompts=16)
+    key = "backbone.image_model.model.stages.2.1.dwconv.bias"
+    assert key in sd, [k for k in sd if "dwconv.bias" in k][:3]
+    sd[key] = (sd[key] + np.float32(500.0)).astype(np.float32)      # every channel's depthwise output shifted: mean >> std over the channels
+    imgs = torch.from_numpy(W.make_images(b, hw, hw)).cuda()
+    t_fold, t_plain = ImageTower(arch, pack(sd, arch), b, hw, hw, precision="fp16x3"), ImageTower(arch, pack(sd, arch), b, hw, hw, precision="fp16x3")
+    t_plain.ln_fold = False
+    t_fold.calibrate(imgs)
+    t_plain.calibrate(imgs)
+    off = sorted(k for k in t_fold.sscale if k.endswith("fold_off"))
+    assert off == ["s2.1.fold_off"], off
+    e0, _ = t_plain.features(imgs)
+    e1, _ = t_fold.features(imgs)
+    torch.cuda.synchronize()
+    assert not bool(t_fold.range_flags.any())
+    assert float((e0 - e1).abs().max()) <= 5e-5 * max(1.0, float(e0.abs().max()))
+    # a second tower of the checkpoint adopts the decision with the scales; a re-calibration never re-enables the fold
+    t2 = ImageTower(arch, t_fold.P, b, hw, hw, precision="fp16x3")
+    t2.adopt_scales(t_fold.sscale)
+    assert t2.sscale.get("s2.1.fold_off") == 2.0
+    t_fold.calibrate(imgs, merge=True)
+    assert t_fold.sscale.get("s2.1.fold_off") == 2.0

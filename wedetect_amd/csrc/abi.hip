@@ -1,7 +1,7 @@
 // abi.hip — version / error-string entry points of libwedetect_hip.so.
 #include "common.h"
 
-extern "C" int wd_abi_version(void) { return 13; }
+extern "C" int wd_abi_version(void) { return 14; }
 
 extern "C" int wd_sizeof_conv_gemm(void) { return (int)sizeof(WdConvGemm); }
 

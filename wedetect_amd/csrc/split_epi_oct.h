@@ -10,8 +10,8 @@ namespace {
 // arithmetic, same order per element as epi_quad (split_gemm_impl.h).  Outputs, any combination the host asks for:
 //   CSPLIT : p.c receives [hi x8 | lo x8] groups (rows / batch-stride rows / the 2x2 deconv scatter)
 //   !CSPLIT: p.c receives fp32
-//   p.c2   : an fp32 copy in plain rows (ldc2) next to a CSPLIT output — for consumers that read fp32
-//            (the BottleRep "+ alpha x" residual, yolo_world_pafpn.py:602-605)
+//   p.c2   : an fp32 copy in plain rows (ldc2; with c_batch_stride: the rows of c) next to a CSPLIT output — for consumers
+//            that read fp32 (the BottleRep "+ alpha x" residual, yolo_world_pafpn.py:602-605; round 6: the region embeddings)
 // Host-side contract: n % 8 == 0, bias / res / c / c2 16-byte aligned, ldres % 4 == 0, ldc2 % 4 == 0,
 // ldc % 8 == 0 (CSPLIT) or % 4 == 0.
 // ---------------------------------------------------------------------------------------
@@ -44,7 +44,9 @@ __device__ __forceinline__ void epi_oct_core(const WdConvGemm& p, float unscale,
     }
   }
   if (p.c2 != nullptr) {
-    float* qp = p.c2 + (size_t)m * p.ldc2 + n;
+    // round 6: with c_batch_stride the fp32 twin takes the SAME per-image row mapping as c (the head's embedding conv writes
+    // [B, anchors, 768] twice: hi/lo groups for the fp16x3 similarity GEMM, fp32 for the gather and the callers)
+    float* qp = p.c2 + (SPECIAL && p.c_batch_stride > 0 ? er.crow : (size_t)m) * p.ldc2 + n;
     *reinterpret_cast<f32x4*>(qp) = o0;
     *reinterpret_cast<f32x4*>(qp + 4) = o1;
   }

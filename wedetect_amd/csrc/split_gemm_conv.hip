@@ -338,9 +338,8 @@ bool wd_conv_pp_ok(const WdConvGemm& p, int flags) {
   if (!wd_aligned16(p.a) || !wd_aligned16(p.c)) return false;
   if (p.bias && !wd_aligned16(p.bias)) return false;
   if (p.res && (!wd_aligned16(p.res) || p.ldres % 4)) return false;
-  if (p.c2 && (!(flags & WD_SPLIT_C) || !wd_aligned16(p.c2) || p.ldc2 % 4 || p.ldc2 < p.n || p.out_mode != WD_OUT_ROWS ||
-               p.c_batch_stride > 0))
-    return false;
+  if (p.c2 && (!(flags & WD_SPLIT_C) || !wd_aligned16(p.c2) || p.ldc2 % 4 || p.ldc2 < p.n || p.out_mode != WD_OUT_ROWS))
+    return false;                                     // (c_batch_stride: c2 takes c's row mapping, split_epi_oct.h)
   if ((flags & WD_SPLIT_C) ? (p.ldc % 8 != 0) : (p.ldc % 4 != 0)) return false;
   if (p.out_mode == WD_OUT_DECONV2X2 && (p.n % 32)) return false;
   return true;

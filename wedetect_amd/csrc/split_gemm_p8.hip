@@ -197,7 +197,8 @@ __device__ __forceinline__ void p8_retr_epilogue(const WdConvGemm& p, const P8Re
 template <int VAR, int ABL = 0, bool PERSIST = false>
 __global__ void __launch_bounds__(512, 2)
 split_gemm_p8_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, int k16, float unscale, int nbn,
-                     int vec_c, int vec_res, int vec_bias, int ngrp, int nbm, const P8Persist ps, const P8Retr rt, int stagger) {
+                     int vec_c, int vec_res, int vec_bias, int ngrp, int nbm, const P8Persist ps, const P8Retr rt, int stagger,
+                     int arows, int wrows) {
   constexpr int TM = 4, TN = 2, BM = 256, BN = 256, ROWB = P8_ROWB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int t = threadIdx.x, lane = t & 63;
@@ -283,7 +284,9 @@ split_gemm_p8_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, 
       const unsigned char* base = is_w ? wsp : abase;
       const unsigned pitch = (unsigned)(is_w ? k16 : p.lda) * 4u;
       // retrieval: any row counts — the operand buffers of wd_split_weights are padded to whole groups of eight rows
-      const int limit = (VAR & P8VAR_RETR) ? (((is_w ? p.n : p.m) + 7) & ~7) - 8 : (is_w ? p.n : p.m) - 8;
+      // arows / wrows: rows the operand BUFFERS hold, whole groups of eight (= p.m / p.n for the plain launches, which require
+      // multiples of eight; the similarity launch and the retrieval pad their buffers instead)
+      const int limit = (VAR & P8VAR_RETR) ? (((is_w ? p.n : p.m) + 7) & ~7) - 8 : (is_w ? wrows : arows) - 8;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         int row = is_w ? n0 + (2 * j + (wave >> 2)) * 64 + (wave & 3) * 8 + half * 32 : m0 + j * 128 + wave * 8 + half * 64;
@@ -528,6 +531,9 @@ split_gemm_p8_kernel(const WdConvGemm p, const unsigned char* __restrict__ wsp, 
       }
     } else if (epi_res_prefetch_ok(p, ev, nw, 64) && mw < p.m) {
       split_epilogue_res_prefetch<TM, TN, 3>(p, ev, mw, nw, lane_e, acc, patch);
+    } else if (!PERSIST && (p.seg_rows > 0 || p.sigmoid || p.out_scale != 1.0f || p.out_bias != 0.0f)) {
+      // round 6 (wd_similarity_split): per-level affine + sigmoid of the region x text logits, ragged n; no activation
+      split_epilogue_lds<TM, TN, WD_ACT_NONE, true>(p, ev, mw, nw, lane_e, acc, patch);
     } else {
       switch (p.act) {
         case WD_ACT_RELU: split_epilogue_lds<TM, TN, WD_ACT_RELU, false>(p, ev, mw, nw, lane_e, acc, patch); break;
@@ -569,13 +575,14 @@ int p8_stagger() {
 int p8_gang(int nbn) { return nbn % 8 == 0 ? 8 : nbn % 4 == 0 ? 4 : nbn % 2 == 0 ? 2 : 1; }
 
 template <int VAR, int ABL = 0, bool PERSIST = false>
-int launch_p8(const WdConvGemm& p, const void* wsp, float unscale, hipStream_t st, float* ws = nullptr, long long ws_floats = 0) {
+int launch_p8(const WdConvGemm& p, const void* wsp, float unscale, hipStream_t st, float* ws = nullptr, long long ws_floats = 0,
+              int arows = 0, int wrows = 0) {
   const int nbm = (p.m + 255) / 256, nbn = (p.n + 255) / 256;
   const long long nblk = (long long)nbm * nbn;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return WD_ERR_BAD_ARG;
   const int k16 = (p.k + 15) / 16 * 16;
   // 32-bit DMA offsets from the operand bases
-  if ((unsigned long long)p.m * p.lda * 4 >= (1ull << 32) || (unsigned long long)p.n * k16 * 4 >= (1ull << 32))
+  if ((unsigned long long)(arows > 0 ? arows : p.m) * p.lda * 4 >= (1ull << 32) || (unsigned long long)(wrows > 0 ? wrows : p.n) * k16 * 4 >= (1ull << 32))
     return WD_ERR_UNSUPPORTED;
   const int vec_c = (p.ldc % 4 == 0) && wd_aligned16(p.c);
   const int vec_res = p.res ? ((p.ldres % 4 == 0) && wd_aligned16(p.res)) : 0;
@@ -605,7 +612,7 @@ int launch_p8(const WdConvGemm& p, const void* wsp, float unscale, hipStream_t s
   static WdAttrOnce attr;
   if (wd_set_max_lds(attr, reinterpret_cast<const void*>(k), P8_LDS) != WD_OK) return WD_ERR_LAUNCH;
   WD_LAUNCH_GEMM(k, dim3((unsigned)grid), dim3(512), P8_LDS, st, p, static_cast<const unsigned char*>(wsp), k16, unscale, nbn,
-                 vec_c, vec_res, vec_bias, ngrp, nbm, ps, P8Retr{}, p8_stagger());
+                 vec_c, vec_res, vec_bias, ngrp, nbm, ps, P8Retr{}, p8_stagger(), arows > 0 ? arows : p.m, wrows > 0 ? wrows : p.n);
   return wd_launch_status();
 }
 
@@ -621,7 +628,7 @@ int launch_p8_retr(const WdConvGemm& p, const void* wsp, float unscale, const P8
   static WdAttrOnce attr;
   if (wd_set_max_lds(attr, reinterpret_cast<const void*>(k), P8_LDS) != WD_OK) return WD_ERR_LAUNCH;
   WD_LAUNCH_GEMM(k, dim3((unsigned)nblk), dim3(512), P8_LDS, st, p, static_cast<const unsigned char*>(wsp), k16, unscale, nbn,
-                 0, 0, 0, 8, nbm, P8Persist{nullptr, nullptr, nullptr, (int)nblk}, rt, 0);
+                 0, 0, 0, 8, nbm, P8Persist{nullptr, nullptr, nullptr, (int)nblk}, rt, 0, 0, 0);
   return wd_launch_status();
 }
 
@@ -696,4 +703,14 @@ int wd_launch_p8_retrieval(const void* t_split, int n_cls, const void* e_split, 
   p.out_scale = 1.0f;
   p.range_flag = range_flag;
   return launch_p8_retr(p, e_split, unscale, P8Retr{scale, bias, count, out, rows_per_img, ldo}, st);
+}
+
+// wd_similarity_split on the 256 x 256 kernel (round 6; yolo_world_head.py:90-108, generate_proposal.py:1129-1131): region rows
+// [rows][dim] as fp16 hi/lo groups (buffer padded to a multiple of eight rows) x text rows [n_cls][dim] split by
+// wd_split_weights_padded; out[row][cls] = (sigmoid)(<e, t> * unscale * seg_scale[level(row)] + seg_bias[level(row)]), the
+// epilogue of the fp32 similarity GEMM.  Ragged n_cls (1203) and ldo are fine (scalar stores when ldo % 4).
+int wd_launch_p8_similarity(const WdConvGemm& p, const void* t_split, float unscale, hipStream_t st) {
+  if (p.k % 32 || p.k < 32 || p.lda % 8 || !wd_aligned16(p.a) || !wd_aligned16(t_split)) return WD_ERR_UNSUPPORTED;
+  if (p.res || p.c2 || p.bias || p.act != WD_ACT_NONE || p.out_mode != WD_OUT_ROWS || p.c_batch_stride > 0 || p.ln_stats) return WD_ERR_UNSUPPORTED;
+  return launch_p8<0>(p, t_split, unscale, st, nullptr, 0, (p.m + 7) & ~7, (p.n + 7) & ~7);
 }

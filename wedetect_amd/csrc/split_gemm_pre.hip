@@ -595,7 +595,11 @@ extern "C" int wd_retrieval_max_split(const void* e_split, const void* t_split, 
   const bool use_p8 = !(env_p8 && env_p8[0] == '0');
   if (use_p8 && dim % 32 == 0 && wd_aligned16(scale) && wd_aligned16(bias) &&
       (unsigned long long)((n_rows + 7) & ~7ll) * dim * 4 < (1ull << 32)) {
-    const int chunk = 1 << 20;
+    // classes per launch: the kernel addresses the bank chunk with 32-bit byte offsets (a fixed 2^20 overran them from
+    // dim = 1024 and the error reached the caller after `out` had been zeroed)
+    long long chunk_ll = ((1ll << 32) - 1) / ((long long)dim * 4) - 8;
+    chunk_ll &= ~7ll;
+    const int chunk = (int)(chunk_ll < (1 << 20) ? chunk_ll : (1 << 20));
     for (long long c0 = 0; c0 < n_cls; c0 += chunk) {
       const int nc = (int)(n_cls - c0 < chunk ? n_cls - c0 : chunk);
       const int rc = wd_launch_p8_retrieval(static_cast<const unsigned char*>(t_split) + (size_t)c0 * dim * 4, nc, e_split, (int)n_rows,
@@ -613,4 +617,32 @@ extern "C" int wd_retrieval_max_split(const void* e_split, const void* t_split, 
   p.out_scale = 1.0f;
   const RetrArgs ra{scale, bias, count, out, rows_per_img, n_cls};
   return launch_pingpong<SVAR_RETRMAX, 3, 2>(p, t_split, t_unscale, st, ra);
+}
+
+int wd_launch_p8_similarity(const WdConvGemm& p, const void* t_split, float unscale, hipStream_t st);   // split_gemm_p8.hip
+
+// wd_similarity_split (ABI 14): the region x text similarity GEMM on the fp16x3 256 x 256 kernel.
+extern "C" int wd_similarity_split(const void* e_split, int64_t rows, const void* t_split, float unscale, float* out, int32_t n_cls,
+                                   int32_t dim, int32_t ldo, int32_t seg_rows, int32_t seg_end0, int32_t seg_end1,
+                                   const float* seg_scale, const float* seg_bias, int32_t sigmoid, uint32_t* range_flag, void* stream) {
+  if (!e_split || !t_split || !out || rows <= 0 || rows > 0x7ffffff0LL || n_cls <= 0 || dim <= 0 || ldo < n_cls || !(unscale > 0.f))
+    return WD_ERR_BAD_ARG;
+  if (seg_rows < 0 || (seg_rows > 0 && (!seg_scale || !seg_bias || !(0 <= seg_end0 && seg_end0 <= seg_end1 && seg_end1 <= seg_rows))))
+    return WD_ERR_BAD_ARG;
+  WdConvGemm p{};
+  p.a = static_cast<const float*>(e_split);
+  p.c = out;
+  p.batch = 1; p.hin = 1; p.win = (int)rows; p.cin = dim; p.lda = dim;
+  p.kh = p.kw = p.stride = 1; p.hout = 1; p.wout = (int)rows;
+  p.m = (int)rows; p.n = n_cls; p.k = dim; p.ldc = ldo;
+  p.out_scale = 1.0f;
+  p.sigmoid = sigmoid ? 1 : 0;
+  p.seg_rows = seg_rows; p.seg_end0 = seg_end0; p.seg_end1 = seg_end1;
+  for (int i = 0; i < 3; ++i) {
+    p.seg_scale[i] = seg_rows > 0 ? seg_scale[i] : 1.0f;
+    p.seg_bias[i] = seg_rows > 0 ? seg_bias[i] : 0.0f;
+  }
+  p.range_flag = range_flag;
+  if (!p.sigmoid && p.seg_rows == 0) return WD_ERR_UNSUPPORTED;   // a plain product: wd_conv_gemm_split covers it
+  return wd_launch_p8_similarity(p, t_split, unscale, static_cast<hipStream_t>(stream));
 }

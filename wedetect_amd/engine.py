@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import math
 import os
+import weakref
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -105,6 +106,7 @@ class ImageTower:
         self._side: List[torch.cuda.Stream] = []
         self._events: List[torch.cuda.Event] = []
         self._ev_i = 0
+        self._ev_after_neck = 0
         self._lane_i = 0
         self._fws_lane: Dict[int, torch.Tensor] = {}
         self._head_evs: List[torch.cuda.Event] = []
@@ -142,6 +144,17 @@ class ImageTower:
         # launches and 6 GB of HBM traffic per Base step less, +1.2 % (profiles/r05_ln_fold.txt).
         self.ln_fold = os.environ.get("WEDETECT_LN_FOLD", "1") == "1"
         self.ln_part = self.ln_stats = None
+        # round 6: the region x text similarity GEMM on the fp16x3 256 x 256 kernel for LARGE text banks (wd_similarity_split;
+        # yolo_world_head.py:90-108).  The 80-class launch is bound by its 86 MB of scores and 826 MB of embeddings, not by the fp32
+        # MFMA rate, and keeps the fp32 kernel; from 256 classes the contraction dominates (1203 classes: 2.3 of a 41 ms step at
+        # 0.67 of the fp32 MFMA peak = 106 TFLOP/s, against ~380 on the fp16x3 kernel).  The embedding conv then writes its output
+        # twice — fp16 hi/lo groups for this GEMM, fp32 for the gather and the callers (WdConvGemm.c2 with the batch-stride row map).
+        # $WEDETECT_SIM_SPLIT: "auto" (default) = banks of at least SIM_SPLIT_MIN rows, "1" = always, "0" = never.
+        self.sim_split = os.environ.get("WEDETECT_SIM_SPLIT", "auto")
+        self.embed_s: Optional[torch.Tensor] = None          # [round_up(B * anchors, 8), 768] hi/lo groups, allocated on first use
+        self._embed_split_on = False                          # the head of the step being issued writes embed_s
+        self._embed_split_valid = False                       # embed_s holds the split of self.embed
+        self._text_split: list = []                           # (weakref to the bank tensor, version, normalize, (split buffer, unscale))
         self.overflowed = False
         # sticky range flag of the fp16x3 GEMMs (WdConvGemm.range_flag): set by a launch whose accumulators are inf / NaN
         self.range_flags = torch.zeros(2, dtype=torch.int32, device=torch.device(device))
@@ -231,6 +244,7 @@ class ImageTower:
         self.lvl_scale = [float(np.exp(np.float32(self.P.s[f"head{l}.logit_scale"]))) for l in range(3)]
         self.lvl_bias = [float(np.float32(self.P.s[f"head{l}.bias"])) for l in range(3)]
         self.lvl_logit_scale = [float(np.float32(self.P.s[f"head{l}.logit_scale"])) for l in range(3)]
+        self._prepare_fold()
 
     def _alloc_post(self, k: int) -> None:
         self.max_classes = k
@@ -326,6 +340,24 @@ class ImageTower:
             return
         self.P.t[q + "w1g"], self.P.t[q + "u"], self.P.t[q + "v"] = fold_layernorm_into_linear(
             self.P[q + "w1"], self.P[q + "b1"], self.P[q + "ln_w"], self.P[q + "ln_b"])
+
+    def _prepare_fold(self) -> None:
+        """Statistics buffers and the folded weights (W', u, v) of every block whose LayerNorm is folded — in __init__, not lazily
+        inside backbone(): an allocation or the torch math of the fold must never land in a captured hipGraph."""
+        a = self.a
+        stages = [i for i in range(4)
+                  if self._fold_ok(i, self.precision == "fp16x3" and a.dims[i] % 8 == 0 and (i == 0 or a.dims[i - 1] % 8 == 0))]
+        if not stages:
+            return
+        if self.ln_stats is None:
+            rows = max(self.M[k] for k in range(4))
+            blk = max(self.M[k] * (a.dims[k] // 32) for k in range(4) if a.dims[k] % 32 == 0)
+            self.ln_part = torch.empty(2 * blk, dtype=torch.float32, device=self.dev)
+            self.ln_stats = torch.empty(2 * rows, dtype=torch.float32, device=self.dev)
+        if not torch.cuda.is_current_stream_capturing():
+            for i in stages:
+                for j in range(a.depths[i]):
+                    self._fold_weights(f"s{i}.{j}.")
 
     def _fold_ok(self, i: int, pre: bool) -> bool:
         c = self.a.dims[i]
@@ -494,13 +526,9 @@ class ImageTower:
                                stride=2, pad=0, n=c, ldc=c, split_flags=fa, a_key=f"down{i}.ln" if pre else None)
             for j in range(a.depths[i]):
                 q = f"s{i}.{j}."
-                if self._fold_ok(i, pre):
+                if self._fold_ok(i, pre) and not self.sscale.get(q + "fold_off"):
                     # LayerNorm folded into pwconv1: dwconv -> (split d, block statistics) -> row statistics -> GEMM
-                    if self.ln_stats is None:
-                        rows = max(self.M[k] for k in range(4))
-                        blk = max(self.M[k] * (a.dims[k] // 32) for k in range(4) if a.dims[k] % 32 == 0)
-                        self.ln_part = torch.empty(2 * blk, dtype=torch.float32, device=self.dev)
-                        self.ln_stats = torch.empty(2 * rows, dtype=torch.float32, device=self.dev)
+                    self._prepare_fold()            # buffers and folded weights exist since __init__; a switch flipped later lands here
                     self._fold_weights(q)
                     L.dwconv7_stats(self.x[i], self.P[q + "dw_w"], self.P[q + "dw_b"], self.tmp, self.ln_part, B, h, w, c,
                                     scale=self.sscale.get(q + "dw", 1.0))
@@ -518,6 +546,11 @@ class ImageTower:
                     L.dwconv7(self.x[i], self.P[q + "dw_w"], self.P[q + "dw_b"], self.tmp, B, h, w, c)
                     if self._calib is not None and self.ln_fold:
                         self._record(q + "dw", self.tmp[: self.M[i] * c])      # the folded path splits the pre-norm tensor itself
+                        # and centres AFTER the contraction: rstd (W'd - mean u) loses |mean| / std x 2^-22 of the output to
+                        # cancellation.  Record the worst row's |mean| / std; calibrate() keeps the LayerNorm kernel for a block
+                        # where it exceeds FOLD_MAX_MEAN_OVER_STD
+                        d = self.tmp[: self.M[i] * c].view(self.M[i], c)
+                        self._calib[q + "dw.mr"] = (d.mean(dim=1).abs() / d.std(dim=1, unbiased=False).clamp_min(1e-30)).max()
                     L.layernorm_rows(self.tmp, self.tmp, g_, b_, self.M[i], c, split=pre)
                 self._record(q + "ln", self.tmp[: self.M[i] * c])
                 if pre and self.fuse_mlp and L.mlp_fused_supported(self.M[i], c, 4 * c):
@@ -670,6 +703,7 @@ class ImageTower:
         self._conv(self.p4, "downsample1.w", "downsample1.b", self.cat_n4, hin=hw4[0], win=hw4[1], cin=nc["n3"],
                    lda=nc["n3"], n=nc["d1"], ldc=ld4, k=3, stride=2, act=L.ACT_RELU, split_flags=fl, a_key="p4", c_key="cat_n4")
         self._bepc3("Rep_n4", self.cat_n4, ld4, ld4, hw5, self.p5, nc["n4"], "cat_n4", "p5")
+        self._ev_after_neck = self._ev_i
         if _level_ready is not None:
             _level_ready(2)
         return [self.p3, self.p4, self.p5]
@@ -692,8 +726,14 @@ class ImageTower:
             self._conv(c1, f"head{l}.cls1.w", f"head{l}.cls1.b", c2, hin=h, win=w, cin=CLS_MID, lda=CLS_MID, n=CLS_MID,
                        ldc=CLS_MID, k=3, act=L.ACT_SILU, split_flags=fl, a_key=f"h{l}.c1", c_key=f"h{l}.c2")
             dst = self.embed.view(-1, EMBED_DIM)[self.off[l]:]
-            self._conv(c2, f"head{l}.embed.w", f"head{l}.embed.b", dst, hin=h, win=w, cin=CLS_MID, lda=CLS_MID,
-                       n=EMBED_DIM, ldc=EMBED_DIM, c_batch_stride=self.ntot, split_flags=fa, a_key=f"h{l}.c2")
+            if self._embed_split_on and S:
+                # hi/lo groups for the fp16x3 similarity GEMM + the fp32 rows everybody else reads, same per-image row map
+                self._conv(c2, f"head{l}.embed.w", f"head{l}.embed.b", self.embed_s[self.off[l]:], hin=h, win=w, cin=CLS_MID,
+                           lda=CLS_MID, n=EMBED_DIM, ldc=EMBED_DIM, c_batch_stride=self.ntot, split_flags=fl, a_key=f"h{l}.c2",
+                           c_key="embed", c2=dst, ldc2=EMBED_DIM)
+            else:
+                self._conv(c2, f"head{l}.embed.w", f"head{l}.embed.b", dst, hin=h, win=w, cin=CLS_MID, lda=CLS_MID,
+                           n=EMBED_DIM, ldc=EMBED_DIM, c_batch_stride=self.ntot, split_flags=fa, a_key=f"h{l}.c2")
 
         def reg_branch():
             r1, r2, dist = self.hr[l]
@@ -725,11 +765,39 @@ class ImageTower:
         self._after(*self._head_evs)
         self._head_evs = []
 
-    def head(self) -> Tuple[torch.Tensor, torch.Tensor]:
-        """Region embeddings (post contrastive-BN) [B, N, 768] and decoded boxes [B, N, 4]."""
+    SIM_SPLIT_MIN = 256
+    # LayerNorm fold (rstd (W'd - mean u) + v): the centring after the contraction costs |mean| / std x 2^-22 of relative accuracy
+    # on top of the fp16x3 kernels' own 2^-22; 64 keeps it at their level (1.5e-5).  A block beyond it keeps the LayerNorm kernel.
+    FOLD_MAX_MEAN_OVER_STD = 64.0
+
+    def want_sim_split(self, num_classes: Optional[int]) -> bool:
+        """Will similarity() of a ``num_classes``-row bank run on the fp16x3 kernel (so that the head must write the split
+        embeddings)?"""
+        if num_classes is None or self.precision != "fp16x3" or not self._neck_split() or self.sim_split == "0" or self._calib is not None:
+            return False
+        return self.sim_split == "1" or num_classes >= self.SIM_SPLIT_MIN
+
+    def _begin_head(self, num_classes: Optional[int], standalone: bool = False) -> None:
+        if standalone:
+            # a head() outside neck_head() (tests, diagnostics): rewind the event pool to where neck() left it, or repeated calls
+            # would take fresh events forever (ADVICE r5)
+            self._ev_i = self._ev_after_neck
+            self._head_evs = []
+        self._embed_split_on = self.want_sim_split(num_classes)
+        if self._embed_split_on and self.embed_s is None:
+            rows = (self.B * self.ntot + 7) // 8 * 8
+            self.embed_s = torch.empty(rows, EMBED_DIM, dtype=torch.float32, device=self.dev)
+            self.generation += 1
+        self._embed_split_valid = self._embed_split_on
+
+    def head(self, num_classes: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Region embeddings (post contrastive-BN) [B, N, 768] and decoded boxes [B, N, 4].  ``num_classes``: size of the text
+        bank similarity() will be called with (selects the fp16x3 similarity path for large banks, see __init__)."""
+        self._begin_head(num_classes, standalone=True)
         for l in range(3):
             self._head_level(l)
         self._head_join()
+        self._record("embed", self.embed)       # calibrate(): the split scale of the embeddings (every level written: the whole buffer)
         return self.embed, self.boxes
 
     # ------------------------------------------------------------------ similarity
@@ -746,14 +814,41 @@ class ImageTower:
             self.text_norm = torch.empty(k, EMBED_DIM, dtype=torch.float32, device=self.dev)
             self.generation += 1
         t = text.contiguous()
+        out = self.scores.view(-1)[: self.B * self.ntot * k].view(self.B, self.ntot, k)
+        seg = (self.ntot, self.off[1], self.off[2], self.lvl_scale, self.lvl_bias)
+        if self._embed_split_valid and self.precision == "fp16x3" and self.want_sim_split(k):
+            ts = self._split_text(t, normalize)
+            if ts is not None:
+                L.similarity_split(self.embed_s, self.B * self.ntot, ts[0], ts[1] / self.sscale.get("embed", 1.0), out, k, EMBED_DIM, k,
+                                   seg=seg, sigmoid=sigmoid, range_flag=self.range_flag)
+                return out
         if normalize:
             L.l2norm_rows(t, self.text_norm[:k])
             t = self.text_norm[:k]
-        out = self.scores.view(-1)[: self.B * self.ntot * k].view(self.B, self.ntot, k)
-        seg = (self.ntot, self.off[1], self.off[2], self.lvl_scale, self.lvl_bias)
         L.conv_gemm(self.embed, t, None, out, batch=1, hin=1, win=self.B * self.ntot, cin=EMBED_DIM, lda=EMBED_DIM,
                     n=k, ldc=k, sigmoid=sigmoid, seg=seg)
         return out
+
+    def _split_text(self, t: torch.Tensor, normalize: bool):
+        """fp16 hi/lo groups of the (normalised) text rows, split ONCE per bank: an entry is valid for the same tensor OBJECT
+        (held by weak reference: a new tensor that happens to land on a freed bank's address is another object) at the same
+        version counter (an in-place update bumps it).  Splitting reads max |t| on the host — one sync per NEW bank — so a bank
+        first seen under stream capture falls back to the fp32 kernel for that call (None).  Pass the bank as ONE contiguous
+        tensor that lives across calls, as the detectors do; a temporary is split on every call."""
+        for ref, ver, norm, ts in self._text_split:
+            if ref() is t and ver == t._version and norm == bool(normalize):
+                return ts
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        k = t.shape[0]
+        src = t
+        if normalize:
+            L.l2norm_rows(t, self.text_norm[:k])
+            src = self.text_norm[:k]
+        ts = L.split_weights(src)
+        self._text_split = [e for e in self._text_split if e[0]() is not None][-1:]     # the last two live banks
+        self._text_split.append((weakref.ref(t), t._version, bool(normalize), ts))
+        return ts
 
     # ------------------------------------------------------------------ post-process
     NMS_MODES = {"vanilla": L.NMS_VANILLA, "torchvision": L.NMS_TORCHVISION, "mmcv": L.NMS_MMCV}
@@ -822,6 +917,10 @@ class ImageTower:
         amax = dict(zip(keys, vals))
         new = {}
         for k, m in amax.items():
+            if k.endswith(".mr"):                             # worst |mean| / std of a block's pre-norm rows, not a range
+                if not (m <= self.FOLD_MAX_MEAN_OVER_STD):
+                    new[k[: -len("dw.mr")] + "fold_off"] = 2.0    # any value but 1.0: travels with the scales to every tower of the checkpoint
+                continue
             if math.isfinite(m) and m > 0.0:
                 sc = 2.0 ** (self.SCALE_TARGET_LOG2 - math.floor(math.log2(m)) - 1)      # max lands in [2^9, 2^10)
                 if sc != 1.0:
@@ -830,10 +929,12 @@ class ImageTower:
             # re-calibration after the range guard tripped: never RAISE a scale the earlier batch chose (both batches must
             # stay below the fp16 maximum) — per tensor the smaller of the two
             keys = set(new) | set(self.sscale)
-            new = {k: min(new.get(k, 1.0), self.sscale.get(k, 1.0)) for k in keys}
+            off = {k for k in keys if k.endswith("fold_off")}                  # a block that lost its fold keeps the LayerNorm kernel
+            new = {k: (2.0 if k in off else min(new.get(k, 1.0), self.sscale.get(k, 1.0))) for k in keys}
             new = {k: v for k, v in new.items() if v != 1.0}
         self.adopt_scales(new)
-        return amax
+        self.fold_mean_over_std = {k[: -len(".mr")]: v for k, v in amax.items() if k.endswith(".mr")}      # diagnostics
+        return {k: v for k, v in amax.items() if not k.endswith(".mr")}
 
     def adopt_scales(self, sscale: Dict[str, float]) -> None:
         """Take split scales chosen elsewhere (another tower of the same checkpoint: detector._TowerHolder calibrates ONCE per
@@ -854,20 +955,21 @@ class ImageTower:
         return (a >= self.off[1]).to(torch.int64) + (a >= self.off[2]).to(torch.int64)
 
     # ------------------------------------------------------------------ whole steps
-    def neck_head(self):
+    def neck_head(self, num_classes: Optional[int] = None):
         """Neck and head as ONE schedule: in DAG mode a head level is issued on the side lanes the moment its pyramid map
         exists (level 0 beside downsample2 -> Rep_n3 -> downsample1 -> Rep_n4, level 1 beside Rep_n4); otherwise the serial
         chain neck(); head()."""
         if not self._dag_on():
             self.neck()
-            return self.head()
+            return self.head(num_classes)
+        self._begin_head(num_classes)
         self.neck(_level_ready=self._head_level)
         self._head_join()
         return self.embed, self.boxes
 
-    def features(self, images_u8: torch.Tensor):
+    def features(self, images_u8: torch.Tensor, num_classes: Optional[int] = None):
         self.backbone(images_u8)
-        return self.neck_head()
+        return self.neck_head(num_classes)
 
     def detect(self, images_u8, text, meta, *, normalize_text: bool, score_thr: float, iou_thr: float = 0.7,
                with_embed: bool = False, nms: Optional[str] = None, nms_param: Optional[int] = None, nms_device: str = "cpu",
@@ -886,7 +988,7 @@ class ImageTower:
             nms = "mmcv" if normalize_text else "torchvision"
         if not overlap_post:
             self.wait_post()                      # a pipelined step may still be reading the buffers this one is about to write
-            self.features(images_u8)
+            self.features(images_u8, num_classes=text.shape[0])
             scores = self.similarity(text, normalize=normalize_text)
             return self.postprocess(scores, score_thr, meta, iou_thr, with_embed, nms, nms_param, nms_device)
         if self.post_stream is None:
@@ -896,11 +998,11 @@ class ImageTower:
         self.backbone(images_u8)
         if self._dag_on():
             self.wait_post()                  # head level 0 starts inside the neck: the previous post-process must be done with
-            self.neck_head()                  # boxes / embeddings before ANY head kernel is issued (it had the whole backbone)
+            self.neck_head(text.shape[0])     # boxes / embeddings before ANY head kernel is issued (it had the whole backbone)
         else:
             self.neck()
             self.wait_post()
-            self.head()
+            self.head(text.shape[0])
         scores = self.similarity(text, normalize=normalize_text)
         self._post_ready.record(main)
         # the caller's tensors are read by kernels on post_stream after this call returns: tell the caching allocator, or a

@@ -182,8 +182,6 @@ def retrieval_scores(records: List[dict], text_embedding: torch.Tensor, device="
                 raise ValueError(f"record of image {r.get('image_id')} is inconsistent with the text bank / itself")
             e[i, :n], sc[i, :n], bi[i, :n], cnt[i] = r["embedding"], r["scale"], r["bias"], n
         ed, sd, bd, cd = e.to(dev), sc.to(dev), bi.to(dev), cnt.to(dev)
-        if scorer.precision == "fp32" and rows > 320:
-            raise ValueError("the fp32 retrieval kernel takes at most 320 regions per image")
         scorer(ed, cd, sd, bd, out=out[lo:lo + len(chunk)])
     return out
 

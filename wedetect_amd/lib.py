@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("WEDETECT_LIB") or os.path.join(_HERE, "libwedetect_hi
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU = 0, 1, 2, 3
 OUT_ROWS, OUT_DECONV2X2 = 0, 1
 SPLIT_A, SPLIT_C = 1, 2
-ABI_VERSION = 13
+ABI_VERSION = 14
 NMS_VANILLA, NMS_TORCHVISION, NMS_MMCV = 0, 1, 2
 # torchvision/ops/boxes.py batched_nms: the per-class loop (_batched_nms_vanilla) above this many box coordinates
 # (boxes.numel()).  4000 / 20000 are the values of torchvision 0.15 ... 0.21 (the releases contemporary with the
@@ -32,7 +32,7 @@ EXPORTS = (
     "wd_abi_version", "wd_strerror", "wd_sizeof_conv_gemm", "wd_conv_gemm", "wd_conv_gemm_tuned", "wd_conv_gemm_config", "wd_stem_patchify", "wd_dwconv7", "wd_dwconv7_variant",
     "wd_layernorm_rows", "wd_l2norm_rows", "wd_dfl_decode", "wd_topk_workspace_bytes", "wd_topk_capacity",
     "wd_topk_candidates", "wd_nms_workspace_bytes", "wd_nms_gather", "wd_retrieval_max",
-    "wd_split_weights_bytes", "wd_split_weights", "wd_split_weights_padded", "wd_dwconv7_stats", "wd_ln_stats_finalize", "wd_conv_gemm_split", "wd_conv_gemm_split_ws", "wd_conv_gemm_split_config", "wd_layernorm_rows_split", "wd_layernorm_rows_split_s2d", "wd_letterbox_u8", "wd_retrieval_max_split", "wd_text_embed", "wd_attention_small", "wd_recall_scratch_floats", "wd_recall_match",
+    "wd_split_weights_bytes", "wd_split_weights", "wd_split_weights_padded", "wd_dwconv7_stats", "wd_ln_stats_finalize", "wd_conv_gemm_split", "wd_conv_gemm_split_ws", "wd_conv_gemm_split_config", "wd_layernorm_rows_split", "wd_layernorm_rows_split_s2d", "wd_letterbox_u8", "wd_retrieval_max_split", "wd_similarity_split", "wd_text_embed", "wd_attention_small", "wd_recall_scratch_floats", "wd_recall_match",
     "wd_max_sigmoid_attn", "wd_adaptive_maxpool_nhwc", "wd_cross_attention_small", "wd_time_next_gemm",
     "wd_cv_resize_paste_u8", "wd_chw_to_hwc_u8", "wd_p8_workspace_bytes", "wd_dwconv7_ln", "wd_probe_lds_dma", "wd_probe_issue", "wd_mlp_fused_split", "wd_mlp_fused_wide", "wd_stem_fused",
 )
@@ -105,6 +105,7 @@ def _load():
     lib.wd_split_weights.argtypes = [vp, i32, i32, f32, vp, vp]
     lib.wd_split_weights_padded.argtypes = [vp, i32, i32, f32, vp, vp]
     lib.wd_dwconv7_stats.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]
+    lib.wd_similarity_split.argtypes = [vp, i64, vp, f32, vp, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), i32, vp, vp]
     lib.wd_ln_stats_finalize.argtypes = [vp, vp, i64, i32, f32, vp]
     lib.wd_conv_gemm_split.argtypes = [C.POINTER(ConvGemm), vp, f32, i32, i32, vp]
     lib.wd_conv_gemm_split_ws.argtypes = [C.POINTER(ConvGemm), vp, f32, i32, i32, vp, i64, i32, vp]
@@ -422,6 +423,17 @@ def retrieval_max_split(e, t_split, scale, bias, count, out, n_img, rows_per_img
     check(LIB.wd_split_weights_padded(_p(rows), rows.shape[0], dim, 1.0, _p(es), stream_ptr()), "wd_split_weights_padded")
     check(LIB.wd_retrieval_max_split(_p(es), _p(t_split[0]), float(t_split[1]), _p(scale), _p(bias), _p(count), _p(out),
                                      n_img, rows_per_img, n_cls, dim, _p(range_flag), stream_ptr()), "wd_retrieval_max_split")
+
+
+def similarity_split(e_split, rows, t_split, unscale, out, n_cls, dim, ldo, seg=None, sigmoid=True, range_flag=None) -> None:
+    """Region x text similarity on the fp16x3 256 x 256 kernel (wd_similarity_split): ``e_split`` = embeddings as fp16 hi/lo
+    groups (buffer padded to a multiple of 8 rows), ``t_split`` = the text rows from :func:`split_weights`; ``seg`` as in
+    :func:`conv_gemm`; ``unscale`` = text unscale / embedding split scale."""
+    sr, e0, e1 = (int(seg[0]), int(seg[1]), int(seg[2])) if seg is not None else (0, 0, 0)
+    sc = (C.c_float * 3)(*[float(v) for v in (seg[3] if seg is not None else (1, 1, 1))])
+    sb = (C.c_float * 3)(*[float(v) for v in (seg[4] if seg is not None else (0, 0, 0))])
+    check(LIB.wd_similarity_split(_p(e_split), int(rows), _p(t_split), float(unscale), _p(out), int(n_cls), int(dim), int(ldo),
+                                  sr, e0, e1, sc, sb, int(bool(sigmoid)), _p(range_flag), stream_ptr()), "wd_similarity_split")
 
 
 def text_embed(ids, pos_ids, word, pos, type0, out) -> None:

@@ -313,29 +313,50 @@ class BankScorer:
     scorer then switches to the fp32-MFMA kernel (wd_retrieval_max) for good and repeats the call.  "fp32" = that kernel
     from the start.  Round 4 shipped the fp32 kernel here and kept the 2.5 x faster one for tests and scripts."""
 
-    def __init__(self, bank: torch.Tensor, precision: Optional[str] = None):
+    FP32_MAX_ROWS = 320          # wd_retrieval_max keeps an image's rows in one workgroup
+
+    def __init__(self, bank: torch.Tensor, precision: Optional[str] = None, hold_bank: bool = True):
+        """``hold_bank`` False (the module-level cache below): a bank that is already contiguous is held by WEAK reference only, so
+        that caching the scorer does not pin a 3 GB bank the caller has dropped; the fp32 kernel then needs the caller's
+        tensor to be alive, which it is for as long as the cache can hit."""
         import os
+        import weakref
         if precision is None:
             precision = os.environ.get("WEDETECT_RETRIEVAL_PRECISION", "fp16x3")
         if precision not in ("fp32", "fp16x3"):
             raise ValueError("precision must be 'fp32' or 'fp16x3'")
         if bank.dim() != 2 or bank.dtype != torch.float32 or not bank.is_cuda:
             raise ValueError("bank must be a device float32 [K, D] tensor")
-        self.bank = bank.contiguous()
+        cont = bank.contiguous()
+        self._bank = cont if (hold_bank or cont is not bank) else None
+        self._bank_ref = weakref.ref(bank) if self._bank is None else None
+        self.n_classes, self.dim = int(bank.shape[0]), int(bank.shape[1])
         self.precision = precision
         self.overflowed = False
         self._split = None
         self.flag = torch.zeros(1, dtype=torch.int32, device=bank.device)
 
+    @property
+    def bank(self) -> torch.Tensor:
+        b = self._bank if self._bank is not None else self._bank_ref()
+        if b is None:
+            raise RuntimeError("BankScorer: the text bank this scorer was built for has been freed")
+        return b
+
     def _launch(self, e, c, s, b, out):
         from . import lib as L
         n, r, d = e.shape
-        k = self.bank.shape[0]
+        k = self.n_classes
         if self.precision == "fp16x3" and d % 16 == 0:
             if self._split is None:
                 self._split = L.split_weights(self.bank)
             L.retrieval_max_split(e, self._split, s, b, c, out, n, r, k, d, range_flag=self.flag)
             return True
+        # the fp32 kernel — asked for, reached after a range trip, or because dim % 16 != 0: its row limit is checked HERE, with
+        # its own message, whatever ``precision`` read before the call (ADVICE r5)
+        if r > self.FP32_MAX_ROWS:
+            raise ValueError(f"the fp32 retrieval kernel takes at most {self.FP32_MAX_ROWS} regions per image, got {r} "
+                             f"(precision {self.precision!r}{', after a range trip' if self.overflowed else ''}, dim {d})")
         L.retrieval_max(e, self.bank, s, b, c, out, n, r, k, d)
         return False
 
@@ -344,7 +365,7 @@ class BankScorer:
         before it trusts the scores)."""
         n = embeddings.shape[0]
         if out is None:
-            out = torch.empty(n, self.bank.shape[0], dtype=torch.float32, device=embeddings.device)
+            out = torch.empty(n, self.n_classes, dtype=torch.float32, device=embeddings.device)
         e, c = embeddings.contiguous(), count.to(torch.int32).contiguous()
         s, b = scales.contiguous(), bias.contiguous()
         guarded = self._launch(e, c, s, b, out)
@@ -364,21 +385,29 @@ class BankScorer:
 _SCORERS: list = []      # small cache of (weakref to the bank, version, precision, BankScorer): splitting a 1M-class bank is a pass over 3 GB
 
 
+def clear_scorer_cache() -> None:
+    """Drops the cached scorers (and with them the split copies of their banks: 3 GB per 1M x 768 bank)."""
+    _SCORERS.clear()
+
+
 def device_retrieval_scores(embeddings: torch.Tensor, count: torch.Tensor, scales: torch.Tensor, bias: torch.Tensor,
-                            bank: torch.Tensor, precision: Optional[str] = None) -> torch.Tensor:
+                            bank: torch.Tensor, precision: Optional[str] = None, check: bool = True) -> torch.Tensor:
     """[N, K] fp32: max over an image's kept regions of sigmoid(<e, t_k> exp(scale) + bias) on the device
     (retrieval_metric.py:369-375).  ``embeddings`` [N, R, D], ``scales`` / ``bias`` [N, R], ``count`` [N].  Runs the fp16x3
-    kernel under its range guard by default (:class:`BankScorer`); the bank's split form is cached per bank tensor."""
+    kernel under its range guard by default (:class:`BankScorer`); the bank's split form is cached per bank tensor — by WEAK
+    reference: an entry dies with its bank (and takes the split copy with it), :func:`clear_scorer_cache` drops the rest.
+    ``check`` False skips the per-call host read of the range flag (a pipelined caller reads ``BankScorer.tripped()`` itself)."""
     import weakref
     # keyed by the tensor OBJECT (weak reference) and its version counter — never by address: a freed bank's address can be
     # handed to the next one, which would then be scored against the old split
+    _SCORERS[:] = [ent for ent in _SCORERS if ent[0]() is not None]
     for ref, ver, prec, sc in _SCORERS:
         if ref() is bank and ver == bank._version and prec == precision:
-            return sc(embeddings, count, scales, bias)
-    sc = BankScorer(bank, precision)
+            return sc(embeddings, count, scales, bias, check=check)
+    sc = BankScorer(bank, precision, hold_bank=False)
     _SCORERS.append((weakref.ref(bank), bank._version, precision, sc))
     del _SCORERS[:-2]
-    return sc(embeddings, count, scales, bias)
+    return sc(embeddings, count, scales, bias, check=check)
 
 
 def class_sharded_retrieval(embeddings: torch.Tensor, count: torch.Tensor, scales: torch.Tensor, bias: torch.Tensor,
