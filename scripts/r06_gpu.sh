@@ -101,6 +101,29 @@ fullsuite)
   cp gpurun_out/parity_r05.jsonl $OUT/parity.jsonl 2>/dev/null
   tail -25 $OUT/tests_full.log
   ;;
+smallb)
+  export TMPDIR=/tmp
+  BATCH=1 ALL=1 python scripts/neck_layer_times.py > $OUT/layers_b1.txt 2>&1
+  BATCH=8 ALL=1 python scripts/neck_layer_times.py > $OUT/layers_b8.txt 2>&1
+  python bench.py $Q --batch 1 > $OUT/bench_b1.json 2> $OUT/bench_b1.err
+  python bench.py $Q --batch 8 > $OUT/bench_b8.json 2> $OUT/bench_b8.err
+  WEDETECT_SPLIT_K=1 python bench.py $Q --batch 1 > $OUT/bench_b1_splitk.json 2> $OUT/bench_b1_splitk.err
+  WEDETECT_SPLIT_K=1 python bench.py $Q --batch 8 > $OUT/bench_b8_splitk.json 2> $OUT/bench_b8_splitk.err
+  rocprofv3 --kernel-trace --stats -d $OUT/trace -o p -- python bench.py --steps 20 --warmup 5 --batch 1 --no-cpu-baseline --no-fp32-reference --no-host-fed --no-other-configs > /dev/null 2> $OUT/trace.err
+  python scripts/rocpd_summary.py $(ls $OUT/trace/*.db | head -1) > $OUT/summary_b1.txt 2>&1
+  rm -rf $OUT/trace
+  line $OUT/bench_b*.json; head -40 $OUT/summary_b1.txt | cut -c1-120; grep "total" $OUT/layers_b1.txt $OUT/layers_b8.txt
+  ;;
+latency)
+  ( timeout 1200 python -m pytest tests/test_gpu_network.py -q -m gpu -k "latency or split_k" -x 2>&1 | tail -8 ) > $OUT/tests.log
+  for b in 1 2 4 8; do
+    WEDETECT_SPLIT_K=0 python bench.py $Q --batch $b > $OUT/bench_b${b}_off.json 2> $OUT/bench_b${b}_off.err
+    python bench.py $Q --batch $b > $OUT/bench_b${b}_auto.json 2> $OUT/bench_b${b}_auto.err
+  done
+  WEDETECT_SPLIT_K=0 python bench.py $Q --arch tiny --batch 1 > $OUT/bench_tiny_b1_off.json 2>/dev/null
+  python bench.py $Q --arch tiny --batch 1 > $OUT/bench_tiny_b1_auto.json 2>/dev/null
+  cat $OUT/tests.log; line $OUT/bench_*.json
+  ;;
 ceiling)
   WEDETECT_LIB=$GRAFT_REPO_ROOT/wedetect_amd/libwedetect_hip_abl.so python scripts/p8_ceiling.py > $OUT/p8_ceiling.jsonl 2> $OUT/p8_ceiling.err
   cat $OUT/p8_ceiling.jsonl; tail -3 $OUT/p8_ceiling.err

@@ -281,7 +281,7 @@ def test_split_k_latency_mode_matches_default_path():
     """Opt-in split-K (batch-1 latency mode): same detections as the default path up to fp32 summation-order noise."""
     if PRECISION["value"] != "fp16x3":
         pytest.skip("split-K exists for the fp16x3 kernels only")
-    _, t0, imgs = build("base", 1, 320, num_prompts=64)
+    _, t0, imgs = build("base", 1, 320, num_prompts=64, split_k=False)
     _, t1, _ = build("base", 1, 320, num_prompts=64, split_k=True)
     assert t0.kws is None and t1.kws is not None
     x = torch.from_numpy(imgs).cuda()
@@ -605,3 +605,42 @@ def test_similarity_on_the_fp16x3_kernel_matches_the_fp32_similarity(arch, b, hw
 def ImageTowerUnsplit(t, scale):
     from wedetect_amd.engine import ImageTower
     return ImageTower.unsplit(t, scale)
+
+
+def test_latency_mode_is_the_default_of_small_towers_and_batch_invariant(monkeypatch):
+    """Round 6: $WEDETECT_SPLIT_K=auto (the product default; the test session pins 0, conftest.py) turns the latency-mode split-K
+    on for towers of at most four 640 x 640 images and leaves large towers unsplit.  The split count of a layer comes from its
+    per-image geometry, never from the batch: the same image gets the SAME BITS alone and inside a batch of three (same class),
+    and results stay within fp32 summation noise of the unsplit tower."""
+    if PRECISION["value"] != "fp16x3":
+        pytest.skip("split-K exists for the fp16x3 kernels only")
+    from wedetect_amd.engine import ImageTower
+    monkeypatch.setenv("WEDETECT_SPLIT_K", "auto")
+    sd, t3, imgs = build("base", 3, 320, num_prompts=64, split_k=None)
+    _, t1, _ = build("base", 1, 320, num_prompts=64, split_k=None)
+    _, t0, _ = build("base", 3, 320, num_prompts=64, split_k=False)
+    assert t3.kws is not None and t1.kws is not None and t0.kws is None
+    assert 32 * 640 * 640 > ImageTower.SPLIT_K_AUTO_PIXELS >= 4 * 640 * 640           # the benchmark batch stays unsplit
+    x = torch.from_numpy(imgs).cuda()
+    t3.calibrate(x)
+    t1.adopt_scales(t3.sscale)
+    t0.adopt_scales(t3.sscale)
+    kw = dict(normalize_text=False, score_thr=0.0, with_embed=True)
+    r3 = {k: v.clone() for k, v in t3.detect(x, t3.P["prompts"], t3.identity_meta(), **kw).items()}
+    e3, s3 = t3.embed.clone(), t3.scores.view(-1)[: 3 * t3.ntot * 64].view(3, t3.ntot, 64).clone()
+    r0 = {k: v.clone() for k, v in t0.detect(x, t0.P["prompts"], t0.identity_meta(), **kw).items()}
+    e0 = t0.embed.clone()
+    for i in range(3):
+        r1 = t1.detect(x[i:i + 1].contiguous(), t1.P["prompts"], t1.identity_meta(), **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(t1.embed[0], e3[i]), f"image {i}: embeddings alone != in the batch of three"
+        assert torch.equal(t1.scores.view(-1)[: t1.ntot * 64].view(t1.ntot, 64), s3[i])
+        for k in ("bboxes", "scores", "labels", "anchors", "count", "embeddings"):
+            assert torch.equal(r1[k][0], r3[k][i]), f"image {i} {k} alone != in the batch of three"
+    assert_close("latency mode vs unsplit embeddings", e3, e0, 2e-5, 1e-5)
+    assert not torch.equal(e3, e0), "no layer was split: the test shapes no longer exercise the mode"
+    for i in range(3):
+        n0, n3 = int(r0["count"][i]), int(r3["count"][i])
+        a0 = set(zip(r0["anchors"][i, :n0].tolist(), r0["labels"][i, :n0].tolist()))
+        a3 = set(zip(r3["anchors"][i, :n3].tolist(), r3["labels"][i, :n3].tolist()))
+        assert len(a0 & a3) >= 0.97 * max(n0, 1)

@@ -46,6 +46,7 @@ def fold_layernorm_into_linear(w1: torch.Tensor, b1: torch.Tensor, gamma: torch.
 
 class ImageTower:
     PRECISIONS = ("fp32", "fp16x3")
+    SPLIT_K_AUTO_PIXELS = 4 * 640 * 640
 
     def __init__(self, arch, packed: Packed, batch: int, height: int, width: int, device="cuda",
                  max_classes: int = 256, nms_pre: int = 30000, max_out: int = 300,
@@ -70,9 +71,17 @@ class ImageTower:
         self.Ws: Dict[str, tuple] = {}          # weight name -> (split buffer, unscale), fp16x3 mode only
         # split-K workspace for under-filled fp16x3 launches (small batches, the coarsest maps): partial sums [S][m][n]
         if split_k is None:
-            split_k = os.environ.get("WEDETECT_SPLIT_K", "0") == "1"
+            # round 6: "auto" (default) = on for SMALL towers — at most SPLIT_K_AUTO_PIXELS input pixels per batch (four 640 x 640
+            # images) — where every long-K layer is one under-filled, K-sequential launch (Base batch 1: pwconv2 of a stage-3 block =
+            # 52 workgroups walking 128 K stages, 75 us for 3 GFLOP): 7.92 -> 5.08 ms per image, profiles/r06_small_batch.txt.  The
+            # reference runs batch 1 everywhere (infer_wedetect.py:117, generate_proposal.py:1261).  Large towers keep the unsplit
+            # launches, so an image's low-order bits differ between a small and a large tower (1e-6; deterministic within each
+            # class; the detectors' towers of one checkpoint agree bit for bit only inside a class).  "1" / "0" force.
+            env = os.environ.get("WEDETECT_SPLIT_K", "auto")
+            split_k = env == "1" or (env == "auto" and batch * height * width <= self.SPLIT_K_AUTO_PIXELS)
         self.kws = (torch.empty(16 << 20, dtype=torch.float32, device=torch.device(device))
                     if precision == "fp16x3" and split_k else None)
+        self._kws_lane: Dict[int, torch.Tensor] = {}          # the side lanes' own split-K workspaces (DAG mode)
         # Batch-INVARIANT split-K (on by default, $WEDETECT_FIXED_SPLITK=0 turns it off): the 3x3 convs on maps of at most
         # 20 x 20 pixels with K >= 2304 (BepC3 of the coarsest level, the level-2 head convs) always split K in two —
         # decided by the layer alone, never by the batch, so results stay bit-identical across batch sizes.  Base B = 32:
@@ -287,7 +296,15 @@ class ImageTower:
             if ws is None:                      # first use: split once, keep resident
                 wt = self.P[w]
                 ws = self.Ws[w] = L.split_weights(wt.view(wt.shape[0], -1))
-        work = self.kws if ws is not None else None
+        work = None
+        if ws is not None and self.kws is not None:
+            # latency mode: the split count comes from the layer's PER-IMAGE geometry (never from the batch), so that every tower
+            # of the small class gives an image the same bits whatever batch it arrives in
+            ks = self._latency_splits(kw)
+            if ks > 1:
+                kh_, st_, pd_ = kw.get("kh", 1), kw.get("stride", 1), kw.get("pad", 0)
+                m_ = self.B * ((kw["hin"] + 2 * pd_ - kh_) // st_ + 1) * ((kw["win"] + 2 * pd_ - kh_) // st_ + 1)
+                work, kw = self._lane_kws(ks * m_ * kw["n"] + 64), dict(kw, k_splits=ks)
         if (ws is not None and self.fixed_splitk and self.kws is None and kw.get("kh", 1) == 3 and kw.get("stride", 1) == 1
                 and kw["hin"] * kw["win"] <= 400 and 9 * kw["cin"] >= 2304 and kw["n"] % 4 == 0
                 and 2 * self.B * kw["hin"] * kw["win"] * kw["n"] <= self.fws.numel()):
@@ -333,6 +350,35 @@ class ImageTower:
                     self._record(c_key, c[: m * kw["ldc"]])
                 else:
                     self._record(c_key, c[..., : n // 4] if kw.get("out_mode", 0) == L.OUT_DECONV2X2 else c[..., :n])
+
+    def _latency_splits(self, kw) -> int:
+        """K splits of one layer in latency mode, from its geometry at batch ONE (the library's own rules — split_gemm.hip:
+        pick_ksplits and the implicit-GEMM kernel's — evaluated on a single image): 1 = launch unsplit."""
+        flags = kw.get("split_flags", 0)
+        kh, st, pd = kw.get("kh", 1), kw.get("stride", 1), kw.get("pad", 0)
+        n, k = kw["n"], kh * kh * kw["cin"]
+        if n % 4 or kw.get("ln_stats") is not None or "k_splits" in kw:
+            return 1
+        m1 = ((kw["hin"] + 2 * pd - kh) // st + 1) * ((kw["win"] + 2 * pd - kh) // st + 1)
+        plain = kh == 1 and st == 1 and pd == 0
+        special = (kw.get("out_mode", 0) != 0 or kw.get("c_batch_stride", 0) > 0 or kw.get("seg") is not None or kw.get("sigmoid")
+                   or kw.get("out_scale", 1.0) != 1.0 or kw.get("out_bias", 0.0) != 0.0)
+        covered = plain and not special and kw.get("c2") is None and not ((flags & L.SPLIT_C) and kw.get("res") is not None)
+        if (flags & L.SPLIT_A) and not covered:                    # implicit-GEMM LDS-DMA kernels (any epilogue): 256 x 128 tiles
+            if kw["cin"] % 16 or k % 16 or n % 8:
+                return 1
+            tiles, nk = -(-m1 // 256) * -(-n // 128), k // 16
+            if tiles >= 128 or nk < 32:
+                return 1
+            return max(1, min(256 // tiles, nk // 16, 8))
+        if flags & L.SPLIT_C:                                      # GEMM kernels that write hi/lo groups do not split K
+            return 1
+        if (flags & L.SPLIT_A) and not L.gemm_config(self.B * m1, n, k, split=True, presplit=True).endswith("/glds"):
+            return 1                                               # a 256-tile / ping-pong launch (never in the small class's shapes)
+        tiles, nk = -(-m1 // 128) * -(-n // 128), -(-k // 16)
+        if tiles >= 128 or nk < 16:
+            return 1
+        return max(1, min(512 // tiles, nk // 8, 16))
 
     def _fold_weights(self, q: str) -> None:
         """W', u, v of one block (fold_layernorm_into_linear), on the device, once (shared through the packed set)."""
@@ -432,8 +478,26 @@ class ImageTower:
     def _dag_on(self) -> bool:
         """Side streams are used for a step only outside the calibration pass (its recorders are torch ops on the current
         stream) and without the opt-in latency split-K (one shared workspace)."""
-        return (self.dag and self._calib is None and self.kws is None
+        return (self.dag and self._calib is None
                 and (self._dag_in_capture or not torch.cuda.is_current_stream_capturing()))
+
+    def _lane_kws(self, need: int = 0) -> Optional[torch.Tensor]:
+        """Latency-mode split-K workspace of the lane that is launching, at least ``need`` floats (None when the mode is off).
+        Grown on demand — the split count of a layer does not depend on the batch, its partial sums do — and only outside
+        stream capture (a captured step has run eagerly before: GraphedDetect warms up)."""
+        if self.kws is None:
+            return None
+        w = self.kws if self._lane_i == 0 else self._kws_lane.get(self._lane_i)
+        if w is None or w.numel() < need:
+            if torch.cuda.is_current_stream_capturing():
+                raise L.WedetectHipError("split-K workspace must be grown before stream capture (run the step eagerly once)")
+            w = torch.empty(max(need, self.kws.numel()), dtype=torch.float32, device=self.dev)
+            if self._lane_i == 0:
+                self.kws = w
+                self.generation += 1
+            else:
+                self._kws_lane[self._lane_i] = w
+        return w
 
     def _lane_fws(self) -> torch.Tensor:
         """Fixed split-K workspace of the lane that is launching: two lanes may run split-K convs at the same time."""
