@@ -162,6 +162,7 @@ class GemmTimer:
         self._orig_mlp = lib.mlp_fused
         self._orig_mlpw = lib.mlp_fused_wide
         self._orig_sim = lib.similarity_split
+        self._orig_mlpw_ln = lib.mlp_fused_wide_ln
 
     @staticmethod
     def _pair():
@@ -231,6 +232,18 @@ class GemmTimer:
             nbytes = 4.0 * (3 * rows * c + 2 * c * hidden)
             rec.setdefault(f"fp16x3 fused block MLP 128x({c}->{hidden}->{c})/4w/frag", []).append((s, e, 4.0 * rows * c * hidden, nbytes))
         lib.mlp_fused_wide = wrapped_mlpw
+        orig_mlpw_ln = self._orig_mlpw_ln
+
+        def wrapped_mlpw_ln(d_split, rows, c, hidden, *args, **kw):   # round 6: the same kernel with the LayerNorm folded in
+            if self.mode != "time":
+                self.count += self.mode == "count"
+                return orig_mlpw_ln(d_split, rows, c, hidden, *args, **kw)
+            s, e = self.pool.pop() if self.pool else self._pair()
+            lib.time_next_gemm(s, e)
+            orig_mlpw_ln(d_split, rows, c, hidden, *args, **kw)
+            nbytes = 4.0 * (3 * rows * c + 2 * c * hidden)
+            rec.setdefault(f"fp16x3 fused block MLP 128x({c}->{hidden}->{c})/4w/frag", []).append((s, e, 4.0 * rows * c * hidden, nbytes))
+        lib.mlp_fused_wide_ln = wrapped_mlpw_ln
         orig_sim = self._orig_sim
 
         def wrapped_sim(e_split, rows, t_split, unscale, out, n_cls, dim, ldo, **kw):   # round 6: the similarity GEMM on the fp16x3 kernel

@@ -192,6 +192,16 @@ int wd_mlp_fused_split(const void* a_split, int64_t rows, int32_t c, int32_t hid
 int wd_mlp_fused_wide(const void* a_split, int64_t rows, int32_t c, int32_t hidden, const void* w1_frag, float w1_unscale,
                       const float* b1, const void* w2_frag, float w2_unscale, const float* b2, float* x, float hid_scale,
                       uint32_t* range_flag, void* workspace, int64_t workspace_bytes, void* stream);
+/* wd_mlp_fused_wide_ln (ABI 14) — the same kernel with the block's LayerNorm FOLDED into pwconv1 (mm_backbone.py:113-124:
+ * dwconv -> norm -> pwconv1 -> GELU -> pwconv2 -> gamma -> residual, with WdConvGemm.ln_stats / ln_u semantics): d_split = the
+ * raw depthwise output written by wd_dwconv7_stats, ln_stats = wd_ln_stats_finalize's per-row (mean, rstd), w1g_frag = the
+ * fragment-major split of W1 * gamma, v = W1 beta + b1, u = (W1 gamma) 1:
+ *     x <- x + W2 GELU(rstd (W1g d - mean u) + v) + b2
+ * — the hidden epilogue of the two-launch fold, element for element (bit-identical to it).  c == 256. */
+int wd_mlp_fused_wide_ln(const void* d_split, int64_t rows, int32_t c, int32_t hidden, const void* w1g_frag, float w1_unscale,
+                         const float* v, const float* u, const float* ln_stats, const void* w2_frag, float w2_unscale,
+                         const float* b2, float* x, float hid_scale, uint32_t* range_flag, void* workspace,
+                         int64_t workspace_bytes, void* stream);
 
 /* Name of the tile wd_conv_gemm_split picks with cfg < 0 for an (m, n, k) problem; is_conv != 0:
  * not a 1x1 / stride 1 / pad 0 layer (diagnostic). */

@@ -124,6 +124,19 @@ latency)
   python bench.py $Q --arch tiny --batch 1 > $OUT/bench_tiny_b1_auto.json 2>/dev/null
   cat $OUT/tests.log; line $OUT/bench_*.json
   ;;
+foldfused)
+  ( timeout 1500 python -m pytest tests/test_gpu_split.py tests/test_gpu_network.py tests/test_gpu_precision.py -q -m gpu -k "fold or fused or precision or calibrat" -x 2>&1 | tail -8 ) > $OUT/tests.log
+  for i in 1 2; do
+    WEDETECT_LN_FOLD_FUSED=0 python bench.py $Q > $OUT/bench_off_$i.json 2> $OUT/bench_off_$i.err
+    python bench.py $Q > $OUT/bench_on_$i.json 2> $OUT/bench_on_$i.err
+  done
+  cat $OUT/tests.log; line $OUT/bench_o*.json
+  python - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/r06/foldfused/bench_o*_1.json')):
+    d=json.loads(open(f).read().strip().splitlines()[-1]); print(f.split('/')[-1], {k:v for k,v in d['gemm_kernels'].items() if 'fused' in k})
+PY
+  ;;
 ceiling)
   WEDETECT_LIB=$GRAFT_REPO_ROOT/wedetect_amd/libwedetect_hip_abl.so python scripts/p8_ceiling.py > $OUT/p8_ceiling.jsonl 2> $OUT/p8_ceiling.err
   cat $OUT/p8_ceiling.jsonl; tail -3 $OUT/p8_ceiling.err

@@ -928,3 +928,51 @@ def test_layernorm_fold_error_grows_with_mean_over_std(ratio):
     assert err <= (4.0 + ratio) * 2.0 ** -21, (ratio, err)
     if ratio >= 1000.0:
         assert err > 1e-5, "the bound is loose here: revisit FOLD_MAX_MEAN_OVER_STD"
+
+
+@pytest.mark.parametrize("m", [128, 128 * 37, 128 * 300])
+@pytest.mark.parametrize("hid_scale", [1.0, 0.25])
+def test_fused_mlp_wide_with_the_layernorm_folded_is_bit_identical_to_the_two_launch_fold(m, hid_scale):
+    """Round 6: wd_mlp_fused_wide_ln — the 256-channel one-kernel block MLP reading the RAW depthwise output and applying the
+    block's LayerNorm in its hidden epilogue (rstd (W'd - mean u) + v) — against the two launches of the round-5 fold (the 256 x 256
+    kernel with WdConvGemm.ln_stats / ln_u, then pwconv2 + residual): the same bits, tile form and persistent form, repeated
+    launches; and against float64 LayerNorm -> MLP."""
+    from wedetect_amd import lib as L
+    c, h = 256, 1024
+    d = _rand((m, c), 411, 2.0) + 0.7
+    x0 = _rand((m, c), 412, 1.5)
+    gam, bet = torch.rand(c, device="cuda") + 0.5, _rand((c,), 413, 0.1)
+    w1, b1 = _rand((h, c), 414, c ** -0.5), _rand((h,), 415, 0.1)
+    w2, b2 = _rand((c, h), 416, h ** -0.5), _rand((c,), 417, 0.1)
+    d64 = d.double()
+    stats = torch.stack([d64.mean(dim=1), 1.0 / torch.sqrt(d64.var(dim=1, unbiased=False) + 1e-6)], dim=1).float().contiguous()
+    w1g = (w1.double() * gam.double()[None, :]).float()
+    u = w1g.double().sum(dim=1).float()
+    v = (w1.double() @ bet.double() + b1.double()).float()
+    dsc = 4.0
+    ds = _to_split(d * dsc)
+    ws1, ws2 = L.split_weights(w1g), L.split_weights(w2)
+    ws1s, ws2s = (ws1[0], ws1[1] / dsc), (ws2[0], ws2[1] / hid_scale)
+    hid = torch.empty(m, h, device="cuda")
+    want = x0.clone()
+    L.conv_gemm(ds, None, v, hid, w_split=ws1s, batch=1, hin=1, win=m, cin=c, lda=c, n=h, ldc=h, act=L.ACT_GELU,
+                split_flags=L.SPLIT_A | L.SPLIT_C, c_split_scale=hid_scale, ln_stats=stats, ln_u=u)
+    L.conv_gemm(hid, None, b2, want, w_split=ws2s, batch=1, hin=1, win=m, cin=h, lda=h, n=c, ldc=c, res=want, ldres=c,
+                split_flags=L.SPLIT_A)
+    wf1, wf2 = (L.mlp_wide_pack(ws1[0], h, c), ws1s[1]), (L.mlp_wide_pack(ws2[0], c, h), ws2s[1])
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    park = torch.zeros(L.p8_workspace_bytes() // 4, dtype=torch.float32, device="cuda")
+    for ws in (None, park):
+        for _ in range(3):
+            got = x0.clone()
+            L.mlp_fused_wide_ln(ds, m, c, h, wf1, v, u, stats, wf2, b2, got, hid_scale=hid_scale, range_flag=flag, workspace=ws)
+            torch.cuda.synchronize()
+            assert torch.equal(got.view(torch.int32), want.view(torch.int32)), f"workspace {ws is not None}: max|d| {float((got - want).abs().max())}"
+            assert int(park[:1024].view(torch.int32).abs().max()) == 0
+    assert int(flag.item()) == 0
+    if m <= 128 * 37:
+        y = torch.nn.functional.layer_norm(d64, (c,), gam.double(), bet.double(), 1e-6)
+        ref = x0.double() + torch.nn.functional.gelu(y @ w1.double().T + b1.double()) @ w2.double().T + b2.double()
+        assert float((got.double() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+    with pytest.raises(L.WedetectHipError):
+        L.mlp_fused_wide_ln(ds, m, 512, 2048, wf1, v, u, stats, wf2, b2, got)

@@ -65,6 +65,11 @@ struct MwArgs {
   unsigned* flag;               // [workgroup]: 1 = the workgroup's parked accumulators are complete; reset by the consumer
   float* park;                  // [workgroup][4 TN2 accumulators x 4 quads][256 threads] x 16 B
   int nblk;                     // row blocks of 128
+  // round 6 (FOLD): the block's LayerNorm folded into pwconv1 — a = the RAW depthwise output (wd_dwconv7_stats), w1 = W1 gamma,
+  // b1 = W1 beta + b1, ln_u = (W1 gamma) 1, ln_stats = per-row (mean, rstd): hidden = GELU(rstd (W'd - mean u) + v), the
+  // epilogue of the two-launch fold (epi_lds_tile_csplit), element for element
+  const float* ln_stats;        // [m][2]
+  const float* ln_u;            // [H]
 };
 
 // one 1 KB LDS-DMA: 64 lanes x 16 B from base + voff[lane] to LDS [lds_addr, +1024).
@@ -145,7 +150,7 @@ __device__ __forceinline__ void mw_bload(f32x4& d, unsigned voff, const float* b
 // the previous workgroup of the XCD chain began: wait for its flag (set long before), reload the accumulators, continue the
 // chunk loop where it stopped — the same MFMA chain per output, carried by two CUs: bit-identical.  (The scheme of the
 // persistent 256 x 256 kernel, split_gemm_p8.hip.)
-template <int C, int ABL = 0, bool PERSIST = false>
+template <int C, int ABL = 0, bool PERSIST = false, bool FOLD = false>
 __global__ void __launch_bounds__(256) fused_mlp_wide_kernel(const MwArgs q) {
   using P = MW<C>;
   constexpr int TN2 = P::TN2, NKT = P::NKT;
@@ -205,6 +210,7 @@ __global__ void __launch_bounds__(256) fused_mlp_wide_kernel(const MwArgs q) {
   const unsigned char *w1w = w1w_, *w2w = w2w_;
   const unsigned bvoff = (unsigned)hsel * 16u;
   const float* b1p = q.b1 + wave * 32;                                 // bias quads: b1 + 128 j + 32 wave + 8 g + 4 hsel
+  const float* u1p = FOLD ? q.ln_u + wave * 32 : nullptr;              // FOLD: the u quads, same addressing
 
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
@@ -272,6 +278,9 @@ __global__ void __launch_bounds__(256) fused_mlp_wide_kernel(const MwArgs q) {
   h8 wh[2][4], wl[2][4];          // W1 fragments of K tiles t (buffer t & 1): refilled for tile t + 2 step by step
   h8 vh[2][TN2], vl[2][TN2];      // W2 fragments of k16 step S (buffer S & 1): refilled for step S + 2
   f32x4 bq[4];
+  f32x4 uq[4] = {};               // FOLD: u quads of the chunk, requested with the bias quads (4 more VMEM operations per chunk)
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  f32x2_ st[4] = {};              // FOLD: (mean, rstd) of this lane's four rows 32 i + r of the row block
 
   auto load_w1_tile = [&](int j, int kt, int buf) {              // all four steps of one K tile
     if ((ABL & 8) && (j > c0 || kt > 1)) return;
@@ -289,6 +298,11 @@ __global__ void __launch_bounds__(256) fused_mlp_wide_kernel(const MwArgs q) {
     const float* b = b1p + j * P::HC;
 #pragma unroll
     for (int g = 0; g < 4; ++g) mw_bload<PERSIST>(bq[g], bvoff, b + 8 * g);
+    if constexpr (FOLD) {
+      const float* u = u1p + j * P::HC;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) mw_bload<PERSIST>(uq[g], bvoff, u + 8 * g);
+    }
   };
 
   // prologue: K tiles 0 and 1 of chunk 0, their W1 fragments, the bias quads — drained ONCE, so that the counted waits of
@@ -299,7 +313,19 @@ __global__ void __launch_bounds__(256) fused_mlp_wide_kernel(const MwArgs q) {
   load_w1_tile(c0, 0, 0);
   load_w1_tile(c0, 1, 1);
   load_bias(c0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (FOLD) {
+    const float* sp = q.ln_stats + 2 * (size_t)m0;
+    MW_OPAQUE(sp);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned so = (unsigned)(32 * i + r) * 8u;
+      if constexpr (PERSIST) asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2" : "=&v"(st[i]) : "v"(so), "s"(sp) : "memory");
+      else asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(st[i]) : "v"(so), "s"(sp) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(st[0]), "+v"(st[1]), "+v"(st[2]), "+v"(st[3]) :: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
 
   for (int j = c0; j < c1; ++j) {
     const int jn1 = j + 1 < c1 ? j + 1 : j;
@@ -323,7 +349,10 @@ __global__ void __launch_bounds__(256) fused_mlp_wide_kernel(const MwArgs q) {
 #ifdef MW_EXPERIMENT_TILE_WAIT
         MW_WAIT8(MW_EXPERIMENT_TILE_WAIT, wh[BUF][0], wl[BUF][0], wh[BUF][1], wl[BUF][1], wh[BUF][2], wl[BUF][2], wh[BUF][3], wl[BUF][3]);
 #else
-        if constexpr (KT_ == 0 && TN2 == 2) MW_WAIT8(16, wh[BUF][0], wl[BUF][0], wh[BUF][1], wl[BUF][1], wh[BUF][2], wl[BUF][2], wh[BUF][3], wl[BUF][3]);   // a W2 step is 2 TN2 loads
+        // (FOLD: the u quads ride with the bias quads — every count that holds "bias (4)" holds 8)
+        if constexpr (KT_ == 0 && TN2 == 2 && FOLD) MW_WAIT8(20, wh[BUF][0], wl[BUF][0], wh[BUF][1], wl[BUF][1], wh[BUF][2], wl[BUF][2], wh[BUF][3], wl[BUF][3]);
+        else if constexpr (KT_ == 0 && TN2 == 2) MW_WAIT8(16, wh[BUF][0], wl[BUF][0], wh[BUF][1], wl[BUF][1], wh[BUF][2], wl[BUF][2], wh[BUF][3], wl[BUF][3]);   // a W2 step is 2 TN2 loads
+        else if constexpr (KT_ <= 1 && FOLD) MW_WAIT8(24, wh[BUF][0], wl[BUF][0], wh[BUF][1], wl[BUF][1], wh[BUF][2], wl[BUF][2], wh[BUF][3], wl[BUF][3]);
         else if constexpr (KT_ <= 1) MW_WAIT8(20, wh[BUF][0], wl[BUF][0], wh[BUF][1], wl[BUF][1], wh[BUF][2], wl[BUF][2], wh[BUF][3], wl[BUF][3]);
         else if constexpr (KT_ == NKT - 1) MW_WAIT8(8, wh[BUF][0], wl[BUF][0], wh[BUF][1], wl[BUF][1], wh[BUF][2], wl[BUF][2], wh[BUF][3], wl[BUF][3]);
         else MW_WAIT8(16, wh[BUF][0], wl[BUF][0], wh[BUF][1], wl[BUF][1], wh[BUF][2], wl[BUF][2], wh[BUF][3], wl[BUF][3]);
@@ -399,6 +428,7 @@ __global__ void __launch_bounds__(256) fused_mlp_wide_kernel(const MwArgs q) {
 #else
     asm volatile("s_waitcnt vmcnt(48)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]) :: "memory");
 #endif
+    if constexpr (FOLD) asm volatile("" : "+v"(uq[0]), "+v"(uq[1]), "+v"(uq[2]), "+v"(uq[3]));      // requested with the bias quads: complete with them
 
     // ================= bias + GELU + split of the wave's 128 x 32 piece -> hidden-chunk buffer
     // (every wave passed a K-tile barrier after its GEMM 2 of chunk j - 1: the buffer is free)
@@ -416,7 +446,10 @@ __global__ void __launch_bounds__(256) fused_mlp_wide_kernel(const MwArgs q) {
           const f32x4 v = {g1[i][4 * g], g1[i][4 * g + 1], g1[i][4 * g + 2], g1[i][4 * g + 3]};
           f32x4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = wd_gelu(fmaf(v[e], q.unscale1, bq[g][e]));
+          for (int e = 0; e < 4; ++e) {
+            if constexpr (FOLD) o[e] = wd_gelu(fmaf(st[i][1], fmaf(-st[i][0], uq[g][e], v[e] * q.unscale1), bq[g][e]));   // epi_lds_tile_csplit's fold
+            else o[e] = wd_gelu(fmaf(v[e], q.unscale1, bq[g][e]));
+          }
           if (q.hid_scale != 1.0f) o = o * q.hid_scale;            // power of two (exact); wave-uniform branch
           split4(o, hi[g], lo[g]);
         }
@@ -454,7 +487,7 @@ __global__ void __launch_bounds__(256) fused_mlp_wide_kernel(const MwArgs q) {
       static_assert(TN2 == 4 || TN2 == 2, "wait operand lists");
       if constexpr (TN2 == 4) {
 #define MW_W2WAIT(N) MW_WAIT8(N, vh[BUF][0], vl[BUF][0], vh[BUF][1], vl[BUF][1], vh[BUF][2], vl[BUF][2], vh[BUF][3], vl[BUF][3])
-        if constexpr (KS <= 4) MW_W2WAIT(8); else if constexpr (KS == 5) MW_W2WAIT(16); else if constexpr (KS == 6) MW_W2WAIT(24); else MW_W2WAIT(12);
+        if constexpr (KS <= 4) MW_W2WAIT(8); else if constexpr (KS == 5) MW_W2WAIT(16); else if constexpr (KS == 6) MW_W2WAIT(24); else if constexpr (FOLD) MW_W2WAIT(16); else MW_W2WAIT(12);
 #undef MW_W2WAIT
       } else {
 #ifdef MW_EXPERIMENT_ALL0
@@ -463,7 +496,7 @@ __global__ void __launch_bounds__(256) fused_mlp_wide_kernel(const MwArgs q) {
 #define MW_W2WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(vh[BUF][0]), "+v"(vl[BUF][0]), "+v"(vh[BUF][1]), "+v"(vl[BUF][1]) :: "memory")
 #endif
         // TN2 = 2: a W2 step is 4 loads
-        if constexpr (KS <= 4) MW_W2WAIT(4); else if constexpr (KS == 5) MW_W2WAIT(12); else if constexpr (KS == 6) MW_W2WAIT(20); else MW_W2WAIT(12);
+        if constexpr (KS <= 4) MW_W2WAIT(4); else if constexpr (KS == 5) MW_W2WAIT(12); else if constexpr (KS == 6) MW_W2WAIT(20); else if constexpr (FOLD) MW_W2WAIT(16); else MW_W2WAIT(12);
 #undef MW_W2WAIT
       }
       // hidden-chunk fragments: step KS + 1 is read behind the first eight MFMAs of step KS (see GEMM 1)
@@ -514,6 +547,7 @@ __global__ void __launch_bounds__(256) fused_mlp_wide_kernel(const MwArgs q) {
   MW_WAIT8(0, wh[0][0], wl[0][0], wh[0][1], wl[0][1], wh[0][2], wl[0][2], wh[0][3], wl[0][3]);
   asm volatile("" : "+v"(wh[1][0]), "+v"(wl[1][0]), "+v"(wh[1][1]), "+v"(wl[1][1]), "+v"(wh[1][2]), "+v"(wl[1][2]), "+v"(wh[1][3]), "+v"(wl[1][3]));
   asm volatile("" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]));
+  if constexpr (FOLD) asm volatile("" : "+v"(uq[0]), "+v"(uq[1]), "+v"(uq[2]), "+v"(uq[3]));
 #pragma unroll
   for (int jn = 0; jn < TN2; ++jn) asm volatile("" : "+v"(vh[0][jn]), "+v"(vl[0][jn]), "+v"(vh[1][jn]), "+v"(vl[1][jn]));
   MW_BARRIER();                                                   // ring and hidden buffer are free: epilogue patches
@@ -573,7 +607,7 @@ int mw_workgroups() {
   return slot;
 }
 
-template <int C, int ABL = 0>
+template <int C, int ABL = 0, bool FOLD = false>
 int launch_mlp_wide(MwArgs q, hipStream_t st, float* ws, long long ws_floats) {
   using P = MW<C>;
   const int nblk = q.m / P::BM;
@@ -591,13 +625,13 @@ int launch_mlp_wide(MwArgs q, hipStream_t st, float* ws, long long ws_floats) {
     q.flag = reinterpret_cast<unsigned*>(ws);                     // first 4 KB: flags (zero between launches)
     q.park = ws + 1024;
     static WdAttrOnce attr;
-    if (wd_set_max_lds(attr, reinterpret_cast<const void*>(fused_mlp_wide_kernel<C, ABL, true>), P::LDS) != WD_OK) return WD_ERR_LAUNCH;
-    WD_LAUNCH_GEMM((fused_mlp_wide_kernel<C, ABL, true>), dim3((unsigned)wgs), dim3(256), P::LDS, st, q);
+    if (wd_set_max_lds(attr, reinterpret_cast<const void*>(fused_mlp_wide_kernel<C, ABL, true, FOLD>), P::LDS) != WD_OK) return WD_ERR_LAUNCH;
+    WD_LAUNCH_GEMM((fused_mlp_wide_kernel<C, ABL, true, FOLD>), dim3((unsigned)wgs), dim3(256), P::LDS, st, q);
     return wd_launch_status();
   }
   static WdAttrOnce attr;
-  if (wd_set_max_lds(attr, reinterpret_cast<const void*>(fused_mlp_wide_kernel<C, ABL, false>), P::LDS) != WD_OK) return WD_ERR_LAUNCH;
-  WD_LAUNCH_GEMM((fused_mlp_wide_kernel<C, ABL, false>), dim3((unsigned)nblk), dim3(256), P::LDS, st, q);
+  if (wd_set_max_lds(attr, reinterpret_cast<const void*>(fused_mlp_wide_kernel<C, ABL, false, FOLD>), P::LDS) != WD_OK) return WD_ERR_LAUNCH;
+  WD_LAUNCH_GEMM((fused_mlp_wide_kernel<C, ABL, false, FOLD>), dim3((unsigned)nblk), dim3(256), P::LDS, st, q);
   return wd_launch_status();
 }
 
@@ -619,7 +653,7 @@ extern "C" int wd_mlp_fused_wide(const void* a_split, int64_t rows, int32_t c, i
   if (!(w1_unscale > 0.f) || !(w2_unscale > 0.f) || !(hid_scale > 0.f)) return WD_ERR_BAD_ARG;
   MwArgs q{static_cast<const unsigned char*>(a_split), static_cast<const unsigned char*>(w1_frag),
            static_cast<const unsigned char*>(w2_frag), b1, b2, x, range_flag, (int)rows, w1_unscale, w2_unscale, hid_scale,
-           nullptr, nullptr, 0};
+           nullptr, nullptr, 0, nullptr, nullptr};
   float* ws = static_cast<float*>(workspace);
   const long long wsf = workspace ? workspace_bytes / 4 : 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -640,4 +674,25 @@ extern "C" int wd_mlp_fused_wide(const void* a_split, int64_t rows, int32_t c, i
   }
 #endif
   return c == 512 ? launch_mlp_wide<512>(q, st, ws, wsf) : launch_mlp_wide<256>(q, st, ws, wsf);
+}
+
+// wd_mlp_fused_wide_ln (ABI 14): the same block MLP with the block's LayerNorm FOLDED into pwconv1 (WdConvGemm.ln_stats /
+// ln_u semantics): d_split = the raw depthwise output of wd_dwconv7_stats, w1g_frag = fragment-major split of W1 gamma,
+// v = W1 beta + b1, u = (W1 gamma) 1, ln_stats = wd_ln_stats_finalize's per-row (mean, rstd).  256 channels.
+extern "C" int wd_mlp_fused_wide_ln(const void* d_split, int64_t rows, int32_t c, int32_t hidden, const void* w1g_frag,
+                                    float w1_unscale, const float* v, const float* u, const float* ln_stats, const void* w2_frag,
+                                    float w2_unscale, const float* b2, float* x, float hid_scale, uint32_t* range_flag,
+                                    void* workspace, int64_t workspace_bytes, void* stream) {
+  if (workspace && (!wd_aligned16(workspace) || workspace_bytes < 0)) return WD_ERR_BAD_ARG;
+  if (!d_split || !w1g_frag || !w2_frag || !v || !u || !ln_stats || !b2 || !x) return WD_ERR_BAD_ARG;
+  if (c != 256 || hidden != 4 * c) return WD_ERR_UNSUPPORTED;
+  if (rows <= 0 || rows % 128 || rows / 128 > 0x7fffffffLL) return WD_ERR_UNSUPPORTED;
+  if (!wd_aligned16(d_split) || !wd_aligned16(w1g_frag) || !wd_aligned16(w2_frag) || !wd_aligned16(v) || !wd_aligned16(u) ||
+      !wd_aligned16(b2) || !wd_aligned16(x) || (reinterpret_cast<uintptr_t>(ln_stats) & 7u))
+    return WD_ERR_BAD_ARG;
+  if (!(w1_unscale > 0.f) || !(w2_unscale > 0.f) || !(hid_scale > 0.f)) return WD_ERR_BAD_ARG;
+  MwArgs q{static_cast<const unsigned char*>(d_split), static_cast<const unsigned char*>(w1g_frag),
+           static_cast<const unsigned char*>(w2_frag), v, b2, x, range_flag, (int)rows, w1_unscale, w2_unscale, hid_scale,
+           nullptr, nullptr, 0, ln_stats, u};
+  return launch_mlp_wide<256, 0, true>(q, static_cast<hipStream_t>(stream), static_cast<float*>(workspace), workspace ? workspace_bytes / 4 : 0);
 }

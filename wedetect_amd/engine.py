@@ -152,6 +152,9 @@ class ImageTower:
         # embeddings / scores, every golden and index-parity test green with it): $WEDETECT_LN_FOLD, default on — 30 LayerNorm
         # launches and 6 GB of HBM traffic per Base step less, +1.2 % (profiles/r05_ln_fold.txt).
         self.ln_fold = os.environ.get("WEDETECT_LN_FOLD", "1") == "1"
+        # round 6: the fold inside the wide one-kernel block MLP too (stage 2 of Base: dwconv -> LayerNorm kernel -> fused MLP becomes
+        # dwconv with statistics -> finalize -> fused MLP with the (mean, rstd, u, v) hidden epilogue); $WEDETECT_LN_FOLD_FUSED=0: A/B
+        self.ln_fold_fused = os.environ.get("WEDETECT_LN_FOLD_FUSED", "1") == "1"
         self.ln_part = self.ln_stats = None
         # round 6: the region x text similarity GEMM on the fp16x3 256 x 256 kernel for LARGE text banks (wd_similarity_split;
         # yolo_world_head.py:90-108).  The 80-class launch is bound by its 86 MB of scores and 826 MB of embeddings, not by the fp32
@@ -411,9 +414,34 @@ class ImageTower:
             return False
         if self.fuse_dwln == "1" or (self.fuse_dwln == "auto" and (c <= 128 or c in self.fuse_dwln_wide)):
             return False                        # dwconv + LayerNorm run as one kernel there
-        if (self.fuse_mlp and L.mlp_fused_supported(self.M[i], c, 4 * c)) or (c in self.fuse_mlp_wide and L.mlp_wide_supported(self.M[i], c, 4 * c)):
-            return False                        # the one-kernel block MLPs take LayerNorm rows
+        if self.fuse_mlp and L.mlp_fused_supported(self.M[i], c, 4 * c):
+            return False                        # the 128-channel one-kernel block MLP takes LayerNorm rows (its dwconv + LayerNorm is one kernel too)
+        if c in self.fuse_mlp_wide and L.mlp_wide_supported(self.M[i], c, 4 * c):
+            return self.ln_fold_fused and c in L.MLP_WIDE_FOLD_WIDTHS      # round 6: the wide one folds (256 channels)
         return True
+
+    def _mlp_fused_fold(self, q: str, i: int) -> None:
+        """Round 6: the wide one-kernel block MLP WITH the block's LayerNorm folded into its pwconv1 (wd_mlp_fused_wide_ln):
+        self.tmp holds the raw depthwise output as hi/lo groups (wd_dwconv7_stats), self.ln_stats the rows' (mean, rstd)."""
+        c = self.a.dims[i]
+        self._fold_weights(q)
+        ws = []
+        for name, (n_, k_) in ((q + "w1g", (4 * c, c)), (q + "w2", (c, 4 * c))):
+            f_ = self.Wf.get(name)
+            if f_ is None:
+                s_ = self.Ws.get(name)
+                if s_ is None:
+                    wt = self.P[name]
+                    s_ = self.Ws[name] = L.split_weights(wt.view(wt.shape[0], -1))
+                f_ = self.Wf[name] = (L.mlp_wide_pack(s_[0], n_, k_), s_[1])
+            ws.append(f_)
+        sa, sh = self.sscale.get(q + "dw", 1.0), self.sscale.get(q + "hid", 1.0)
+        if self._park_mlp is None:
+            self._park_mlp = self.park if self.park is not None else torch.zeros(
+                max(1, L.p8_workspace_bytes() // 4), dtype=torch.float32, device=self.dev)
+        L.mlp_fused_wide_ln(self.tmp, self.M[i], c, 4 * c, (ws[0][0], ws[0][1] / sa), self.P[q + "v"], self.P[q + "u"], self.ln_stats,
+                            (ws[1][0], ws[1][1] / sh), self.P[q + "b2"], self.x[i], hid_scale=sh, range_flag=self.range_flag,
+                            workspace=self._park_mlp)
 
     def _mlp_fused(self, q: str, i: int, wide: bool = False) -> None:
         """One ConvNeXt block MLP as a single launch: the 4c hidden activation never leaves the CU (wd_mlp_fused_split for the
@@ -597,6 +625,9 @@ class ImageTower:
                     L.dwconv7_stats(self.x[i], self.P[q + "dw_w"], self.P[q + "dw_b"], self.tmp, self.ln_part, B, h, w, c,
                                     scale=self.sscale.get(q + "dw", 1.0))
                     L.ln_stats_finalize(self.ln_part, self.ln_stats, self.M[i], c)
+                    if c in self.fuse_mlp_wide and L.mlp_wide_supported(self.M[i], c, 4 * c):
+                        self._mlp_fused_fold(q, i)
+                        continue
                     self._conv(self.tmp, q + "w1g", q + "v", self.hid, hin=h, win=w, cin=c, lda=c, n=4 * c, ldc=4 * c,
                                act=L.ACT_GELU, split_flags=L.SPLIT_A | L.SPLIT_C, a_key=q + "dw", c_key=q + "hid",
                                ln_stats=self.ln_stats, ln_u=self.P[q + "u"])

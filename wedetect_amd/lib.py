@@ -32,7 +32,7 @@ EXPORTS = (
     "wd_abi_version", "wd_strerror", "wd_sizeof_conv_gemm", "wd_conv_gemm", "wd_conv_gemm_tuned", "wd_conv_gemm_config", "wd_stem_patchify", "wd_dwconv7", "wd_dwconv7_variant",
     "wd_layernorm_rows", "wd_l2norm_rows", "wd_dfl_decode", "wd_topk_workspace_bytes", "wd_topk_capacity",
     "wd_topk_candidates", "wd_nms_workspace_bytes", "wd_nms_gather", "wd_retrieval_max",
-    "wd_split_weights_bytes", "wd_split_weights", "wd_split_weights_padded", "wd_dwconv7_stats", "wd_ln_stats_finalize", "wd_conv_gemm_split", "wd_conv_gemm_split_ws", "wd_conv_gemm_split_config", "wd_layernorm_rows_split", "wd_layernorm_rows_split_s2d", "wd_letterbox_u8", "wd_retrieval_max_split", "wd_similarity_split", "wd_text_embed", "wd_attention_small", "wd_recall_scratch_floats", "wd_recall_match",
+    "wd_split_weights_bytes", "wd_split_weights", "wd_split_weights_padded", "wd_dwconv7_stats", "wd_ln_stats_finalize", "wd_conv_gemm_split", "wd_conv_gemm_split_ws", "wd_conv_gemm_split_config", "wd_layernorm_rows_split", "wd_layernorm_rows_split_s2d", "wd_letterbox_u8", "wd_retrieval_max_split", "wd_similarity_split", "wd_mlp_fused_wide_ln", "wd_text_embed", "wd_attention_small", "wd_recall_scratch_floats", "wd_recall_match",
     "wd_max_sigmoid_attn", "wd_adaptive_maxpool_nhwc", "wd_cross_attention_small", "wd_time_next_gemm",
     "wd_cv_resize_paste_u8", "wd_chw_to_hwc_u8", "wd_p8_workspace_bytes", "wd_dwconv7_ln", "wd_probe_lds_dma", "wd_probe_issue", "wd_mlp_fused_split", "wd_mlp_fused_wide", "wd_stem_fused",
 )
@@ -127,6 +127,7 @@ def _load():
     lib.wd_dwconv7_ln.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]
     lib.wd_mlp_fused_split.argtypes = [vp, i64, i32, i32, vp, f32, vp, vp, f32, vp, vp, f32, vp, vp]
     lib.wd_mlp_fused_wide.argtypes = [vp, i64, i32, i32, vp, f32, vp, vp, f32, vp, vp, f32, vp, vp, i64, vp]
+    lib.wd_mlp_fused_wide_ln.argtypes = [vp, i64, i32, i32, vp, f32, vp, vp, vp, vp, f32, vp, vp, f32, vp, vp, i64, vp]
     lib.wd_stem_fused.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, i32, f32, vp, vp]
     lib.wd_probe_issue.argtypes = [i32, i32, i32, i32, i32, vp, vp, vp]
     lib.wd_probe_lds_dma.argtypes = [vp, i64, i32, i32, i32, i32, vp, vp]
@@ -208,6 +209,7 @@ def mlp_fused_supported(rows: int, c: int, hidden: int) -> bool:
 
 
 MLP_WIDE_WIDTHS = (256, 512)
+MLP_WIDE_FOLD_WIDTHS = (256,)          # wd_mlp_fused_wide_ln
 
 
 def mlp_wide_supported(rows: int, c: int, hidden: int) -> bool:
@@ -233,6 +235,15 @@ def mlp_fused_wide(a_split, rows, c, hidden, w1_frag, b1, w2_frag, b2, x, hid_sc
                                 float(w2_frag[1]), _p(b2), _p(x), float(hid_scale), _p(range_flag), _p(workspace), ws_bytes,
                                 stream_ptr()),
           "wd_mlp_fused_wide")
+
+
+def mlp_fused_wide_ln(d_split, rows, c, hidden, w1g_frag, v, u, ln_stats, w2_frag, b2, x, hid_scale=1.0, range_flag=None, workspace=None) -> None:
+    """The wide one-kernel block MLP with the block's LayerNorm folded into pwconv1 (wd_mlp_fused_wide_ln, c = 256):
+    x <- x + W2 GELU(rstd (W1g d - mean u) + v) + b2; ``d_split`` / ``ln_stats`` from dwconv7_stats / ln_stats_finalize."""
+    ws_bytes = 0 if workspace is None else workspace.numel() * workspace.element_size()
+    check(LIB.wd_mlp_fused_wide_ln(_p(d_split), rows, c, hidden, _p(w1g_frag[0]), float(w1g_frag[1]), _p(v), _p(u), _p(ln_stats),
+                                   _p(w2_frag[0]), float(w2_frag[1]), _p(b2), _p(x), float(hid_scale), _p(range_flag), _p(workspace),
+                                   ws_bytes, stream_ptr()), "wd_mlp_fused_wide_ln")
 
 
 def mlp_fused(a_split, rows, c, hidden, w1_split, b1, w2_split, b2, x, hid_scale=1.0, range_flag=None) -> None:
