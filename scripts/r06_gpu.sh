@@ -137,6 +137,17 @@ for f in sorted(glob.glob('gpurun_out/r06/foldfused/bench_o*_1.json')):
     d=json.loads(open(f).read().strip().splitlines()[-1]); print(f.split('/')[-1], {k:v for k,v in d['gemm_kernels'].items() if 'fused' in k})
 PY
   ;;
+fsplitk)
+  for i in 1 2; do
+    WEDETECT_FIXED_SPLITK=r5 python bench.py $Q > $OUT/bench_r5_$i.json 2> $OUT/bench_r5_$i.err
+    python bench.py $Q > $OUT/bench_r6_$i.json 2> $OUT/bench_r6_$i.err
+  done
+  WEDETECT_FIXED_SPLITK=r5 python bench.py $Q --arch large --batch 16 --classes 1203 > $OUT/large_r5.json 2> $OUT/large_r5.err
+  python bench.py $Q --arch large --batch 16 --classes 1203 > $OUT/large_r6.json 2> $OUT/large_r6.err
+  OUT=$OUT/layers.json python scripts/neck_layer_times.py > $OUT/layers.txt 2>&1
+  ( timeout 1500 python -m pytest tests/test_gpu_network.py tests/test_gpu_configs.py -q -m gpu -x 2>&1 | tail -6 ) > $OUT/tests.log
+  line $OUT/bench_r*.json $OUT/large_r*.json; grep "downsample1\|head2.reg0\|total" $OUT/layers.txt; cat $OUT/tests.log
+  ;;
 ceiling)
   WEDETECT_LIB=$GRAFT_REPO_ROOT/wedetect_amd/libwedetect_hip_abl.so python scripts/p8_ceiling.py > $OUT/p8_ceiling.jsonl 2> $OUT/p8_ceiling.err
   cat $OUT/p8_ceiling.jsonl; tail -3 $OUT/p8_ceiling.err
