@@ -951,6 +951,7 @@ def main():
                            "fp16x3 step is within 5e-5 (embeddings) / 1e-5 (scores) of the fp32 step at this size "
                            "(tests/test_gpu_precision.py); --precision fp32 runs native fp32 MFMA"} if split else {}),
                        "kept_regions_last_step_rank0": kept, "fp16x3_range_guard_tripped": overflow,
+                       "fp16x3_trips": int(tower.fp16x3_trips) + int(overflow),      # ImageTower's counter (checked_counts) + this run's raw flags
                        "gemm_gflop_per_image": round(flops_img / 1e9, 2)},
             "roofline": {"kernel": dom_kernel, "bound": "mfma",
                          "achieved": round(dom["tflops"], 2), "peak": dom_peak, "unit": "TFLOP/s",

@@ -275,3 +275,47 @@ def test_calibrate_keeps_the_layernorm_kernel_for_blocks_with_a_large_mean_over_
     assert t2.sscale.get("s2.1.fold_off") == 2.0
     t_fold.calibrate(imgs, merge=True)
     assert t_fold.sscale.get("s2.1.fold_off") == 2.0
+
+
+def test_a_fallen_back_tower_returns_to_fp16x3_after_clean_batches(monkeypatch):
+    """Round 6: trip -> fp32 fallback -> FALLBACK_RETRY clean batches -> re-calibration on the current batch ->
+    fp16x3 again -> stays.  A second trip doubles the waiting time.  ``fp16x3_trips`` / ``fp16x3_retries`` count."""
+    import warnings
+    from wedetect_amd import weights as W
+    from wedetect_amd.engine import ImageTower
+    from wedetect_amd.pack import pack
+    monkeypatch.setattr(ImageTower, "FALLBACK_RETRY", 3)
+    arch, b, hw = "nano", 2, 128
+    t = ImageTower(arch, pack(W.make_state_dict(arch, num_prompts=32), arch), b, hw, hw, precision="fp16x3")
+    ok = torch.from_numpy(W.make_images(b, hw, hw, seed=5)).cuda()
+    meta = t.identity_meta()
+    kw = dict(normalize_text=False, score_thr=0.0, with_embed=True)
+
+    def step(x):
+        run = lambda: t.detect(x, t.P["prompts"], meta, **kw)
+        return t.checked_counts(run(), run, lambda: t.calibrate(x, merge=True))
+    t.calibrate(ok)
+    step(ok)
+    assert t.precision == "fp16x3" and t.fp16x3_trips == 0
+    # force a trip the re-calibration cannot cure: raise the sticky flag by hand, with scales that do not change
+    def tripping_step(x):
+        run = lambda: t.detect(x, t.P["prompts"], meta, **kw)
+        res = run()
+        t.range_flags[0] = 1
+        with warnings.catch_warnings(record=True) as wrec:
+            warnings.simplefilter("always")
+            counts = t.checked_counts(res, run, lambda: t.calibrate(x, merge=True))
+        assert any("fp32 MFMA" in str(w.message) for w in wrec)
+        return counts
+    tripping_step(ok)
+    assert t.precision == "fp32" and t.overflowed and t.fp16x3_trips == 1 and t._retry_after == 3
+    ref = t.embed.clone()
+    step(ok); step(ok)
+    assert t.precision == "fp32" and t.fp16x3_retries == 0
+    step(ok)                                                   # the third clean batch: back to fp16x3 for the next step
+    assert t.precision == "fp16x3" and not t.overflowed and t.fp16x3_retries == 1
+    step(ok)
+    assert t.precision == "fp16x3" and t.fp16x3_trips == 1 and not bool(t.range_flags.any())
+    assert float((t.embed - ref).abs().max()) < 1e-4           # fp16x3 again, within rounding noise of the fp32 step
+    tripping_step(ok)                                          # a relapse: the wait doubles
+    assert t.precision == "fp32" and t.fp16x3_trips == 2 and t._retry_after == 6

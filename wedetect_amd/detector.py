@@ -110,6 +110,7 @@ class _TowerHolder:
             raise ValueError("nms_pre must be positive")
         self.arch = get_arch(arch)
         self.precision = precision
+        self._asked_precision = precision          # what the caller configured: restored when a fallen-back tower returns to fp16x3
         self.num_prompts = num_prompts
         self.max_classes, self.max_out, self.nms_pre = max_classes, max_out, nms_pre
         self._sd: Optional[Dict[str, np.ndarray]] = None
@@ -361,8 +362,9 @@ class SimpleYOLOWorldDetector(_DeviceModule):
         res = run()
         recal = (lambda: self._h.recalibrate(tower, x)) if self._h.auto_calibrate else None
         counts = tower.checked_counts(res, run, recal)      # one D2H sync per batch (+ the fp16x3 range guard)
-        if tower.overflowed:
-            self._h.precision = "fp32"                      # towers built later for other shapes start in fp32 too
+        # towers built later for other shapes start in fp32 too while this one is in its fallback (round 6: not for good — after
+        # ImageTower.FALLBACK_RETRY clean batches it re-calibrates and returns to fp16x3, and so does the holder's default)
+        self._h.precision = "fp32" if tower.overflowed else self._h._asked_precision
         return res, counts, tower
 
 
@@ -762,8 +764,7 @@ class YOLOWorldDetector(_DeviceModule):
             res = run()
             recal = (lambda: self._h.recalibrate(tower, x)) if self._h.auto_calibrate else None
             counts = tower.checked_counts(res, run, recal)
-            if tower.overflowed:
-                self._h.precision = "fp32"
+            self._h.precision = "fp32" if tower.overflowed else self._h._asked_precision
             for j, (i, n) in enumerate(zip(idxs, counts)):
                 inst = InstanceData(bboxes=res["bboxes"][j, :n].clone(), scores=res["scores"][j, :n].clone(),
                                     labels=res["labels"][j, :n].to(torch.int64))

@@ -168,6 +168,9 @@ class ImageTower:
         self._embed_split_valid = False                       # embed_s holds the split of self.embed
         self._text_split: list = []                           # (weakref to the bank tensor, version, normalize, (split buffer, unscale))
         self.overflowed = False
+        self.fp16x3_trips = 0            # range-guard trips of this tower (each: one re-calibration attempt, then the fp32 fallback)
+        self.fp16x3_retries = 0          # returns from the fp32 fallback to the fp16x3 kernels
+        self._clean_fp32_steps, self._retry_after = 0, self.FALLBACK_RETRY
         # sticky range flag of the fp16x3 GEMMs (WdConvGemm.range_flag): set by a launch whose accumulators are inf / NaN
         self.range_flags = torch.zeros(2, dtype=torch.int32, device=torch.device(device))
         self.range_flag = self.range_flags[0:1]
@@ -861,6 +864,7 @@ class ImageTower:
         self._head_evs = []
 
     SIM_SPLIT_MIN = 256
+    FALLBACK_RETRY, FALLBACK_RETRY_MAX = 64, 4096     # clean fp32 batches before a fallen-back tower tries fp16x3 again (doubles per relapse)
     # LayerNorm fold (rstd (W'd - mean u) + v): the centring after the contraction costs |mean| / std x 2^-22 of relative accuracy
     # on top of the fp16x3 kernels' own 2^-22; 64 keeps it at their level (1.5e-5).  A block beyond it keeps the LayerNorm kernel.
     FOLD_MAX_MEAN_OVER_STD = 64.0
@@ -1123,14 +1127,27 @@ class ImageTower:
         the fp16x3 GEMMs carry fp32 operands as fp16 (hi, lo) pairs, so an activation beyond 65504 becomes inf.  Every
         fp16x3 launch checks its accumulators in the epilogue and raises the tower's sticky ``range_flag`` on inf / NaN
         (a later ReLU would otherwise turn the NaN into a plausible 0), and the top-k kernel reports non-finite score
-        rows as count -1.  When either happens this tower switches to the fp32 MFMA kernels — for good: a checkpoint
-        that overflows once will again — and ``rerun()`` (the caller's closure that repeats the step) is executed once
-        more.  Raises if fp32 produces non-finite scores too.  ``recalibrate``: the caller's closure that re-derives the split
+        rows as count -1.  When either happens this tower switches to the fp32 MFMA kernels and ``rerun()`` (the caller's closure
+        that repeats the step) is executed once more; ``fp16x3_trips`` counts it.  Round 6: after ``FALLBACK_RETRY`` clean fp32
+        batches (doubling after every relapse, at most ``FALLBACK_RETRY_MAX``) the tower re-calibrates on the current batch and
+        returns to the fp16x3 kernels (``fp16x3_retries``) — rounds 1-5 stayed in fp32 "for good", at 0.4 x the throughput.  Raises if fp32 produces non-finite scores too.  ``recalibrate``: the caller's closure that re-derives the split
         scales from THIS batch (detector._TowerHolder.recalibrate: scales only ever go down, every tower of the checkpoint
         adopts them); it is tried once per trip before the fp32 fallback — a first batch of blank images may have chosen
         scales under which an ordinary image overflows, which is a calibration problem, not a checkpoint that needs fp32."""
         self.wait_post()                         # a pipelined step's counts are produced on post_stream: order the read behind it
         counts = res["count"].tolist()
+        if self.overflowed and self.precision == "fp32" and min(counts, default=0) >= 0:
+            # round 6: the fallback is no longer for good.  After FALLBACK_RETRY clean fp32 batches (doubling after every further
+            # trip, capped) the tower re-derives its split scales from the CURRENT batch (scales only go down) and returns to the
+            # fp16x3 kernels for the next step: one odd image in a long-running process no longer costs the rest of it 2.5 x
+            self._clean_fp32_steps += 1
+            if self._clean_fp32_steps >= self._retry_after and recalibrate is not None:
+                self.precision = "fp16x3"
+                recalibrate()                        # calibrate(merge=True) through the caller: its fp32 pass restores self.precision
+                self.overflowed, self._clean_fp32_steps = False, 0
+                self.range_flags.zero_()
+                self.fp16x3_retries += 1
+            return counts
         flags = self.range_flags.tolist() if self.precision == "fp16x3" else [0, 0]
         if flags[1] and not self.neck_pin:
             # a residual stream left the fp16 range in one of the neck layers that read it directly: pin those five layers to
@@ -1145,6 +1162,8 @@ class ImageTower:
         if min(counts, default=0) >= 0 and not tripped:
             return counts
         self.range_flags.zero_()
+        if self.precision == "fp16x3":
+            self.fp16x3_trips += 1
         if self.precision == "fp16x3" and recalibrate is not None:     # also with all-unit scales: a later batch may need scales < 1
             before = dict(self.sscale)
             recalibrate()
@@ -1160,6 +1179,8 @@ class ImageTower:
                       "the fp32 MFMA kernels (ImageTower(precision='fp32') avoids the detour)")
         self.precision = "fp32"
         self.overflowed = True
+        self._clean_fp32_steps = 0
+        self._retry_after = min(self.FALLBACK_RETRY_MAX, self.FALLBACK_RETRY if self.fp16x3_retries == 0 else 2 * self._retry_after)
         counts = rerun()["count"].tolist()
         if min(counts, default=0) < 0:
             raise L.WedetectHipError("non-finite scores in fp32 mode: the checkpoint or the inputs produce inf / NaN")
