@@ -76,6 +76,26 @@ KERNEL_SYMBOL = {
 }
 
 
+def power_ceiling():
+    """What the dominant kernel's K loop sustains on this chip with NO epilogue (VERDICT r5 #2a; scripts/p8_ceiling.py on an ablation
+    build, random data, 0.4 s of back-to-back launches per arm, shader clock sampled): the committed measurement, not a live one —
+    the ablation kernels are not part of the release library."""
+    path = os.path.join(ROOT, "profiles", "r06_p8_power_ceiling.jsonl")
+    try:
+        rows = [json.loads(l) for l in open(path) if l.strip()]
+        loop = [r for r in rows if r.get("kernel", "").startswith("k-loop only")]
+        by = {r["arm"].split()[0]: r for r in loop}
+        return {"frac": round(sum(r["frac_of_fp16x3_roof"] for r in (by["pw1"], by["pw2"])) / 2, 4),
+                "pwconv1_k_loop": {k: by["pw1"][k] for k in ("avg_us", "tflops", "frac_of_fp16x3_roof", "effective_mhz", "frac_at_effective_clock")},
+                "pwconv2_k_loop": {k: by["pw2"][k] for k in ("avg_us", "tflops", "frac_of_fp16x3_roof", "effective_mhz", "frac_at_effective_clock")},
+                "meaning": "fraction of the fp16x3 roof (2516.6 / 3 TF at 2.4 GHz) the 256 x 256 K loop reaches with its epilogue removed, "
+                           "stage-3 shapes of this workload: the chip sustains 1.6 - 1.75 GHz in it (power); `frac` above is the same "
+                           "kernel WITH its epilogues inside the step",
+                "source": "profiles/r06_p8_power_ceiling.jsonl (scripts/p8_ceiling.py, -DWD_DEBUG_ABLATIONS build)"}
+    except Exception as ex:                      # the file is evidence, not a dependency of the measurement
+        return {"frac": None, "source": f"profiles/r06_p8_power_ceiling.jsonl unreadable: {ex}"}
+
+
 def measured_traffic(tag):
     """HBM bytes per launch from the committed PMC passes (profiles/r04_traffic.json, else r03 / r02, for the fp16x3
     build; profiles/r01_traffic.json for the fp32 build: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same
@@ -967,6 +987,7 @@ def main():
                              "frac_of_fp16_peak": round(SPLIT_PASSES * dom["tflops"] / F16_MFMA_PEAK_TFLOPS, 4)} if dom_split else {}),
                          "traffic": traffic, "traffic_provenance": traffic_src,
                          "traffic_unit": "HBM bytes per launch (PMC, separate rocprofv3 passes; see traffic_provenance)",
+                         **({"power_limited_ceiling": power_ceiling()} if dom_split else {}),
                          "timing": "HIP events stamped by each kernel's own dispatch (hipExtLaunchKernelGGL via "
                                    f"wd_time_next_gemm) on the launch stream, every GEMM launch of the last {n_inst} of the "
                                    f"{args.steps} timed steps (stamping all steps would slow the step it measures by 2.4 %)",
