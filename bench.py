@@ -97,7 +97,7 @@ def power_ceiling():
 
 
 def measured_traffic(tag):
-    """HBM bytes per launch from the committed PMC passes (profiles/r04_traffic.json, else r03 / r02, for the fp16x3
+    """HBM bytes per launch from the committed PMC passes (profiles/r06_traffic.json, else r05 ... r02, for the fp16x3
     build; profiles/r01_traffic.json for the fp32 build: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same
     command, FETCH_SIZE doubled per MI355X_MICROARCH.md) — PMC passes cannot run inside the timed process, so the figure
     comes from a file, and its PROVENANCE is returned with it: the file, the commit and kernel-source hash it was taken
@@ -108,7 +108,7 @@ def measured_traffic(tag):
     if syms is None:
         return None, None
     syms = [syms] if isinstance(syms, str) else syms
-    for name in (("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_fp16x3_traffic.json")
+    for name in (("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_fp16x3_traffic.json")
                  if tag.startswith("fp16x3") else ("r01_traffic.json",)):
         try:
             doc = json.load(open(os.path.join(ROOT, "profiles", name)))

@@ -1,6 +1,6 @@
 # end-of-round evidence on the GPU box: WD_COMMIT=<commit of the build> [TAG=r05] [QUICK=1: profile + default bench only] bash scripts/final_evidence.sh
 export WD_COMMIT=${WD_COMMIT:?set WD_COMMIT to the commit being measured (the box has no .git)}
-TAG=${TAG:-r05}
+TAG=${TAG:-r06}
 export TMPDIR=/tmp
 mkdir -p gpurun_out/final
 bash scripts/profile_final.sh $TAG > gpurun_out/final/prof.log 2>&1
