@@ -152,5 +152,50 @@ ceiling)
   WEDETECT_LIB=$GRAFT_REPO_ROOT/wedetect_amd/libwedetect_hip_abl.so python scripts/p8_ceiling.py > $OUT/p8_ceiling.jsonl 2> $OUT/p8_ceiling.err
   cat $OUT/p8_ceiling.jsonl; tail -3 $OUT/p8_ceiling.err
   ;;
+c3pmc)
+  # what the 3 x 3 K loop is bound by: SQ / TCC / TCP counters per form (kernel names carry the form), one layer per run
+  export TMPDIR=/tmp
+  for sh in 0 1; do
+    export SHAPE=$sh
+    rocprofv3 --kernel-trace --stats -d $OUT/trace$sh -o p -- python scripts/conv3_pmc.py > /dev/null 2> $OUT/trace$sh.err
+    rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE -d $OUT/pmc1_$sh -o p -- python scripts/conv3_pmc.py > /dev/null 2> $OUT/pmc1_$sh.err
+    rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum -d $OUT/pmc2_$sh -o p -- python scripts/conv3_pmc.py > /dev/null 2> $OUT/pmc2_$sh.err
+    rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_GATE_EN1_sum -d $OUT/pmc3_$sh -o p -- python scripts/conv3_pmc.py > /dev/null 2> $OUT/pmc3_$sh.err
+    rocprofv3 --pmc TA_BUSY_avr TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum -d $OUT/pmc4_$sh -o p -- python scripts/conv3_pmc.py > /dev/null 2> $OUT/pmc4_$sh.err
+    P=""; for d in $OUT/pmc1_$sh $OUT/pmc2_$sh $OUT/pmc3_$sh $OUT/pmc4_$sh; do f=$(ls $d/*.db 2>/dev/null | head -1); [ -n "$f" ] && P="$P --pmc $f"; done
+    python scripts/rocpd_summary.py $(ls $OUT/trace$sh/*.db | head -1) $P > $OUT/summary$sh.txt 2>&1
+    rm -rf $OUT/trace$sh $OUT/pmc?_$sh
+    grep -i "conv3\|kernel  \|## PMC" $OUT/summary$sh.txt | cut -c1-330; tail -2 $OUT/pmc3_$sh.err $OUT/pmc4_$sh.err
+  done
+  ;;
+ws12)
+  # the twelve-wave producer / consumer 3 x 3 kernel (cfg 79) against the eight-wave forms
+  ( timeout 1200 python -m pytest tests/test_gpu_split.py -q -m gpu -k "conv3 or conv_pp" -x 2>&1 | tail -8 ) > $OUT/tests.log
+  python scripts/conv3_bench.py > $OUT/conv3_bench.txt 2>&1
+  WEDETECT_CONV3_WS=0 python scripts/neck_layer_times.py > $OUT/layers_off.txt 2>&1
+  python scripts/neck_layer_times.py > $OUT/layers_on.txt 2>&1
+  for i in 1 2; do
+    WEDETECT_CONV3_WS=0 python bench.py $Q > $OUT/bench_off_$i.json 2> $OUT/bench_off_$i.err
+    python bench.py $Q > $OUT/bench_on_$i.json 2> $OUT/bench_on_$i.err
+  done
+  WEDETECT_CONV3_WS=0 WEDETECT_DAG=0 python bench.py $Q > $OUT/bench_dag0_off.json 2> $OUT/bench_dag0_off.err
+  WEDETECT_DAG=0 python bench.py $Q > $OUT/bench_dag0_on.json 2> $OUT/bench_dag0_on.err
+  cat $OUT/tests.log; grep -v amdgpu.ids $OUT/conv3_bench.txt | cut -c1-400; grep total $OUT/layers_off.txt $OUT/layers_on.txt; line $OUT/bench_o*.json $OUT/bench_dag0_o*.json
+  ;;
+stag)
+  # the staggered K loop of the 3 x 3 kernel (cfg 77) against the in-step loop (cfg 78): identity tests, isolated A/B, per-layer serial
+  # chain, step A/B (DAG on and off)
+  ( timeout 1200 python -m pytest tests/test_gpu_split.py -q -m gpu -k "conv3 or conv_pp" -x 2>&1 | tail -8 ) > $OUT/tests.log
+  python scripts/conv3_bench.py > $OUT/conv3_bench.txt 2>&1
+  WEDETECT_CONV3_STAG=0 python scripts/neck_layer_times.py > $OUT/layers_off.txt 2>&1
+  python scripts/neck_layer_times.py > $OUT/layers_on.txt 2>&1
+  for i in 1 2; do
+    WEDETECT_CONV3_STAG=0 python bench.py $Q > $OUT/bench_off_$i.json 2> $OUT/bench_off_$i.err
+    python bench.py $Q > $OUT/bench_on_$i.json 2> $OUT/bench_on_$i.err
+  done
+  WEDETECT_CONV3_STAG=0 WEDETECT_DAG=0 python bench.py $Q > $OUT/bench_dag0_off.json 2> $OUT/bench_dag0_off.err
+  WEDETECT_DAG=0 python bench.py $Q > $OUT/bench_dag0_on.json 2> $OUT/bench_dag0_on.err
+  cat $OUT/tests.log; grep -v amdgpu.ids $OUT/conv3_bench.txt | cut -c1-260; grep total $OUT/layers_off.txt $OUT/layers_on.txt; line $OUT/bench_o*.json $OUT/bench_dag0_o*.json
+  ;;
 *) echo "unknown step $STEP"; exit 2;;
 esac

@@ -595,7 +595,7 @@ def _same(got: torch.Tensor, ref: torch.Tensor, exact: bool, what: str) -> None:
 
 
 @pytest.mark.parametrize("case", CONV_PP_CASES, ids=[c[0] for c in CONV_PP_CASES])
-@pytest.mark.parametrize("cfg", [-1, 73, 74, 75])
+@pytest.mark.parametrize("cfg", [-1, 73, 74, 75, 78])
 def test_conv_pp_bit_identical_to_loader_split(case, cfg):
     """The LDS-DMA implicit-GEMM kernel on pre-split activations (every output form: fp32, fp16 hi/lo, both at once,
     channel slices, batch-strided rows; fp32 residual) against the register-staged loader-split kernel on the fp32 twin
@@ -603,9 +603,9 @@ def test_conv_pp_bit_identical_to_loader_split(case, cfg):
     from wedetect_amd import lib as L
     name, b_, h, w_, ci, co, kk, stride, act, with_res, form = case
     conv3 = kk == 3 and stride == 1                               # production (and cfg 75) run the row-sharing kernel there
-    if cfg == 75 and not conv3:
-        pytest.skip("cfg 75 = the 3 x 3 / stride 1 kernel")
-    exact = not (conv3 and cfg in (-1, 75))
+    if cfg in (75, 78) and not conv3:
+        pytest.skip("cfg 75 / 78 = the 3 x 3 / stride 1 kernel (production K loop / the in-step K loop of round 4)")
+    exact = not (conv3 and cfg in (-1, 75, 78))
     pad = 1 if kk == 3 else 0
     ho, wo = (h + 2 * pad - kk) // stride + 1, (w_ + 2 * pad - kk) // stride + 1
     m = b_ * ho * wo
@@ -652,7 +652,8 @@ def test_conv_pp_bit_identical_to_loader_split(case, cfg):
 
 @pytest.mark.parametrize("b_,h,w_,ci,co", [(1, 2, 2, 16, 8), (2, 5, 3, 32, 64), (3, 40, 40, 128, 128), (1, 80, 80, 64, 256), (2, 19, 23, 48, 136),
                                             (32, 20, 20, 256, 64)])
-def test_conv3_row_sharing_kernel_against_fp64(b_, h, w_, ci, co):
+@pytest.mark.parametrize("cfg", [77, 78, 79])
+def test_conv3_row_sharing_kernel_against_fp64(b_, h, w_, ci, co, cfg):
     """split_conv3_kernel (cfg 75): every border case of the register-masked left / right padding and the zero-page top /
     bottom padding — maps narrower than a tile row group, tiles that start and end mid-row and mid-image, a 2 x 2 map where
     every pixel touches every border — against a float64 convolution of the same (hi + lo) operands."""
@@ -664,12 +665,45 @@ def test_conv3_row_sharing_kernel_against_fp64(b_, h, w_, ci, co):
     xs = _to_split(x)
     got = torch.empty(b_ * h * w_, co, device="cuda")
     L.conv_gemm(xs, None, bias, got, batch=b_, hin=h, win=w_, cin=ci, lda=ci, kh=3, kw=3, stride=1, pad=1, n=co, ldc=co,
-                act=L.ACT_NONE, w_split=ws, split_flags=L.SPLIT_A, split_cfg=75)
+                act=L.ACT_NONE, w_split=ws, split_flags=L.SPLIT_A, split_cfg=cfg)
     xd = _from_split(xs).view(b_, h, w_, ci).permute(0, 3, 1, 2)
     wd = wrow.double().view(co, 3, 3, ci).permute(0, 3, 1, 2)
     ref = torch.nn.functional.conv2d(xd, wd, bias.double(), padding=1).permute(0, 2, 3, 1).reshape(b_ * h * w_, co)
     err = float((got.double() - ref).abs().max())
     assert err < 2e-5 * float(ref.abs().max()), f"max|d| {err:.3e}"
+
+
+@pytest.mark.parametrize("b_,h,w_,ci,co,splits", [(2, 5, 3, 32, 64, 1), (3, 40, 40, 128, 128, 1), (1, 80, 80, 64, 256, 1), (2, 19, 23, 48, 136, 1),
+                                                   (4, 20, 20, 256, 256, 2), (2, 20, 20, 256, 64, 2), (1, 33, 31, 16, 64, 1), (2, 20, 20, 512, 256, 3)])
+def test_conv3_staggered_k_loop_bit_identical_to_in_step(b_, h, w_, ci, co, splits):
+    """Round 6: the two-row-group staggered K loop (cfg 77; one barrier per read phase and per MFMA phase, DMA of stage s + 2 issued in
+    the tap-1 / tap-2 phases, border lanes reading the zero staged row) and the twelve-wave producer / consumer kernel (cfg 79: four
+    DMA waves beside eight free-running MFMA waves, the ds_reads pinned into the MFMA stream by inline asm) run the same MFMA chain per accumulator as the in-step loop of round 4 (cfg 78): every
+    output form equal bit for bit, with and without the fixed split-K."""
+    from wedetect_amd import lib as L
+    m = b_ * h * w_
+    x = _rand((m, ci), 171)
+    wrow = _rand((co, 9 * ci), 172, (9 * ci) ** -0.5)
+    bias = _rand((co,), 173)
+    res = _rand((m, co), 174)
+    ws = L.split_weights(wrow)
+    xs = _to_split(x)
+    geo = dict(batch=b_, hin=h, win=w_, cin=ci, lda=ci, kh=3, kw=3, stride=1, pad=1, n=co, ldc=co, act=L.ACT_SILU, res=res, ldres=co,
+               res_alpha=0.5, w_split=ws)
+    if splits > 1:
+        geo.update(workspace=torch.empty(splits * m * co + 64, device="cuda"), k_splits=splits)
+    out = {}
+    for cfg in (77, 78, 79):
+        c = torch.full((m, co), float("nan"), device="cuda")
+        cs = torch.full((m, co), float("nan"), device="cuda")
+        c2 = torch.full((m, co), float("nan"), device="cuda")
+        L.conv_gemm(xs, None, bias, c, split_flags=L.SPLIT_A, split_cfg=cfg, **geo)
+        L.conv_gemm(xs, None, bias, cs, split_flags=L.SPLIT_A | L.SPLIT_C, split_cfg=cfg, c2=c2, ldc2=co, **geo)
+        out[cfg] = (c, cs, c2)
+    for cfg in (77, 79):
+        for a, b, what in zip(out[cfg], out[78], ("fp32", "hi/lo", "fp32 twin")):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), f"cfg {cfg}: {what}"
+    assert bool(torch.isfinite(out[77][0]).all())
 
 
 def test_conv_pp_split_k_deconv_and_c_only_split():

@@ -49,11 +49,15 @@ def source_hash() -> str:
 NO_SCRATCH = {"stem.hip": ["stem_fused_kernel"], "split_gemm_mlpw.hip": ["fused_mlp_wide_kernel"],
               "split_gemm_mlp.hip": ["fused_mlp128_kernel"], "split_gemm_p8.hip": ["split_gemm_p8_kernel"],
               "split_gemm_p4.hip": ["split_gemm_p4_kernel"], "split_gemm_conv.hip": ["split_conv_pp_kernel"],
-              "split_gemm_conv3.hip": ["split_conv3_kernel"],
+              "split_gemm_conv3.hip": ["split_conv3_kernel", "split_conv3w_kernel"],
               "split_gemm_pre.hip": ["split_gemm_pingpong_kernel", "split_gemm_glds_kernel"],
               "elementwise.hip": ["dwconv7_dma_kernel", "dwconv7_ln_reg4_dma_kernel"]}
 ASM_VMEM_SOURCES = {"split_gemm_mlpw.hip": ["fused_mlp_wide_kernel"], "split_gemm_mlp.hip": [], "split_gemm_p8.hip": [],
                     "split_gemm_p4.hip": [], "split_gemm_pre.hip": [], "split_gemm_conv.hip": [], "split_gemm_conv3.hip": [], "stem.hip": [], "elementwise.hip": []}
+
+
+# kernels that issue ds_reads from inline asm (invisible to the compiler's waitcnt pass): scripts/check_asm_ds_reads.py
+ASM_DS_READ_SOURCES = {"split_gemm_conv3.hip": ["split_conv3w_kernel"]}
 
 
 def check_isa(src: str, verbose: bool = True) -> None:
@@ -70,6 +74,10 @@ def check_isa(src: str, verbose: bool = True) -> None:
         r = subprocess.run([sys.executable, os.path.join(scripts, "check_asm_loads.py"), asm, *syms], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"pending asm load touched in the ISA of {src}:\n{r.stdout[-2000:]}")
+    if src in ASM_DS_READ_SOURCES:
+        r = subprocess.run([sys.executable, os.path.join(scripts, "check_asm_ds_reads.py"), asm, *ASM_DS_READ_SOURCES[src]], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"pending asm ds_read touched in the ISA of {src}:\n{r.stdout[-2000:]}")
     if src in NO_SCRATCH:
         import re
         meta = open(asm).read()

@@ -218,7 +218,7 @@ static int conv_gemm_split_impl(const WdConvGemm* pp, const void* w_split, float
     if (!p.ln_stats || !p.ln_u || flags != (WD_SPLIT_A | WD_SPLIT_C) || !plain || special || p.res || p.c2 || force_splits > 1 ||
         !wd_aligned16(p.ln_u) || (reinterpret_cast<uintptr_t>(p.ln_stats) & 7u))
       return WD_ERR_BAD_ARG;
-    if (cfg == 70 || cfg == 73 || cfg == 74 || cfg == 75 || cfg == 76 || (cfg >= 700 && cfg < 716)) return WD_ERR_UNSUPPORTED;
+    if (cfg == 70 || cfg == 73 || cfg == 74 || (cfg >= 75 && cfg <= 79) || (cfg >= 700 && cfg < 716)) return WD_ERR_UNSUPPORTED;
   }
   if (flags & WD_SPLIT_A) {
     // Pre-split activations.  Plain row-output 1x1 layers keep the GEMM kernels tuned for the ConvNeXt MLPs (below);
@@ -230,10 +230,10 @@ static int conv_gemm_split_impl(const WdConvGemm* pp, const void* w_split, float
     // ($WEDETECT_CONV3=0 keeps the tap-per-stage kernel: A/B runs)
     static const bool conv3_on = [] { const char* e = getenv("WEDETECT_CONV3"); return !(e && e[0] == '0'); }();
     // (latency mode — a workspace on offer with the split count left to the library — stays with the tap-per-stage kernel's rule)
-    if (cfg == 75 || cfg == 76 || (production && conv3_on && !(force_splits == 0 && ws != nullptr))) {
+    if ((cfg >= 75 && cfg <= 79) || (production && conv3_on && !(force_splits == 0 && ws != nullptr))) {
       if (wd_conv3_ok(p, flags) && wd_conv_pp_ok(p, flags))
-        return wd_launch_conv3(p, w_split, w_unscale, flags, st, cfg == 76 ? 2 : 0, force_splits > 1 ? force_splits : 1, ws, ws ? ws_bytes / 4 : 0);
-      if (cfg == 75 || cfg == 76) return WD_ERR_UNSUPPORTED;
+        return wd_launch_conv3(p, w_split, w_unscale, flags, st, cfg == 76 ? 2 : cfg == 77 ? 7 : cfg == 78 ? 8 : cfg == 79 ? 9 : 0, force_splits > 1 ? force_splits : 1, ws, ws ? ws_bytes / 4 : 0);
+      if (cfg >= 75 && cfg <= 79) return WD_ERR_UNSUPPORTED;
     }
     if (forced || (production && !covered)) {
       if (!wd_conv_pp_ok(p, flags)) return forced || !covered ? WD_ERR_UNSUPPORTED : WD_ERR_BAD_ARG;
