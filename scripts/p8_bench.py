@@ -24,9 +24,25 @@ SHAPES = {
     "e1_pw1 fp32out noact (stage 1)": dict(m=819200, n=512, k=128),
     "s4_pw1 12800x4096x1024 gelu": dict(m=12800, n=4096, k=1024, gelu=True),
     "s4_pw2 12800x1024x4096 res": dict(m=12800, n=1024, k=4096, res=True),
+    # Base B = 8 (ONLY=b8): the stage 2 - 4 MLPs at a quarter of the rows
+    "b8_s2_pw1 51200x1024x256 gelu": dict(m=51200, n=1024, k=256, gelu=True),
+    "b8_s2_pw2 51200x256x1024 res": dict(m=51200, n=256, k=1024, res=True),
+    "b8_s3_pw1 12800x2048x512 gelu": dict(m=12800, n=2048, k=512, gelu=True),
+    "b8_s3_pw2 12800x512x2048 res": dict(m=12800, n=512, k=2048, res=True),
+    "b8_s4_pw1 3200x4096x1024 gelu": dict(m=3200, n=4096, k=1024, gelu=True),
+    "b8_s4_pw2 3200x1024x4096 res": dict(m=3200, n=1024, k=4096, res=True),
 }
-cfgs = [int(c) for c in os.environ.get("CFGS", "60,63,64,65").split(",")]
 park = torch.zeros(L.p8_workspace_bytes() // 4, dtype=torch.float32, device=dev)
+# cfg 60SS (e.g. 6002): cfg 60 with SS K splits through a workspace (fp32-output layers only)
+kws = torch.empty(16 << 20, dtype=torch.float32, device="cuda")
+
+
+def run(cfg, xs, b, c, ws, flags, kw):
+    if cfg >= 6000:
+        L.conv_gemm(xs, None, b, c, w_split=ws, split_cfg=60, split_flags=flags, workspace=kws, k_splits=cfg - 6000, **kw)
+    else:
+        L.conv_gemm(xs, None, b, c, w_split=ws, split_cfg=cfg, split_flags=flags, workspace=park if cfg == 65 else None, **kw)
+cfgs = [int(c) for c in os.environ.get("CFGS", "60,63,64,65").split(",")]
 rounds = int(os.environ.get("ROUNDS", "5"))
 reps = int(os.environ.get("REPS", "6"))
 only = os.environ.get("ONLY")
@@ -58,7 +74,7 @@ for name, sh in SHAPES.items():
     for cfg in cfgs:
         try:
             c.copy_(c_init)
-            L.conv_gemm(xs, None, b, c, w_split=ws, split_cfg=cfg, split_flags=flags, workspace=park if cfg == 65 else None, **kw)
+            run(cfg, xs, b, c, ws, flags, kw)
             torch.cuda.synchronize()
             if ref is None:
                 ref = c.clone()
@@ -72,10 +88,10 @@ for name, sh in SHAPES.items():
             if ok[cfg].startswith("FAILED"):
                 continue
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            L.conv_gemm(xs, None, b, c, w_split=ws, split_cfg=cfg, split_flags=flags, workspace=park if cfg == 65 else None, **kw)
+            run(cfg, xs, b, c, ws, flags, kw)
             s.record()
             for _ in range(reps):
-                L.conv_gemm(xs, None, b, c, w_split=ws, split_cfg=cfg, split_flags=flags, workspace=park if cfg == 65 else None, **kw)
+                run(cfg, xs, b, c, ws, flags, kw)
             e.record()
             torch.cuda.synchronize()
             times[cfg].append(1e3 * s.elapsed_time(e) / reps)

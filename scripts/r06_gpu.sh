@@ -152,6 +152,16 @@ ceiling)
   WEDETECT_LIB=$GRAFT_REPO_ROOT/wedetect_amd/libwedetect_hip_abl.so python scripts/p8_ceiling.py > $OUT/p8_ceiling.jsonl 2> $OUT/p8_ceiling.err
   cat $OUT/p8_ceiling.jsonl; tail -3 $OUT/p8_ceiling.err
   ;;
+midclass)
+  # mid-class latency split-K (5 - 8 images of 640 x 640): class-invariance test, B = 5 .. 8 with / without, B = 1 / 4 unchanged
+  ( timeout 1200 python -m pytest tests/test_gpu_network.py -q -m gpu -k "latency or split_k or mid_class" -x 2>&1 | tail -6 ) > $OUT/tests.log
+  for b in 5 6 8; do
+    WEDETECT_SPLIT_K=0 python bench.py $Q --batch $b > $OUT/bench_b${b}_off.json 2> $OUT/bench_b${b}_off.err
+    python bench.py $Q --batch $b > $OUT/bench_b${b}_auto.json 2> $OUT/bench_b${b}_auto.err
+  done
+  for b in 1 4 16; do python bench.py $Q --batch $b > $OUT/bench_b${b}_auto.json 2> $OUT/bench_b${b}_auto.err; done
+  cat $OUT/tests.log; line $OUT/bench_*.json
+  ;;
 c3pmc)
   # what the 3 x 3 K loop is bound by: SQ / TCC / TCP counters per form (kernel names carry the form), one layer per run
   export TMPDIR=/tmp

@@ -644,3 +644,36 @@ def test_latency_mode_is_the_default_of_small_towers_and_batch_invariant(monkeyp
         a0 = set(zip(r0["anchors"][i, :n0].tolist(), r0["labels"][i, :n0].tolist()))
         a3 = set(zip(r3["anchors"][i, :n3].tolist(), r3["labels"][i, :n3].tolist()))
         assert len(a0 & a3) >= 0.97 * max(n0, 1)
+
+
+def test_mid_class_latency_split_is_batch_invariant_inside_the_class(monkeypatch):
+    """Round 6: towers between four and eight 640 x 640 images' worth of pixels (the MID class) split K by the layer's geometry at
+    the class's reference batch — an image gets the SAME BITS in a batch of seven and in a batch of eight, the results stay within
+    fp32 summation noise of the unsplit tower, and at least one layer is split."""
+    if PRECISION["value"] != "fp16x3":
+        pytest.skip("split-K exists for the fp16x3 kernels only")
+    from wedetect_amd.engine import ImageTower
+    monkeypatch.setenv("WEDETECT_SPLIT_K", "auto")
+    size = 512
+    assert ImageTower.SPLIT_K_AUTO_PIXELS < 7 * size * size and 8 * size * size <= ImageTower.SPLIT_K_MID_PIXELS
+    sd, t8, imgs = build("base", 8, size, num_prompts=64, split_k=None)
+    _, t7, _ = build("base", 7, size, num_prompts=64, split_k=None)
+    _, t0, _ = build("base", 8, size, num_prompts=64, split_k=False)
+    assert t8.kws is not None and t7.kws is not None and t0.kws is None
+    assert t8._split_ref == t7._split_ref == ImageTower.SPLIT_K_MID_PIXELS // (size * size) > 1
+    x = torch.from_numpy(imgs).cuda()
+    t8.calibrate(x)
+    t7.adopt_scales(t8.sscale)
+    t0.adopt_scales(t8.sscale)
+    kw = dict(normalize_text=False, score_thr=0.0, with_embed=True)
+    r8 = {k: v.clone() for k, v in t8.detect(x, t8.P["prompts"], t8.identity_meta(), **kw).items()}
+    e8 = t8.embed.clone()
+    t0.detect(x, t0.P["prompts"], t0.identity_meta(), **kw)
+    e0 = t0.embed.clone()
+    r7 = t7.detect(x[1:8].contiguous(), t7.P["prompts"], t7.identity_meta(), **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(t7.embed, e8[1:8]), "embeddings in the batch of seven != in the batch of eight"
+    for k in ("bboxes", "scores", "labels", "anchors", "count", "embeddings"):
+        assert torch.equal(r7[k], r8[k][1:8]), f"{k}: batch of seven != batch of eight"
+    assert_close("mid-class latency mode vs unsplit embeddings", e8, e0, 2e-5, 1e-5)
+    assert not torch.equal(e8, e0), "no layer was split: the test shapes no longer exercise the mid class"

@@ -47,6 +47,7 @@ def fold_layernorm_into_linear(w1: torch.Tensor, b1: torch.Tensor, gamma: torch.
 class ImageTower:
     PRECISIONS = ("fp32", "fp16x3")
     SPLIT_K_AUTO_PIXELS = 4 * 640 * 640
+    SPLIT_K_MID_PIXELS = 8 * 640 * 640
 
     def __init__(self, arch, packed: Packed, batch: int, height: int, width: int, device="cuda",
                  max_classes: int = 256, nms_pre: int = 30000, max_out: int = 300,
@@ -70,6 +71,7 @@ class ImageTower:
         self.precision = precision
         self.Ws: Dict[str, tuple] = {}          # weight name -> (split buffer, unscale), fp16x3 mode only
         # split-K workspace for under-filled fp16x3 launches (small batches, the coarsest maps): partial sums [S][m][n]
+        auto_class = split_k is None and os.environ.get("WEDETECT_SPLIT_K", "auto") == "auto"
         if split_k is None:
             # round 6: "auto" (default) = on for SMALL towers — at most SPLIT_K_AUTO_PIXELS input pixels per batch (four 640 x 640
             # images) — where every long-K layer is one under-filled, K-sequential launch (Base batch 1: pwconv2 of a stage-3 block =
@@ -78,7 +80,15 @@ class ImageTower:
             # launches, so an image's low-order bits differ between a small and a large tower (1e-6; deterministic within each
             # class; the detectors' towers of one checkpoint agree bit for bit only inside a class).  "1" / "0" force.
             env = os.environ.get("WEDETECT_SPLIT_K", "auto")
-            split_k = env == "1" or (env == "auto" and batch * height * width <= self.SPLIT_K_AUTO_PIXELS)
+            split_k = env == "1" or (env == "auto" and batch * height * width <= self.SPLIT_K_MID_PIXELS)
+        # The split count of a layer comes from its per-image geometry times the REFERENCE batch of the tower's class, never from the
+        # batch itself: 1 for the small class (<= SPLIT_K_AUTO_PIXELS per batch, and for split_k=True towers of any size), and — round
+        # 6, later — the number of images of this size that fill the MID class (<= SPLIT_K_MID_PIXELS, eight 640 x 640 images: the
+        # 3 x 3 convs of the 40 x 40 / 20 x 20 maps are 50 / 26 tiles on 256 CUs there).  Inside a class an image gets the same bits
+        # in any batch; between classes they differ in the low-order bits (1e-6).
+        self._split_ref = 1
+        if split_k and auto_class and batch * height * width > self.SPLIT_K_AUTO_PIXELS:
+            self._split_ref = max(1, self.SPLIT_K_MID_PIXELS // (height * width))
         self.kws = (torch.empty(16 << 20, dtype=torch.float32, device=torch.device(device))
                     if precision == "fp16x3" and split_k else None)
         self._kws_lane: Dict[int, torch.Tensor] = {}          # the side lanes' own split-K workspaces (DAG mode)
@@ -358,14 +368,14 @@ class ImageTower:
                     self._record(c_key, c[..., : n // 4] if kw.get("out_mode", 0) == L.OUT_DECONV2X2 else c[..., :n])
 
     def _latency_splits(self, kw) -> int:
-        """K splits of one layer in latency mode, from its geometry at batch ONE (the library's own rules — split_gemm.hip:
-        pick_ksplits and the implicit-GEMM kernel's — evaluated on a single image): 1 = launch unsplit."""
+        """K splits of one layer in latency mode, from its geometry at the class's reference batch (ONE image in the small class;
+        the library's own rules — split_gemm.hip: pick_ksplits and the implicit-GEMM kernel's): 1 = launch unsplit."""
         flags = kw.get("split_flags", 0)
         kh, st, pd = kw.get("kh", 1), kw.get("stride", 1), kw.get("pad", 0)
         n, k = kw["n"], kh * kh * kw["cin"]
         if n % 4 or kw.get("ln_stats") is not None or "k_splits" in kw:
             return 1
-        m1 = ((kw["hin"] + 2 * pd - kh) // st + 1) * ((kw["win"] + 2 * pd - kh) // st + 1)
+        m1 = ((kw["hin"] + 2 * pd - kh) // st + 1) * ((kw["win"] + 2 * pd - kh) // st + 1) * self._split_ref   # rows of the class's reference batch
         plain = kh == 1 and st == 1 and pd == 0
         special = (kw.get("out_mode", 0) != 0 or kw.get("c_batch_stride", 0) > 0 or kw.get("seg") is not None or kw.get("sigmoid")
                    or kw.get("out_scale", 1.0) != 1.0 or kw.get("out_bias", 0.0) != 0.0)
@@ -379,7 +389,7 @@ class ImageTower:
             return max(1, min(256 // tiles, nk // 16, 8))
         if flags & L.SPLIT_C:                                      # GEMM kernels that write hi/lo groups do not split K
             return 1
-        if (flags & L.SPLIT_A) and not L.gemm_config(self.B * m1, n, k, split=True, presplit=True).endswith("/glds"):
+        if (flags & L.SPLIT_A) and not L.gemm_config((self.B if self._split_ref == 1 else 1) * m1, n, k, split=True, presplit=True).endswith("/glds"):
             return 1                                               # a 256-tile / ping-pong launch (never in the small class's shapes)
         tiles, nk = -(-m1 // 128) * -(-n // 128), -(-k // 16)
         if tiles >= 128 or nk < 16:
