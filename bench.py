@@ -73,6 +73,11 @@ KERNEL_SYMBOL = {
     "fp16x3 256x256x32/8w/p8/plain": ["split_gemm_p8_kernel<2048, 0, false>", "split_gemm_p8_kernel<0, 0, false>",
                                       "split_gemm_p8_kernel<2048, 0, true>", "split_gemm_p8_kernel<0, 0, true>"],
     "fp16x3 256x128x16/8w/dma/conv": ["split_conv_pp_kernel<3, 2, true, 0>", "split_conv_pp_kernel<4, 2, true, 0>"],
+    # round 6: the 3 x 3 / stride 1 layers — twelve-wave producer / consumer kernel; the narrow layers with more tiles than CUs on the
+    # eight-wave ring-of-two form
+    "fp16x3 256x128x16/12w/dma3/conv": ["split_conv3w_kernel<2, true>", "split_conv3w_kernel<2, false>"],
+    "fp16x3 256x64x16/12w/dma3/conv": ["split_conv3w_kernel<1, true>", "split_conv3w_kernel<1, false>"],
+    "fp16x3 256x64x16/8w/dma3/ring2/conv": ["split_conv3_kernel<1, true, 2, false>", "split_conv3_kernel<1, false, 2, false>"],
 }
 
 
@@ -217,7 +222,9 @@ class GemmTimer:
             covered = plain and not special and kw.get("c2") is None and not ((flags & lib.SPLIT_C) and kw.get("res") is not None)
             dma = kw.get("w_split") is not None and bool(flags & lib.SPLIT_A) and not covered
             tag = lib.gemm_config(m, n, k, split=kw.get("w_split") is not None, conv=not plain,
-                                  presplit=bool(flags & lib.SPLIT_A), park=park, dma=dma) + ("/plain" if plain else "/conv")
+                                  presplit=bool(flags & lib.SPLIT_A), park=park, dma=dma,
+                                  conv3=dma and kh == 3 and kw_ == 3 and stride == 1 and pad == 1 and kw["cin"] % 16 == 0
+                                  and os.environ.get("WEDETECT_CONV3", "1") != "0") + ("/plain" if plain else "/conv")
             if os.environ.get("WEDETECT_BENCH_BY_SHAPE") == "1":       # diagnostic: one line per layer shape
                 tag += f" m{m} n{n} k{kh}x{kw_}x{kw['cin']} s{stride}" + (" ks2" if kw.get("k_splits") else "")
             s, e = self.pool.pop() if self.pool else self._pair()

@@ -10,9 +10,9 @@ python bench.py --mode retrieval > gpurun_out/final/bench_retrieval_1m.json 2> g
 # the retrieval kernel under the profiler: kernel trace + fabric traffic (separate PMC passes)
 R="python bench.py --mode retrieval --steps 2 --warmup 1 --no-cpu-baseline"
 OUT=$PWD/gpurun_out/prof_${TAG}_retr; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o p -- $R > $OUT/trace_bench.json 2> $OUT/trace.err
-rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- $R > /dev/null 2> $OUT/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o p -- $R > /dev/null 2> $OUT/pmc_write.err
+timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace -o p -- $R > $OUT/trace_bench.json 2> $OUT/trace.err
+timeout 900 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- $R > /dev/null 2> $OUT/pmc_fetch.err
+timeout 900 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o p -- $R > /dev/null 2> $OUT/pmc_write.err
 python scripts/rocpd_summary.py $(ls $OUT/trace/*.db | head -1) > $OUT/summary.txt 2>&1
 python scripts/traffic_json.py $(ls $OUT/pmc_fetch/*.db | head -1) $(ls $OUT/pmc_write/*.db | head -1) > $OUT/traffic.json 2> $OUT/traffic.err
 rm -f $OUT/*/*.db

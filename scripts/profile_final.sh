@@ -8,14 +8,14 @@ TAG=${1:-final}; shift
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fp32-reference --no-host-fed --no-other-configs --no-calibrate $*"
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o p -- $CMD > $OUT/trace_bench.json 2> $OUT/trace.err
+timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace -o p -- $CMD > $OUT/trace_bench.json 2> $OUT/trace.err
 if [ -n "$TRACE_ONLY" ]; then     # kernel trace only (TRACE_ONLY=1): no counter passes
   python scripts/rocpd_summary.py $(ls $OUT/trace/*.db | head -1) > $OUT/summary.txt 2>&1
   rm -f $OUT/*/*.db; head -30 $OUT/summary.txt; cut -c1-300 $OUT/trace_bench.json; exit 0
 fi
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $OUT/pmc_sq -o p -- $CMD > /dev/null 2> $OUT/pmc_sq.err
-rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- $CMD > /dev/null 2> $OUT/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o p -- $CMD > /dev/null 2> $OUT/pmc_write.err
+timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $OUT/pmc_sq -o p -- $CMD > /dev/null 2> $OUT/pmc_sq.err
+timeout 900 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- $CMD > /dev/null 2> $OUT/pmc_fetch.err
+timeout 900 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o p -- $CMD > /dev/null 2> $OUT/pmc_write.err
 T=$(ls $OUT/trace/*.db | head -1); S=$(ls $OUT/pmc_sq/*.db | head -1); F=$(ls $OUT/pmc_fetch/*.db | head -1); W=$(ls $OUT/pmc_write/*.db | head -1)
 python scripts/rocpd_summary.py $T --pmc $S > $OUT/summary.txt 2>&1
 python scripts/traffic_json.py $F $W > $OUT/traffic.json 2> $OUT/traffic.err

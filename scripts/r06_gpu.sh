@@ -28,10 +28,10 @@ dwpmc)
   export TMPDIR=/tmp
   python scripts/dwconv_bench.py > $OUT/dwconv_bench.txt 2>&1
   python scripts/hbm_bw_probe.py > $OUT/hbm_probe.txt 2>&1
-  rocprofv3 --kernel-trace --stats -d $OUT/trace -o p -- python scripts/dwconv_bench.py > /dev/null 2> $OUT/trace.err
-  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE -d $OUT/pmc1 -o p -- python scripts/dwconv_bench.py > /dev/null 2> $OUT/pmc1.err
-  rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU -d $OUT/pmc2 -o p -- python scripts/dwconv_bench.py > /dev/null 2> $OUT/pmc2.err
-  rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum -d $OUT/pmc3 -o p -- python scripts/dwconv_bench.py > /dev/null 2> $OUT/pmc3.err
+  timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o p -- python scripts/dwconv_bench.py > /dev/null 2> $OUT/trace.err
+  timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE -d $OUT/pmc1 -o p -- python scripts/dwconv_bench.py > /dev/null 2> $OUT/pmc1.err
+  timeout 600 rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU -d $OUT/pmc2 -o p -- python scripts/dwconv_bench.py > /dev/null 2> $OUT/pmc2.err
+  timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum -d $OUT/pmc3 -o p -- python scripts/dwconv_bench.py > /dev/null 2> $OUT/pmc3.err
   python scripts/rocpd_summary.py $(ls $OUT/trace/*.db | head -1) --pmc $(ls $OUT/pmc1/*.db | head -1) --pmc $(ls $OUT/pmc2/*.db | head -1) --pmc $(ls $OUT/pmc3/*.db | head -1) > $OUT/summary.txt 2>&1
   rm -rf $OUT/trace $OUT/pmc1 $OUT/pmc2 $OUT/pmc3
   grep -v amdgpu.ids $OUT/dwconv_bench.txt; tail -5 $OUT/hbm_probe.txt; grep -i "dwconv\|kernel  \|## PMC" $OUT/summary.txt | cut -c1-330; tail -3 $OUT/pmc*.err
@@ -50,9 +50,9 @@ dwdma2)
   export TMPDIR=/tmp
   ( timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_split.py -q -m gpu -k "dwconv or stats or fold" -x 2>&1 | tail -5 ) > $OUT/tests.log
   python scripts/dwconv_bench.py > $OUT/dwconv_bench.txt 2>&1
-  VARIANTS=4 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE -d $OUT/pmc1 -o p -- python scripts/dwconv_bench.py > /dev/null 2> $OUT/pmc1.err
-  VARIANTS=4 rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU -d $OUT/pmc2 -o p -- python scripts/dwconv_bench.py > /dev/null 2> $OUT/pmc2.err
-  VARIANTS=4 rocprofv3 --kernel-trace --stats -d $OUT/trace -o p -- python scripts/dwconv_bench.py > /dev/null 2> $OUT/trace.err
+  VARIANTS=4 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE -d $OUT/pmc1 -o p -- python scripts/dwconv_bench.py > /dev/null 2> $OUT/pmc1.err
+  VARIANTS=4 timeout 600 rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU -d $OUT/pmc2 -o p -- python scripts/dwconv_bench.py > /dev/null 2> $OUT/pmc2.err
+  VARIANTS=4 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o p -- python scripts/dwconv_bench.py > /dev/null 2> $OUT/trace.err
   python scripts/rocpd_summary.py $(ls $OUT/trace/*.db | head -1) --pmc $(ls $OUT/pmc1/*.db | head -1) --pmc $(ls $OUT/pmc2/*.db | head -1) > $OUT/summary.txt 2>&1
   rm -rf $OUT/trace $OUT/pmc1 $OUT/pmc2
   for i in 1 2; do
@@ -109,7 +109,7 @@ smallb)
   python bench.py $Q --batch 8 > $OUT/bench_b8.json 2> $OUT/bench_b8.err
   WEDETECT_SPLIT_K=1 python bench.py $Q --batch 1 > $OUT/bench_b1_splitk.json 2> $OUT/bench_b1_splitk.err
   WEDETECT_SPLIT_K=1 python bench.py $Q --batch 8 > $OUT/bench_b8_splitk.json 2> $OUT/bench_b8_splitk.err
-  rocprofv3 --kernel-trace --stats -d $OUT/trace -o p -- python bench.py --steps 20 --warmup 5 --batch 1 --no-cpu-baseline --no-fp32-reference --no-host-fed --no-other-configs > /dev/null 2> $OUT/trace.err
+  timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o p -- python bench.py --steps 20 --warmup 5 --batch 1 --no-cpu-baseline --no-fp32-reference --no-host-fed --no-other-configs > /dev/null 2> $OUT/trace.err
   python scripts/rocpd_summary.py $(ls $OUT/trace/*.db | head -1) > $OUT/summary_b1.txt 2>&1
   rm -rf $OUT/trace
   line $OUT/bench_b*.json; head -40 $OUT/summary_b1.txt | cut -c1-120; grep "total" $OUT/layers_b1.txt $OUT/layers_b8.txt
@@ -167,15 +167,15 @@ c3pmc)
   export TMPDIR=/tmp
   for sh in 0 1; do
     export SHAPE=$sh
-    rocprofv3 --kernel-trace --stats -d $OUT/trace$sh -o p -- python scripts/conv3_pmc.py > /dev/null 2> $OUT/trace$sh.err
-    rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE -d $OUT/pmc1_$sh -o p -- python scripts/conv3_pmc.py > /dev/null 2> $OUT/pmc1_$sh.err
-    rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum -d $OUT/pmc2_$sh -o p -- python scripts/conv3_pmc.py > /dev/null 2> $OUT/pmc2_$sh.err
-    rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_GATE_EN1_sum -d $OUT/pmc3_$sh -o p -- python scripts/conv3_pmc.py > /dev/null 2> $OUT/pmc3_$sh.err
-    rocprofv3 --pmc TA_BUSY_avr TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum -d $OUT/pmc4_$sh -o p -- python scripts/conv3_pmc.py > /dev/null 2> $OUT/pmc4_$sh.err
-    P=""; for d in $OUT/pmc1_$sh $OUT/pmc2_$sh $OUT/pmc3_$sh $OUT/pmc4_$sh; do f=$(ls $d/*.db 2>/dev/null | head -1); [ -n "$f" ] && P="$P --pmc $f"; done
+    timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace$sh -o p -- python scripts/conv3_pmc.py > /dev/null 2> $OUT/trace$sh.err
+    timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE -d $OUT/pmc1_$sh -o p -- python scripts/conv3_pmc.py > /dev/null 2> $OUT/pmc1_$sh.err
+    timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum -d $OUT/pmc2_$sh -o p -- python scripts/conv3_pmc.py > /dev/null 2> $OUT/pmc2_$sh.err
+    timeout 600 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_GATE_EN1_sum -d $OUT/pmc3_$sh -o p -- python scripts/conv3_pmc.py > /dev/null 2> $OUT/pmc3_$sh.err
+    # (a --pmc TA_* pass aborted inside a torch kernel and hung the profiler for 18 minutes: not collected)
+    P=""; for d in $OUT/pmc1_$sh $OUT/pmc2_$sh $OUT/pmc3_$sh; do f=$(ls $d/*.db 2>/dev/null | head -1); [ -n "$f" ] && P="$P --pmc $f"; done
     python scripts/rocpd_summary.py $(ls $OUT/trace$sh/*.db | head -1) $P > $OUT/summary$sh.txt 2>&1
     rm -rf $OUT/trace$sh $OUT/pmc?_$sh
-    grep -i "conv3\|kernel  \|## PMC" $OUT/summary$sh.txt | cut -c1-330; tail -2 $OUT/pmc3_$sh.err $OUT/pmc4_$sh.err
+    grep -i "conv3\|kernel  \|## PMC" $OUT/summary$sh.txt | cut -c1-330; tail -n 2 $OUT/pmc3_$sh.err
   done
   ;;
 ws12)

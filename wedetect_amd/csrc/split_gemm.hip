@@ -123,6 +123,7 @@ int wd_launch_conv_pp(const WdConvGemm& p, const void* w, float unscale, int fla
                       long long ws_floats, int variant);
 // split_gemm_conv3.hip: 3 x 3 / stride 1 / pad 1, one stage per (filter row, channel chunk) shared by the row's three taps
 bool wd_conv3_ok(const WdConvGemm& p, int flags);
+const char* wd_conv3_config_name(int m, int n);
 int wd_launch_conv3(const WdConvGemm& p, const void* w, float unscale, int flags, hipStream_t st, int variant, int ksplits, float* ws,
                     long long ws_floats);
 
@@ -156,13 +157,14 @@ static int pick_presplit_cfg(int m, int n, int k, bool park) {
   return m >= 131072 ? 63 : 60;
 }
 
-// is_conv: 0 = plain, 1 = conv, 2 = plain with pre-split operands, 3 = the same with a park workspace on offer,
+// is_conv: 0 = plain, 1 = conv, 2 = plain with pre-split operands, 3 = the same with a park workspace on offer, 5 = 3 x 3 / stride 1 (conv3),
 // 4 = pre-split activations through the implicit-GEMM LDS-DMA kernel (k x k / strided convs, scatter / batch-stride / dual outputs)
 extern "C" const char* wd_conv_gemm_split_config(int32_t m, int32_t n, int32_t k, int32_t is_conv) {
   if (is_conv == 4) {
     const bool narrow = (n % 128) != 0 && ((n + 63) / 64) * 64 < ((n + 127) / 128) * 128;
     return narrow ? "fp16x3 256x64x16/8w/dma" : "fp16x3 256x128x16/8w/dma";
   }
+  if (is_conv == 5) return wd_conv3_config_name(m, n);               // 3 x 3 / stride 1 / pad 1 on pre-split activations: the row-sharing kernels
   if ((is_conv == 2 || is_conv == 3) && k % 16 == 0) {
     switch (pick_presplit_cfg(m, n, k, is_conv == 3)) {
       case 65: return "fp16x3 256x256x32/8w/p8s";

@@ -731,3 +731,15 @@ int wd_launch_conv3(const WdConvGemm& p, const void* w, float unscale, int flags
   if (stag) return csplit ? launch_conv3<2, true, 3, true>(p, w, unscale, st, 1, tws) : launch_conv3<2, false, 3, true>(p, w, unscale, st, 1, tws);
   return csplit ? launch_conv3<2, true>(p, w, unscale, st) : launch_conv3<2, false>(p, w, unscale, st);
 }
+
+// the kernel form wd_launch_conv3 picks for an m x n layer without split-K (bench.py's gemm_kernels table)
+const char* wd_conv3_config_name(int m, int n) {
+  const bool narrow = (n % 128) != 0 && ((n + 63) / 64) * 64 < ((n + 127) / 128) * 128;
+  const bool w12 = conv3_ws_default();
+  if (narrow) {
+    const long long tiles = (long long)((m + C3_BM - 1) / C3_BM) * ((n + 63) / 64);
+    if (tiles > 256) return "fp16x3 256x64x16/8w/dma3/ring2";
+    return w12 ? "fp16x3 256x64x16/12w/dma3" : "fp16x3 256x64x16/8w/dma3";
+  }
+  return w12 ? "fp16x3 256x128x16/12w/dma3" : "fp16x3 256x128x16/8w/dma3";
+}

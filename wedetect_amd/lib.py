@@ -275,9 +275,12 @@ def p8_workspace_bytes() -> int:
 
 
 def gemm_config(m: int, n: int, k: int, split: bool = False, conv: bool = False, presplit: bool = False,
-                park: bool = False, dma: bool = False) -> str:
+                park: bool = False, dma: bool = False, conv3: bool = False) -> str:
     """``dma``: a pre-split layer outside the plain-row 1x1 case (k x k / strided conv, scatter or batch-stride output,
-    residual or dual-format output of a SPLIT_C layer): the implicit-GEMM LDS-DMA kernel of split_gemm_conv.hip."""
+    residual or dual-format output of a SPLIT_C layer): the implicit-GEMM LDS-DMA kernel of split_gemm_conv.hip; ``conv3``:
+    3 x 3 / stride 1 / pad 1 among those — the row-sharing kernels of split_gemm_conv3.hip."""
+    if split and dma and conv3:
+        return LIB.wd_conv_gemm_split_config(m, n, k, 5).decode()
     if split and dma:
         return LIB.wd_conv_gemm_split_config(m, n, k, 4).decode()
     if split:
