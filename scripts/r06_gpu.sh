@@ -152,6 +152,14 @@ ceiling)
   WEDETECT_LIB=$GRAFT_REPO_ROOT/wedetect_amd/libwedetect_hip_abl.so python scripts/p8_ceiling.py > $OUT/p8_ceiling.jsonl 2> $OUT/p8_ceiling.err
   cat $OUT/p8_ceiling.jsonl; tail -3 $OUT/p8_ceiling.err
   ;;
+dryrun)
+  # the N > 1 code of bench.py with 8 / 2 gloo ranks time-sliced on the one GPU of this pool (not a scaling measurement)
+  WEDETECT_BENCH_SHARE_GPU=1 WEDETECT_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 8 --batch 4 --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-reference --no-host-fed --no-other-configs > $OUT/bench_n8_dry.json 2> $OUT/bench_n8_dry.err
+  WEDETECT_BENCH_SHARE_GPU=1 WEDETECT_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 --batch 32 --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-reference --no-host-fed --no-other-configs > $OUT/bench_n2_dry.json 2> $OUT/bench_n2_dry.err
+  WEDETECT_BENCH_SHARE_GPU=1 WEDETECT_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 --mode retrieval --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_n2_retrieval_dry.json 2> $OUT/bench_n2_retrieval_dry.err
+  for f in $OUT/bench_n*_dry.json; do python -c "
+import json; d=json.loads(open('$f').read().strip().splitlines()[-1]); print('$f'.split('/')[-1], d['n_gpus'], d.get('ranks_seen'), d.get('collective_backend'), d['value'], d['unit'])" || tail -n 5 ${f%.json}.err; done
+  ;;
 midclass)
   # mid-class latency split-K (5 - 8 images of 640 x 640): class-invariance test, B = 5 .. 8 with / without, B = 1 / 4 unchanged
   ( timeout 1200 python -m pytest tests/test_gpu_network.py -q -m gpu -k "latency or split_k or mid_class" -x 2>&1 | tail -6 ) > $OUT/tests.log
