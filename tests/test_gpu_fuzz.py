@@ -152,3 +152,52 @@ def test_split_k_conv_and_special_epilogue():
     L.conv_gemm(a, w, None, c0, **kw)
     L.conv_gemm(a, None, None, c1, w_split=L.split_weights(w), workspace=torch.empty(4 * m * n, device="cuda"), k_splits=4, **kw)
     assert_close("split-K seg + sigmoid", c1, c0, 2e-6)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_conv3_random_geometry_all_forms_bit_identical(seed):
+    """Round 6: random 3 x 3 / stride 1 geometries on pre-split activations — maps narrower than a tile row, tiles that end mid-row
+    and mid-image, ragged channel counts (cin % 16 == 0, n % 8 == 0), one- and two-stage K loops, residual and dual outputs, K
+    splits — through the production choice (twelve-wave producer / consumer kernel), the eight-wave staggered form (cfg 77) and the
+    in-step form of round 4 (cfg 78): the same bits, and within 2e-5 of a float64 convolution of the same (hi + lo) operands."""
+    from wedetect_amd import lib as L
+    g = torch.Generator(device="cuda").manual_seed(900 + seed)
+    rnd = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g, device="cuda"))
+    for _ in range(4):
+        b_, h, w_ = rnd(1, 5), rnd(2, 45), rnd(2, 45)
+        ci, co = 16 * rnd(1, 9), 8 * rnd(1, 40)
+        m = b_ * h * w_
+        x = torch.randn(m, ci, device="cuda", generator=g)
+        wrow = torch.randn(co, 9 * ci, device="cuda", generator=g) * (9 * ci) ** -0.5
+        bias = torch.randn(co, device="cuda", generator=g)
+        res = torch.randn(m, co, device="cuda", generator=g)
+        ws = L.split_weights(wrow)
+        xs = torch.empty(m, ci, device="cuda")
+        L.check(L.LIB.wd_split_weights(x.data_ptr(), m, ci, 1.0, xs.data_ptr(), L.stream_ptr()), "split")
+        splits = rnd(1, 3)
+        geo = dict(batch=b_, hin=h, win=w_, cin=ci, lda=ci, kh=3, kw=3, stride=1, pad=1, n=co, ldc=co, act=L.ACT_SILU, res=res, ldres=co,
+                   res_alpha=0.25, w_split=ws)
+        if splits > 1:
+            geo.update(workspace=torch.empty(splits * m * co + 64, device="cuda"), k_splits=splits)
+        outs = {}
+        for cfg in (-1, 77, 78, 79):
+            c = torch.full((m, co), float("nan"), device="cuda")
+            c2 = torch.full((m, co), float("nan"), device="cuda")
+            cs = torch.full((m, co), float("nan"), device="cuda")
+            L.conv_gemm(xs, None, bias, c, split_flags=L.SPLIT_A, split_cfg=cfg, **geo)
+            L.conv_gemm(xs, None, bias, cs, split_flags=L.SPLIT_A | L.SPLIT_C, split_cfg=cfg, c2=c2, ldc2=co, **geo)
+            outs[cfg] = (c, cs, c2)
+        what = f"b{b_} {h}x{w_} c{ci}->{co} splits {splits}"
+        for cfg in (-1, 77, 79):
+            for a, b in zip(outs[cfg], outs[78]):
+                assert torch.equal(a.view(torch.int32), b.view(torch.int32)), f"cfg {cfg} != cfg 78: {what}"
+        assert torch.equal(outs[78][0], outs[78][2]), f"fp32 twin != fp32 output: {what}"
+        # float64 reference on the split operands ([hi x8 | lo x8] groups)
+        hl = xs.contiguous().view(torch.float16).view(m, ci // 8, 2, 8)
+        xd = (hl[:, :, 0].double() + hl[:, :, 1].double()).reshape(m, ci)
+        xd4 = xd.view(b_, h, w_, ci).permute(0, 3, 1, 2)
+        wd = wrow.double().view(co, 3, 3, ci).permute(0, 3, 1, 2)
+        ref = torch.nn.functional.conv2d(xd4, wd, bias.double(), padding=1).permute(0, 2, 3, 1).reshape(m, co)
+        ref = torch.nn.functional.silu(ref) + 0.25 * res.double()
+        err = float((outs[78][0].double() - ref).abs().max())
+        assert err < 3e-5 * max(1.0, float(ref.abs().max())), f"{what}: max|d| {err:.3e}"
