@@ -284,7 +284,7 @@ class GemmTimer:
             rec.setdefault(SIM_SPLIT_TAG, []).append((s, e, 2.0 * rows * n_cls * dim, nbytes))
         lib.similarity_split = wrapped_sim
 
-    def summary(self):
+    def summary(self, busy: bool = False):
         out = {}
         merged = {}
         for tag, lst in self.rec.items():
@@ -296,7 +296,34 @@ class GemmTimer:
             fl = sum(r[2] for r in lst)
             out[tag] = dict(launches=len(lst), ms_total=ms, flops_total=fl, bytes_total=sum(r[3] for r in lst),
                             avg_us=1e3 * ms / len(lst), tflops=fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0)
+            if busy:
+                # launches of one family on different streams overlap in time (image chains): the time during which AT LEAST ONE of
+                # them was running = the union of their [begin, end] intervals on the device clock
+                t0 = lst[0][0]
+                iv = sorted((t0.elapsed_time(r[0]), t0.elapsed_time(r[1])) for r in lst)
+                tot, (lo, hi) = 0.0, iv[0]
+                for a_, b_ in iv[1:]:
+                    if a_ > hi:
+                        tot, lo, hi = tot + hi - lo, a_, b_
+                    else:
+                        hi = max(hi, b_)
+                out[tag]["busy_ms"] = tot + hi - lo
         return out
+
+
+def timed_region_record(summ, dom_tag, peak, n_inst, tower):
+    """The dominant kernel family as stamped INSIDE the timed region, where its launches run beside launches of other streams
+    (the other image chain's, the previous step's neck / head): raw per-launch average (what a rocprofv3 trace of the default
+    command shows) and the family's flops over the time at least one of its launches was running."""
+    d = summ.get(dom_tag) or max(summ.values(), key=lambda v: v["flops_total"])
+    fl, busy, n, ms = d["flops_total"], d.get("busy_ms", d["ms_total"]), d["launches"], d["ms_total"]
+    return {"image_chains": tower._n_chains(), "neck_head_on_nh_stream": bool(tower._pipe_neck_on()),
+            "launches_per_step": n // n_inst, "avg_launch_us_raw": round(1e3 * ms / max(1, n), 2),
+            "algorithmic_gflop_per_launch": round(fl / max(1, n) / 1e9, 3),
+            "busy_ms_per_step": round(busy / n_inst, 3),
+            "achieved_over_busy_time": round(fl / (busy * 1e-3) / 1e12, 2) if busy > 0 else None,
+            "frac_over_busy_time": round(fl / (busy * 1e-3) / 1e12 / peak, 4) if busy > 0 else None,
+            "note": "busy time = union of the family's [begin, end] stamps on the device clock; other kernels run inside it"}
 
 
 class ClockSampler:
@@ -557,6 +584,17 @@ def detect_leg(timer, L, arch, B, K, uni, steps=5, warmup=2):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     timer.mode = "off"
+    if tower._n_chains() > 1 or tower._pipe_neck_on():
+        # per-kernel figures from a serial step (see main(): in the pipelined steps launches of several streams share the chip)
+        timer.rec.clear()
+        tower.bb_chains, tower.pipe_neck = "1", "0"
+        tower.detect(images, text, meta, **kw)
+        torch.cuda.synchronize()
+        timer.prepare(timer.count // max(1, warmup))
+        timer.mode = "time"
+        tower.detect(images, text, meta, **kw)
+        torch.cuda.synchronize()
+        timer.mode = "off"
     summ = timer.summary()
     timer.rec.clear()
     out = {"workload": f"WeDetect-{arch.capitalize()}{'-Uni' if uni else ''}, batch {B}x{S}x{S}, {K}-class similarity, mode "
@@ -936,6 +974,31 @@ def main():
     kept = int(res["count"].sum().item())
     overflow = bool((res["count"] < 0).any().item()) or bool(tower.range_flags.any().item())     # fp16x3 range guards
 
+    # Round 6: in the timed region the backbone runs as image chains on two streams and the neck / head of step i beside the
+    # backbone of step i + 1 (engine.ImageTower: bb_chains, pipe_neck): a launch then shares the chip with launches of other
+    # streams and its begin-to-end time is no longer its own.  The per-kernel figures of the line (roofline, gemm_kernels,
+    # sim_gemm) therefore come from a SERIAL LEG — the same step, same kernels, one launch at a time on one stream (DAG lanes of
+    # the neck aside, as in rounds 1-5), two warm-ups + n_inst instrumented steps right after the timed region — and the timed
+    # region's own stamps are kept beside them (roofline.timed_region).
+    concurrent = overlap and (tower._n_chains() > 1 or tower._pipe_neck_on())
+    timed_summ = None
+    if concurrent:
+        dog.phase("serial leg (per-kernel timing)")
+        timed_summ = timer.summary(busy=True) if rank == 0 else None
+        saved_modes = (tower.bb_chains, tower.pipe_neck)
+        tower.bb_chains, tower.pipe_neck = "1", "0"
+        for _ in range(2):
+            step()
+        sync()
+        timer.rec.clear()
+        timer.prepare(timer.count // max(1, args.warmup) * n_inst)
+        timer.mode = "time"
+        for _ in range(n_inst):
+            step()
+        sync()
+        timer.mode = "off"
+        tower.bb_chains, tower.pipe_neck = saved_modes
+
     if rank == 0:
         summ = timer.summary()
         dom_tag = max(summ, key=lambda k: summ[k]["flops_total"])
@@ -970,8 +1033,12 @@ def main():
                        "global_batch": world * B, "per_gpu_batch": B, "image": [S, S], "classes": K,
                        "parallelism": f"image-shard x{world}" + (" + all-gather of kept-region embeddings" if world > 1 else ""),
                        "precision": tower.precision,
-                       "pipelining": ("top-k / NMS of step i on a second stream beside the backbone of step i + 1 (same kernels; every "
-                                      "step's post-process completes inside the timed bracket); --no-overlap-post issues them in line"
+                       "pipelining": (("neck + head + similarity of step i on the tower's nh stream and its top-k / NMS on the post stream beside "
+                                       "the backbone of step i + 1" if tower._pipe_neck_on() else
+                                       "top-k / NMS of step i on a second stream beside the backbone of step i + 1")
+                                      + f"; backbone as {tower._n_chains()} image chain(s)"
+                                      + " (same kernels, bit-identical results; every step completes inside the timed bracket); "
+                                        "--no-overlap-post issues a step's kernels in line"
                                       if overlap else "none: every kernel of a step on one stream"),
                        **({"precision_evidence": "error vs a float64 run of the same network (oracle, Base@128): embeddings "
                            "fp32 8.5e-6 / fp16x3 9.5e-6, scores 8.0e-7 / 9.2e-7 (tests/probe_split_precision.py); on device the "
@@ -996,11 +1063,16 @@ def main():
                          "traffic_unit": "HBM bytes per launch (PMC, separate rocprofv3 passes; see traffic_provenance)",
                          **({"power_limited_ceiling": power_ceiling()} if dom_split else {}),
                          "timing": "HIP events stamped by each kernel's own dispatch (hipExtLaunchKernelGGL via "
-                                   f"wd_time_next_gemm) on the launch stream, every GEMM launch of the last {n_inst} of the "
-                                   f"{args.steps} timed steps (stamping all steps would slow the step it measures by 2.4 %)",
+                                   "wd_time_next_gemm) on the launch stream, every GEMM launch of "
+                                   + (f"the serial leg's {n_inst} instrumented steps (measured_in)" if concurrent else
+                                      f"the last {n_inst} of the {args.steps} timed steps (stamping all steps would slow the step it measures by 2.4 %)"),
                          "algorithmic_bytes_per_launch": round(dom["bytes_total"] / dom["launches"]),
                          "launches_per_step": dom["launches"] // n_inst, "avg_launch_us": round(dom["avg_us"], 2),
-                         "algorithmic_gflop_per_launch": round(dom["flops_total"] / dom["launches"] / 1e9, 3)},
+                         "algorithmic_gflop_per_launch": round(dom["flops_total"] / dom["launches"] / 1e9, 3),
+                         **({"measured_in": f"serial leg: {n_inst} instrumented steps after two warm-ups, right after the timed region, "
+                                            "with WEDETECT_BB_CHAINS=1 WEDETECT_PIPE_NECK=0 semantics (one backbone chain, neck / head in line) — "
+                                            "in the timed region launches of several streams share the chip (timed_region below)",
+                             "timed_region": timed_region_record(timed_summ, dom_tag, dom_peak, n_inst, tower)} if concurrent else {})},
             "gemm_kernels": {k: {"launches_per_step": v["launches"] // n_inst, "avg_us": round(v["avg_us"], 2),
                                  "tflops": round(v["tflops"], 2)} for k, v in sorted(summ.items())},
         }

@@ -16,6 +16,86 @@ for f in sys.argv[1:]:
 PY
 }
 case $STEP in
+pipesmalldag)
+  for i in 1 2; do
+    for b in 1 4 8 16; do
+      WEDETECT_PIPE_NECK=1 python bench.py $Q --batch $b > $OUT/bench_b${b}_p1_dagoff_$i.json 2> $OUT/bench_b${b}_p1_dagoff_$i.err
+      WEDETECT_DAG=1 WEDETECT_PIPE_NECK=1 python bench.py $Q --batch $b > $OUT/bench_b${b}_p1_dag1_$i.json 2> $OUT/bench_b${b}_p1_dag1_$i.err
+    done
+  done
+  line $OUT/bench_*.json; cat $OUT/*.err | grep -v amdgpu.ids | tail -n 20
+  ;;
+pipesmall)
+  # the pipelined neck at small batches (latency split-K classes), tests first
+  ( timeout 1200 python -m pytest tests/test_gpu_network.py -q -m gpu -k "image_chains or pipelined or latency or mid_class" -x 2>&1 | tail -8 ) > $OUT/tests.log
+  for i in 1 2; do
+    for b in 1 2 4 8; do
+      for pn in 0 1; do
+        WEDETECT_PIPE_NECK=$pn python bench.py $Q --batch $b > $OUT/bench_b${b}_p${pn}_$i.json 2> $OUT/bench_b${b}_p${pn}_$i.err
+      done
+    done
+  done
+  cat $OUT/tests.log; line $OUT/bench_*.json; cat $OUT/*.err | grep -v amdgpu.ids | tail -n 20
+  ;;
+pipecfg)
+  # where do image chains / the pipelined neck pay?  other towers and batches, same-box alternating
+  for i in 1 2; do
+    for cfg in "tiny32:--arch tiny" "base64:--batch 64" "base16:--batch 16" "large16:--arch large --batch 16 --classes 1203" "uni32:--mode uni --classes 256"; do
+      name=${cfg%%:*}; fl=${cfg#*:}
+      for m in "1 0" "2 0" "1 1" "2 1"; do
+        set -- $m
+        WEDETECT_BB_CHAINS=$1 WEDETECT_PIPE_NECK=$2 python bench.py $Q $fl > $OUT/bench_${name}_c$1p$2_$i.json 2> $OUT/bench_${name}_c$1p$2_$i.err
+      done
+    done
+  done
+  line $OUT/bench_*.json; cat $OUT/*.err | grep -v amdgpu.ids | tail -n 20
+  ;;
+pipedag)
+  # with the neck / head pipelined beside the next backbone, is the DAG (three more streams on four hardware queues) still worth it?
+  for i in 1 2; do
+    for d in auto 0; do
+      for m in "1 1" "2 1" "2 0"; do
+        set -- $m
+        WEDETECT_DAG=$d WEDETECT_BB_CHAINS=$1 WEDETECT_PIPE_NECK=$2 python bench.py $Q > $OUT/bench_dag${d}_c$1p$2_$i.json 2> $OUT/bench_dag${d}_c$1p$2_$i.err
+      done
+    done
+  done
+  line $OUT/bench_*.json; cat $OUT/*.err | grep -v amdgpu.ids | tail -n 20
+  ;;
+hwq)
+  # do the streams of a step (caller, post, three DAG lanes, image chain, nh) collide on the runtime's 4 hardware queues?
+  for i in 1 2; do
+    for q in ${HWQS:-4 8}; do
+      for m in "1 0" "2 0" "1 1" "2 1"; do
+        set -- $m
+        GPU_MAX_HW_QUEUES=$q WEDETECT_BB_CHAINS=$1 WEDETECT_PIPE_NECK=$2 python bench.py $Q > $OUT/bench_q${q}_c$1p$2_$i.json 2> $OUT/bench_q${q}_c$1p$2_$i.err
+      done
+    done
+  done
+  line $OUT/bench_*.json; cat $OUT/*.err | grep -v amdgpu.ids | tail -n 20
+  ;;
+pipe)
+  # neck / head of step i on the nh stream beside the backbone of step i + 1: identity tests, same-box alternating A/B
+  ( timeout 1200 python -m pytest tests/test_gpu_network.py -q -m gpu -k "image_chains or pipelined" -x 2>&1 | tail -8 ) > $OUT/tests.log
+  for i in 1 2 3; do
+    WEDETECT_BB_CHAINS=1 WEDETECT_PIPE_NECK=0 python bench.py $Q > $OUT/bench_c1p0_$i.json 2> $OUT/bench_c1p0_$i.err
+    WEDETECT_BB_CHAINS=2 WEDETECT_PIPE_NECK=0 python bench.py $Q > $OUT/bench_c2p0_$i.json 2> $OUT/bench_c2p0_$i.err
+    WEDETECT_BB_CHAINS=1 WEDETECT_PIPE_NECK=1 python bench.py $Q > $OUT/bench_c1p1_$i.json 2> $OUT/bench_c1p1_$i.err
+    WEDETECT_BB_CHAINS=2 WEDETECT_PIPE_NECK=1 python bench.py $Q > $OUT/bench_c2p1_$i.json 2> $OUT/bench_c2p1_$i.err
+  done
+  cat $OUT/tests.log; line $OUT/bench_*.json; cat $OUT/*.err | grep -v amdgpu.ids | tail -n 20
+  ;;
+chains)
+  # backbone as independent image chains on side streams: identity test, then same-box alternating A/B of the step
+  ( timeout 1200 python -m pytest tests/test_gpu_network.py -q -m gpu -k "image_chains" -x 2>&1 | tail -8 ) > $OUT/tests.log
+  for i in 1 2 3; do
+    WEDETECT_BB_CHAINS=1 python bench.py $Q > $OUT/bench_chains1_$i.json 2> $OUT/bench_chains1_$i.err
+    for o in free dw gemm both; do
+      WEDETECT_BB_CHAINS=2 WEDETECT_BB_CHAIN_ORDER=$o python bench.py $Q > $OUT/bench_chains2_${o}_$i.json 2> $OUT/bench_chains2_${o}_$i.err
+    done
+  done
+  cat $OUT/tests.log; line $OUT/bench_*.json; tail -n 3 $OUT/*.err | tail -n 30
+  ;;
 baseline)
   python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
   WEDETECT_DAG=0 python bench.py $Q > $OUT/bench_dag0.json 2> $OUT/bench_dag0.err

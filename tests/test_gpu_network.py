@@ -328,6 +328,45 @@ def test_pipelined_post_process_equals_the_in_line_step():
         assert torch.equal(ref[0][k], r[k]), f"in-line step behind a pipelined one: {k} differs"
 
 
+@pytest.mark.parametrize("arch,b,hw,chains,dag,split_k", [("base", 2, 320, 1, True, False), ("tiny", 4, 128, 2, True, False),
+                                                           ("tiny", 3, 128, 1, False, False), ("base", 1, 320, 1, True, True)])
+def test_neck_head_pipelined_behind_the_next_backbone_equals_the_in_line_step(arch, b, hw, chains, dag, split_k):
+    """Round 6: in a stream of batches (detect(overlap_post=True)) the neck + head + similarity of step i run on the tower's nh
+    stream beside the BACKBONE of step i + 1 (c1..c4 double-buffered), the post-process behind them on the post stream.  Six
+    DIFFERENT batches issued back to back with no host synchronisation must give exactly the tensors of the in-line steps — with
+    the backbone as one chain or as image chains, the neck / head as a DAG or a serial chain, in the latency split-K class
+    (whose neck then takes split-K workspaces apart from the backbone's) — and so must an in-line step right behind a pipelined one."""
+    from wedetect_amd import weights as W
+    if split_k and PRECISION["value"] != "fp16x3":
+        pytest.skip("latency split-K is an fp16x3 mode")
+    _, t, _ = build(arch, b, hw, num_prompts=48, split_k=split_k)      # split_k: the latency class (its lanes own split-K workspaces)
+    meta = t.identity_meta()
+    batches = [torch.from_numpy(W.make_images(b, hw, hw, seed=950 + i)).cuda() for i in range(6)]
+    kw = dict(normalize_text=False, score_thr=0.0, with_embed=True)
+    t.bb_chains, t.pipe_neck, t.dag = "1", "0", False
+    ref = []
+    for x in batches:
+        r = t.detect(x, t.P["prompts"], meta, **kw)
+        torch.cuda.synchronize()
+        ref.append({k: v.clone() for k, v in r.items()})
+    t.bb_chains, t.pipe_neck, t.dag = str(chains), "1", dag
+    assert t._pipe_neck_on() and t._n_chains() == chains
+    got = []
+    for x in batches:                                   # no synchronisation between the calls
+        r = t.detect(x, t.P["prompts"], meta, overlap_post=True, **kw)
+        with torch.cuda.stream(t.post_stream):
+            got.append({k: v.clone() for k, v in r.items()})
+    r = t.detect(batches[0], t.P["prompts"], meta, **kw)     # in line, right behind a pipelined call
+    t.wait_post()
+    torch.cuda.synchronize()
+    assert t._nh_stream is not None and len(t._x_sets) == 2
+    for i, (a_, b_) in enumerate(zip(ref, got)):
+        for k in a_:
+            assert torch.equal(a_[k], b_[k]), f"batch {i}: {k} differs between the pipelined neck / head and the in-line step"
+    for k in ref[0]:
+        assert torch.equal(ref[0][k], r[k]), f"in-line step behind a pipelined one: {k} differs"
+
+
 @pytest.mark.parametrize("arch,b,hw", [("base", 2, 320), ("tiny", 3, 128)])
 def test_neck_head_dag_on_side_streams_equals_the_serial_chain(arch, b, hw):
     """Round 5: the neck / head issued as a DAG — BiFusion input branches on lanes 1 / 2 from the start of the neck, every
@@ -350,6 +389,7 @@ def test_neck_head_dag_on_side_streams_equals_the_serial_chain(arch, b, hw):
         ref.append({k: v.clone() for k, v in r.items()})
         feats.append((t.embed.clone(), t.boxes.clone(), [p.clone() for p in (t.p3, t.p4, t.p5)]))
     t.dag = t._dag_in_capture = True
+    t.pipe_neck = "0"          # round 6: a pipelined neck / head runs as one chain on the nh stream (its own test, above); here: the lanes
     assert t._dag_on()
     for overlap in (False, True):
         got = []
@@ -378,6 +418,53 @@ def test_neck_head_dag_on_side_streams_equals_the_serial_chain(arch, b, hw):
     torch.cuda.synchronize()
     for k in ref[3]:
         assert torch.equal(ref[3][k], out[k]), f"hipGraph replay of the DAG step: {k} differs"
+
+
+@pytest.mark.parametrize("arch,b,hw,chains,order", [("base", 4, 320, 2, "free"), ("base", 4, 256, 4, "both"), ("tiny", 6, 128, 2, "dw"),
+                                                    ("tiny", 4, 128, 2, "gemm")])
+def test_backbone_image_chains_equal_the_single_chain(arch, b, hw, chains, order):
+    """Round 6: the backbone issued as independent IMAGE chains (contiguous image groups, each running the whole ConvNeXt on its
+    own stream over its rows of the same buffers; mm_backbone.py:233-255 is batch-parallel throughout) must give EXACTLY the
+    tensors of the one-chain step — c1..c4, then everything downstream — for batches issued back to back with no host
+    synchronisation, with the post-process pipelined, and under hipGraph capture."""
+    from wedetect_amd import weights as W
+    from wedetect_amd.engine import GraphedDetect
+    _, t, _ = build(arch, b, hw, num_prompts=48, split_k=False)
+    meta = t.identity_meta()
+    batches = [torch.from_numpy(W.make_images(b, hw, hw, seed=900 + i)).cuda() for i in range(4)]
+    kw = dict(normalize_text=False, score_thr=0.0, with_embed=True)
+    t.bb_chains = "1"
+    assert t._n_chains() == 1
+    ref, cs = [], []
+    for x in batches:
+        r = t.detect(x, t.P["prompts"], meta, **kw)
+        torch.cuda.synchronize()
+        ref.append({k: v.clone() for k, v in r.items()})
+        cs.append([c.clone() for c in t.x])
+    t.bb_chains, t.bb_chain_order = str(chains), order
+    t._dag_in_capture = True
+    assert t._n_chains() == chains
+    t.backbone(batches[1])
+    torch.cuda.synchronize()
+    for i, (g_, r_) in enumerate(zip(t.x, cs[1])):
+        assert torch.equal(g_, r_), f"c{i + 1} differs between {chains} image chains and one"
+    for overlap in (False, True):
+        got = []
+        for x in batches:                               # no synchronisation between the calls
+            r = t.detect(x, t.P["prompts"], meta, overlap_post=overlap, **kw)
+            with torch.cuda.stream(t.post_stream if overlap else torch.cuda.current_stream()):
+                got.append({k: v.clone() for k, v in r.items()})
+        t.wait_post()
+        torch.cuda.synchronize()
+        assert len(t._chain_evs) == 3 * chains
+        for i, (a_, b_) in enumerate(zip(ref, got)):
+            for k in a_:
+                assert torch.equal(a_[k], b_[k]), f"batch {i} (overlap_post={overlap}): {k} differs between {chains} image chains and one"
+    g = GraphedDetect(t, 48, normalize_text=False, score_thr=0.0)
+    out = {k: v.clone() for k, v in g(batches[3], t.P["prompts"], meta).items()}
+    torch.cuda.synchronize()
+    for k in ref[3]:
+        assert torch.equal(ref[3][k], out[k]), f"hipGraph replay of the image-chain step: {k} differs"
 
 
 def test_hipgraph_replay_equals_eager_and_is_faster_at_batch1():

@@ -14,6 +14,8 @@ Reference call stack being replaced:
 """
 from __future__ import annotations
 
+import contextlib
+import copy
 import math
 import os
 import weakref
@@ -121,6 +123,7 @@ class ImageTower:
         # "auto" = always when launching eagerly, from that size under capture.
         dag = os.environ.get("WEDETECT_DAG", "auto")
         self.dag = dag != "0"
+        self._dag_forced = dag == "1"
         self._dag_in_capture = dag == "1" or batch * height * width >= 8 * 640 * 640
         self._side: List[torch.cuda.Stream] = []
         self._events: List[torch.cuda.Event] = []
@@ -129,6 +132,34 @@ class ImageTower:
         self._lane_i = 0
         self._fws_lane: Dict[int, torch.Tensor] = {}
         self._head_evs: List[torch.cuda.Event] = []
+        # Backbone as INDEPENDENT IMAGE CHAINS on side streams (round 6, late; $WEDETECT_BB_CHAINS = "auto" (default), "1" = one
+        # chain = rounds 1-5, "2" / "4": that many).  A ConvNeXt stage is one dependent chain of launches — depthwise 7 x 7 (HBM-bound,
+        # no MFMA), statistics finalize, pwconv1, pwconv2 (MFMA-bound, the HBM idle) — but only ALONG an image: images never meet
+        # before the result gather (mm_backbone.py:233-255 is batch-parallel throughout).  The batch is cut into contiguous image
+        # groups, each group runs the whole backbone on its own stream over row slices of the SAME buffers, the neck starts when
+        # all have arrived: one group's depthwise / LayerNorm launches then run beside another's GEMMs and the tail of one
+        # launch is filled by the next group's head.  Same kernels on the same rows (every kernel form gives a row the same
+        # bits whatever batch it arrives in): bit-identical to the one-chain step
+        # (tests/test_gpu_network.py::test_backbone_image_chains_equal_the_single_chain).  "auto": two chains for large towers
+        # (no latency split-K: that class splits K by the batch's reference geometry) of at least BB_CHAINS_MIN_PIXELS per batch.
+        self.bb_chains = os.environ.get("WEDETECT_BB_CHAINS", "auto")
+        self.bb_chain_order = os.environ.get("WEDETECT_BB_CHAIN_ORDER", "free")
+        self._chain_streams: List[torch.cuda.Stream] = []
+        # A stream of batches (detect(overlap_post=True)), round 6, late: neck + head + similarity of step i on the tower's own
+        # "nh" stream beside the BACKBONE of step i + 1 ($WEDETECT_PIPE_NECK = "auto" (default: the towers that run image chains),
+        # "1", "0").  The neck / head launches fill 50 - 200 of 256 CUs at 0.15 - 0.45 of the MFMA roof; the next batch's
+        # backbone — which touches none of their buffers once c1..c4 are double-buffered (0.8 GB for Base, B = 32) — runs in
+        # the gaps.  Same kernels, same arguments: bit-identical results
+        # (tests/test_gpu_network.py::test_neck_head_pipelined_behind_the_next_backbone_equals_the_in_line_step).
+        self.pipe_neck = os.environ.get("WEDETECT_PIPE_NECK", "auto")
+        self._nh_stream: Optional[torch.cuda.Stream] = None
+        self._nh_issue = False                    # neck / head launches are being issued on the nh stream (never lend them self.park)
+        self._x_sets: List[List[torch.Tensor]] = []
+        self._x_par = 0
+        self._x_free: List[Optional[torch.cuda.Event]] = [None, None]
+        self._bb_done: Optional[torch.cuda.Event] = None
+        self._chain_parks: Dict[int, torch.Tensor] = {}
+        self._chain_evs: List[torch.cuda.Event] = []
         self.s2d_down = os.environ.get("WEDETECT_S2D_DOWN", "1") != "0"     # downsample convs as plain GEMMs on space-to-depth LayerNorm rows
         self.park = None
         if precision == "fp16x3" and self.p8_mode == "persist" and L.p8_workspace_bytes() > 0:
@@ -331,7 +362,7 @@ class ImageTower:
         if ws is not None and (kw.get("split_flags", 0) & L.SPLIT_A):
             plain = kw.get("kh", 1) == 1 and kw.get("kw", 1) == 1 and kw.get("stride", 1) == 1 and kw.get("pad", 0) == 0
             m = self.B * kw["hin"] * kw["win"]
-            if plain and self.park is not None and self._lane_i == 0 and L.gemm_config(m, kw["n"], kw["cin"], split=True, presplit=True,
+            if plain and self.park is not None and self._lane_i == 0 and not self._nh_issue and L.gemm_config(m, kw["n"], kw["cin"], split=True, presplit=True,
                                                                                        park=True).endswith("/p8s"):
                 work = self.park
             elif plain and self.p8_mode == "0" and kw["cin"] % 16 == 0:
@@ -519,6 +550,12 @@ class ImageTower:
     def _dag_on(self) -> bool:
         """Side streams are used for a step only outside the calibration pass (its recorders are torch ops on the current
         stream) and without the opt-in latency split-K (one shared workspace)."""
+        if self._nh_issue and not self._dag_forced:
+            # round 6: a neck / head pipelined beside the NEXT batch's backbone (detect(overlap_post=True), _pipe_neck_on) is one
+            # serial chain on the nh stream: the backbone fills its under-filled launches, and caller + image chain + nh + post are
+            # exactly the runtime's four hardware queues — three more lane streams would share queues with them and serialise
+            # behind the backbone (Base B = 32: 963 images/s against 934 with the lanes, profiles/r06_pipeline.txt)
+            return False
         return (self.dag and self._calib is None
                 and (self._dag_in_capture or not torch.cuda.is_current_stream_capturing()))
 
@@ -528,16 +565,19 @@ class ImageTower:
         stream capture (a captured step has run eagerly before: GraphedDetect warms up)."""
         if self.kws is None:
             return None
-        w = self.kws if self._lane_i == 0 else self._kws_lane.get(self._lane_i)
+        # a neck / head issued on the nh stream runs beside the NEXT step's backbone (lane 0 of the caller's stream): its lanes,
+        # lane 0 included, take workspaces of their own
+        li = self._lane_i + (16 if self._nh_issue else 0)
+        w = self.kws if li == 0 else self._kws_lane.get(li)
         if w is None or w.numel() < need:
             if torch.cuda.is_current_stream_capturing():
                 raise L.WedetectHipError("split-K workspace must be grown before stream capture (run the step eagerly once)")
             w = torch.empty(max(need, self.kws.numel()), dtype=torch.float32, device=self.dev)
-            if self._lane_i == 0:
+            if li == 0:
                 self.kws = w
                 self.generation += 1
             else:
-                self._kws_lane[self._lane_i] = w
+                self._kws_lane[li] = w
         return w
 
     def _lane_fws(self) -> torch.Tensor:
@@ -590,12 +630,114 @@ class ImageTower:
                 st.wait_event(ev)
 
     # ------------------------------------------------------------------ backbone
+    BB_CHAINS_MIN_PIXELS = 32 * 640 * 640
+    PIPE_NECK_MIN_PIXELS = 0                 # every size gains (B = 1 ... 64, profiles/r06_pipeline.txt)
+
+    def _n_chains(self) -> int:
+        """Image chains of this step's backbone (see __init__): 1 inside the calibration pass (its recorders are torch ops on
+        the current stream), in the latency split-K classes, and wherever the DAG rule keeps a captured step on one stream."""
+        if self.bb_chains == "1" or self._calib is not None or self.kws is not None:
+            return 1
+        if torch.cuda.is_current_stream_capturing() and not self._dag_in_capture:
+            return 1
+        n = 2 if self.bb_chains == "auto" else int(self.bb_chains)
+        if self.bb_chains == "auto" and not (self.BB_CHAINS_MIN_PIXELS <= self.B * self.H * self.W < 2 * self.BB_CHAINS_MIN_PIXELS):
+            return 1                # measured window (profiles/r06_pipeline.txt): pays at 32 x 640 x 640, loses at 16 x and 64 x
+        while n > 1 and (self.B % n or any(t.numel() % (64 * n) for t in (self.tmp, self.hid))):
+            n -= 1
+        return max(1, n)
+
+    def _chain_views(self, n: int) -> List["ImageTower"]:
+        """``n`` shallow copies of the tower, each seeing batch B / n: its images' ROWS of the residual streams c1..c4 (the very
+        buffers the neck reads afterwards), its own n-th of the scratch buffers, its own park workspace (two persistent launches
+        may be in flight at once).  Weights, split caches, scales and flags are shared by reference; built per step — the
+        towers' switches (precision fallback, pins) may change between steps."""
+        if self._park_mlp is None:
+            self._park_mlp = self.park if self.park is not None else torch.zeros(
+                max(1, L.p8_workspace_bytes() // 4), dtype=torch.float32, device=self.dev)
+        part = lambda t, h: None if t is None else t[h * (t.numel() // n): (h + 1) * (t.numel() // n)]
+        views = []
+        for h in range(n):
+            v = copy.copy(self)
+            v.B = self.B // n
+            v.M = [m // n for m in self.M]
+            v.x = [t[h * (m // n): (h + 1) * (m // n)] for t, m in zip(self.x, self.M)]
+            v.patches = self.patches[h * v.M[0]: (h + 1) * v.M[0]]
+            v.tmp, v.hid, v.ln_part, v.ln_stats = part(self.tmp, h), part(self.hid, h), part(self.ln_part, h), part(self.ln_stats, h)
+            v._lane_i = 0
+            if h:
+                if h not in self._chain_parks:
+                    if torch.cuda.is_current_stream_capturing():
+                        raise L.WedetectHipError("image-chain workspaces must exist before stream capture (run the step eagerly once)")
+                    self._chain_parks[h] = torch.zeros(max(1, L.p8_workspace_bytes() // 4), dtype=torch.float32, device=self.dev)
+                v.park = self._chain_parks[h] if self.park is not None else None
+                v._park_mlp = self._chain_parks[h]
+            views.append(v)
+        return views
+
     def backbone(self, images_u8: torch.Tensor) -> List[torch.Tensor]:
-        a, B = self.a, self.B
+        B = self.B
         if images_u8.dtype != torch.uint8 or tuple(images_u8.shape) != (B, self.H, self.W, 3):
             raise L.WedetectHipError(f"images must be uint8 [{B},{self.H},{self.W},3] (RGB, NHWC)")
         if not images_u8.is_contiguous():
             images_u8 = images_u8.contiguous()
+        n = self._n_chains()
+        if n == 1:
+            for _ in self._backbone_blocks(images_u8):
+                pass
+            return self.x
+        # n image chains: chain 0 on the caller's stream, chain h on side stream h - 1; launches are issued phase by phase in
+        # turn so that no stream's queue runs dry while the host is busy with another's
+        views = self._chain_views(n)
+        while len(self._chain_streams) < n - 1:        # their own streams: the DAG lanes may be running the previous step's neck
+            self._chain_streams.append(torch.cuda.Stream(device=self.dev))
+        while len(self._chain_evs) < 3 * n:
+            self._chain_evs.append(torch.cuda.Event())
+        done, ev_dw, ev_mlp = self._chain_evs[:n], self._chain_evs[n:2 * n], self._chain_evs[2 * n:3 * n]
+        main = torch.cuda.current_stream()
+        streams = [main] + self._chain_streams[: n - 1]
+        done[0].record(main)
+        gens, pending = [], []
+        for h, v in enumerate(views):
+            if h:
+                streams[h].wait_event(done[0])          # everything issued before this step (the previous neck reads c1..c4)
+            gens.append(ImageTower._backbone_blocks(v, images_u8[h * v.B: (h + 1) * v.B]))
+            pending.append(next(gens[h]))               # the phase the chain issues next
+        order = self.bb_chain_order
+        rec_dw, rec_mlp = [False] * n, [False] * n
+        alive = list(range(n))
+        while alive:
+            for h in list(alive):
+                tag, before = pending[h], (h - 1) % n
+                with (torch.cuda.stream(streams[h]) if h else contextlib.nullcontext()):
+                    # phase order ACROSS chains ($WEDETECT_BB_CHAIN_ORDER): "dw" = the depthwise phases take turns (a chain's
+                    # HBM-bound phase then always runs beside another chain's GEMMs), "gemm" = the block MLPs take turns
+                    if tag == "dw" and order in ("dw", "both") and rec_dw[before]:
+                        streams[h].wait_event(ev_dw[before])
+                    if tag == "mlp" and order in ("gemm", "both") and rec_mlp[before]:
+                        streams[h].wait_event(ev_mlp[before])
+                    try:
+                        pending[h] = next(gens[h])
+                    except StopIteration:
+                        alive.remove(h)
+                        if h:
+                            done[h].record(streams[h])
+                    if tag == "dw" and order in ("dw", "both"):
+                        ev_dw[h].record(streams[h])
+                        rec_dw[h] = True
+                    if tag == "mlp" and order in ("gemm", "both"):
+                        ev_mlp[h].record(streams[h])
+                        rec_mlp[h] = True
+        for h in range(1, n):
+            main.wait_event(done[h])
+        return self.x
+
+    def _backbone_blocks(self, images_u8: torch.Tensor):
+        """The backbone's launches on the current stream as a generator: yields the name of the phase it issues NEXT — "stem",
+        "down" (downsample LayerNorm + conv), "dw" (depthwise 7 x 7 with its LayerNorm / statistics), "mlp" (the block MLP) —
+        ``backbone`` interleaves the image chains' launches at these points."""
+        a, B = self.a, self.B
+        yield "stem"
         if self.fuse_stem and a.dims[0] in L.STEM_FUSED_WIDTHS:
             # patchify + conv + LayerNorm in one fp32 kernel: the image is read once, the rows written once
             L.stem_fused(images_u8, self.P["stem.w"], self.P["stem.b"], self.P["stem.ln_w"], self.P["stem.ln_b"], self.x[0])
@@ -613,6 +755,7 @@ class ImageTower:
             pre = self.precision == "fp16x3" and c % 8 == 0 and (i == 0 or a.dims[i - 1] % 8 == 0)
             fa = L.SPLIT_A if pre else 0
             if i > 0:
+                yield "down"
                 cp = a.dims[i - 1]
                 hp, wp = self.hw[i - 1]
                 if pre and hp % 2 == 0 and wp % 2 == 0 and self.s2d_down:
@@ -631,6 +774,7 @@ class ImageTower:
                                stride=2, pad=0, n=c, ldc=c, split_flags=fa, a_key=f"down{i}.ln" if pre else None)
             for j in range(a.depths[i]):
                 q = f"s{i}.{j}."
+                yield "dw"
                 if self._fold_ok(i, pre) and not self.sscale.get(q + "fold_off"):
                     # LayerNorm folded into pwconv1: dwconv -> (split d, block statistics) -> row statistics -> GEMM
                     self._prepare_fold()            # buffers and folded weights exist since __init__; a switch flipped later lands here
@@ -638,6 +782,7 @@ class ImageTower:
                     L.dwconv7_stats(self.x[i], self.P[q + "dw_w"], self.P[q + "dw_b"], self.tmp, self.ln_part, B, h, w, c,
                                     scale=self.sscale.get(q + "dw", 1.0))
                     L.ln_stats_finalize(self.ln_part, self.ln_stats, self.M[i], c)
+                    yield "mlp"
                     if c in self.fuse_mlp_wide and L.mlp_wide_supported(self.M[i], c, 4 * c):
                         self._mlp_fused_fold(q, i)
                         continue
@@ -661,6 +806,7 @@ class ImageTower:
                         self._calib[q + "dw.mr"] = (d.mean(dim=1).abs() / d.std(dim=1, unbiased=False).clamp_min(1e-30)).max()
                     L.layernorm_rows(self.tmp, self.tmp, g_, b_, self.M[i], c, split=pre)
                 self._record(q + "ln", self.tmp[: self.M[i] * c])
+                yield "mlp"
                 if pre and self.fuse_mlp and L.mlp_fused_supported(self.M[i], c, 4 * c):
                     self._mlp_fused(q, i)       # pwconv1 -> GELU -> pwconv2 -> residual in one kernel: same bits
                     continue
@@ -673,7 +819,6 @@ class ImageTower:
                 # x <- x + (gamma*W2) hid + gamma*b2   (in place: each element is read then written by one lane)
                 self._conv(self.hid, q + "w2", q + "b2", self.x[i], hin=h, win=w, cin=4 * c, lda=4 * c, n=c, ldc=c,
                            res=self.x[i], ldres=c, split_flags=fa, a_key=q + "hid" if pre else None)
-        return self.x
 
     # ------------------------------------------------------------------ neck
     def _bepc3(self, name: str, x, ldx: int, cin: int, hw: Tuple[int, int], out, cout: int, xkey: str, okey: str):
@@ -1104,21 +1249,48 @@ class ImageTower:
             self.post_stream = torch.cuda.Stream(device=self.dev)
             self._post_ready = torch.cuda.Event()
         main = torch.cuda.current_stream()
+        pipe = self._pipe_neck_on()
+        if pipe:
+            # c1..c4 double-buffered: this backbone writes the set the neck of step i - 2 read
+            if not self._x_sets:
+                self._x_sets = [self.x, [torch.empty_like(t) for t in self.x]]
+                self._nh_stream = torch.cuda.Stream(device=self.dev)
+                self._bb_done = torch.cuda.Event()
+            self._x_par ^= 1
+            self.x = self._x_sets[self._x_par]
+            if self._x_free[self._x_par] is not None:
+                main.wait_event(self._x_free[self._x_par])
         self.backbone(images_u8)
-        if self._dag_on():
-            self.wait_post()                  # head level 0 starts inside the neck: the previous post-process must be done with
-            self.neck_head(text.shape[0])     # boxes / embeddings before ANY head kernel is issued (it had the whole backbone)
-        else:
-            self.neck()
-            self.wait_post()
-            self.head(text.shape[0])
-        scores = self.similarity(text, normalize=normalize_text)
-        self._post_ready.record(main)
-        # the caller's tensors are read by kernels on post_stream after this call returns: tell the caching allocator, or a
-        # caller that drops `meta` / `text` right away could see the block reused while top-k / NMS still read it
+        nh = self._nh_stream if pipe else main
+        if pipe:
+            self._bb_done.record(main)
+        with (torch.cuda.stream(nh) if pipe else contextlib.nullcontext()):
+            if pipe:
+                nh.wait_event(self._bb_done)
+                self._nh_issue = True
+            try:
+                if self._dag_on():
+                    self.wait_post()                  # head level 0 starts inside the neck: the previous post-process must be done with
+                    self.neck_head(text.shape[0])     # boxes / embeddings before ANY head kernel is issued (it had the whole backbone)
+                else:
+                    self.neck()
+                    self.wait_post()
+                    self.head(text.shape[0])
+                scores = self.similarity(text, normalize=normalize_text)
+            finally:
+                self._nh_issue = False
+            self._post_ready.record(nh)
+            if pipe:
+                if self._x_free[self._x_par] is None:
+                    self._x_free[self._x_par] = torch.cuda.Event()
+                self._x_free[self._x_par].record(nh)
+        # the caller's tensors are read by kernels on post_stream (and the nh stream) after this call returns: tell the caching
+        # allocator, or a caller that drops `meta` / `text` right away could see the block reused while they still read it
         for t_ in (meta, text):
             if isinstance(t_, torch.Tensor) and t_.is_cuda:
                 t_.record_stream(self.post_stream)
+                if pipe:
+                    t_.record_stream(nh)
         with torch.cuda.stream(self.post_stream):
             self.post_stream.wait_event(self._post_ready)
             res = self.postprocess(scores, score_thr, meta, iou_thr, with_embed, nms, nms_param, nms_device)
@@ -1126,6 +1298,12 @@ class ImageTower:
                 self._post_done = torch.cuda.Event()
             self._post_done.record(self.post_stream)
         return res
+
+    def _pipe_neck_on(self) -> bool:
+        """Neck / head of a pipelined step on the nh stream?  Never inside the calibration pass or stream capture."""
+        if self.pipe_neck == "0" or self._calib is not None or torch.cuda.is_current_stream_capturing():
+            return False
+        return self.pipe_neck == "1" or self.B * self.H * self.W >= self.PIPE_NECK_MIN_PIXELS
 
     def wait_post(self) -> None:
         """Makes the CURRENT stream wait for the post-process of the last ``detect(overlap_post=True)`` call (no-op otherwise)."""
