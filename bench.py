@@ -300,15 +300,22 @@ class GemmTimer:
                 # launches of one family on different streams overlap in time (image chains): the time during which AT LEAST ONE of
                 # them was running = the union of their [begin, end] intervals on the device clock
                 t0 = lst[0][0]
-                iv = sorted((t0.elapsed_time(r[0]), t0.elapsed_time(r[1])) for r in lst)
-                tot, (lo, hi) = 0.0, iv[0]
-                for a_, b_ in iv[1:]:
-                    if a_ > hi:
-                        tot, lo, hi = tot + hi - lo, a_, b_
-                    else:
-                        hi = max(hi, b_)
-                out[tag]["busy_ms"] = tot + hi - lo
+                out[tag]["busy_ms"] = union_length([(t0.elapsed_time(r[0]), t0.elapsed_time(r[1])) for r in lst])
         return out
+
+
+def union_length(intervals) -> float:
+    """Total length of the union of [begin, end] intervals (any order, may overlap or nest)."""
+    iv = sorted(intervals)
+    if not iv:
+        return 0.0
+    tot, (lo, hi) = 0.0, iv[0]
+    for a_, b_ in iv[1:]:
+        if a_ > hi:
+            tot, lo, hi = tot + hi - lo, a_, b_
+        else:
+            hi = max(hi, b_)
+    return tot + hi - lo
 
 
 def timed_region_record(summ, dom_tag, peak, n_inst, tower):

@@ -16,6 +16,15 @@ for f in sys.argv[1:]:
 PY
 }
 case $STEP in
+chainstages)
+  ( timeout 1200 python -m pytest tests/test_gpu_network.py -q -m gpu -k "image_chains or pipelined" -x 2>&1 | tail -8 ) > $OUT/tests.log
+  for i in 1 2; do
+    for st in 0-3 2-3 2-2 0-1 1-3; do
+      WEDETECT_BB_CHAIN_STAGES=$st python bench.py $Q > $OUT/bench_st${st}_$i.json 2> $OUT/bench_st${st}_$i.err
+    done
+  done
+  cat $OUT/tests.log; line $OUT/bench_*.json; cat $OUT/*.err | grep -v amdgpu.ids | tail -n 20
+  ;;
 pipesmalldag)
   for i in 1 2; do
     for b in 1 4 8 16; do

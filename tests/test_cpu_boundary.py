@@ -567,3 +567,49 @@ def test_bench_gpus_n_launches_n_ranks_itself(monkeypatch, capsys):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert "WORLD_SIZE 2" in str(e.value.code)
+
+
+def test_bench_busy_time_is_the_union_of_launch_intervals():
+    """Round 6: launches of one kernel family on different streams overlap (image chains; the previous step's neck beside the
+    next backbone) — bench.py reports the family's flops over the time AT LEAST ONE launch was running (roofline.timed_region)."""
+    import importlib
+    bench = importlib.import_module("bench")
+    u = bench.union_length
+    assert u([]) == 0.0
+    assert u([(0.0, 1.0), (2.0, 3.0)]) == 2.0                      # disjoint
+    assert u([(2.0, 3.0), (0.0, 1.0)]) == 2.0                      # any order
+    assert u([(0.0, 2.0), (1.0, 3.0)]) == 3.0                      # overlapping launches of two chains
+    assert u([(0.0, 5.0), (1.0, 2.0), (3.0, 4.0)]) == 5.0          # nested
+    assert u([(-1.0, 0.5), (0.5, 1.0)]) == 2.0                     # touching; a stamp before the reference event
+    rng = np.random.default_rng(5)
+    iv = [(float(a), float(a + d)) for a, d in zip(rng.uniform(0, 50, 200), rng.uniform(0.1, 3, 200))]
+    grid = np.zeros(60000, dtype=bool)                            # 1 us grid over 60 ms
+    for a, b in iv:
+        grid[int(round(a * 1000)): int(round(b * 1000))] = True
+    assert abs(u(iv) - grid.sum() / 1000.0) < 0.25
+
+
+def test_image_chain_and_pipeline_rules_are_host_logic(monkeypatch):
+    """engine.ImageTower's stream rules without a device: chains only in the measured window and never in the latency split-K
+    classes, the calibration pass on one stream, the chain views cut every buffer by rows."""
+    import types
+    from wedetect_amd.engine import ImageTower
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)        # no device here
+    t = types.SimpleNamespace(bb_chains="auto", _calib=None, kws=None, B=32, H=640, W=640, _dag_in_capture=True,
+                              tmp=torch.empty(3 << 12), hid=torch.empty(3 << 14), BB_CHAINS_MIN_PIXELS=ImageTower.BB_CHAINS_MIN_PIXELS)
+    n = lambda: ImageTower._n_chains(t)
+    assert n() == 2
+    t.B = 16
+    assert n() == 1                                               # below the window (measured: - 6 %)
+    t.B = 64
+    assert n() == 1                                               # above it (- 0.8 %)
+    t.B, t.kws = 32, torch.empty(4)
+    assert n() == 1                                               # latency split-K classes: one chain
+    t.kws, t._calib = None, {}
+    assert n() == 1                                               # calibration pass: its recorders are torch ops on one stream
+    t._calib, t.bb_chains = None, "4"
+    assert n() == 4
+    t.B = 6
+    assert n() == 3                                               # the largest count <= 4 that divides the batch
+    t.bb_chains = "1"
+    assert n() == 1

@@ -442,6 +442,7 @@ def test_backbone_image_chains_equal_the_single_chain(arch, b, hw, chains, order
         ref.append({k: v.clone() for k, v in r.items()})
         cs.append([c.clone() for c in t.x])
     t.bb_chains, t.bb_chain_order = str(chains), order
+    t.bb_chain_stages = {"free": (0, 3), "both": (2, 3), "dw": (1, 2), "gemm": (0, 1)}[order]     # the stages outside run as one chain
     t._dag_in_capture = True
     assert t._n_chains() == chains
     t.backbone(batches[1])

@@ -144,6 +144,8 @@ class ImageTower:
         # (no latency split-K: that class splits K by the batch's reference geometry) of at least BB_CHAINS_MIN_PIXELS per batch.
         self.bb_chains = os.environ.get("WEDETECT_BB_CHAINS", "auto")
         self.bb_chain_order = os.environ.get("WEDETECT_BB_CHAIN_ORDER", "free")
+        st = os.environ.get("WEDETECT_BB_CHAIN_STAGES", "0-3").split("-")       # the stages (0-based, inclusive) that run as chains
+        self.bb_chain_stages = (max(0, int(st[0])), min(3, int(st[-1])))
         self._chain_streams: List[torch.cuda.Stream] = []
         # A stream of batches (detect(overlap_post=True)), round 6, late: neck + head + similarity of step i on the tower's own
         # "nh" stream beside the BACKBONE of step i + 1 ($WEDETECT_PIPE_NECK = "auto" (default: the towers that run image chains),
@@ -681,13 +683,26 @@ class ImageTower:
             raise L.WedetectHipError(f"images must be uint8 [{B},{self.H},{self.W},3] (RGB, NHWC)")
         if not images_u8.is_contiguous():
             images_u8 = images_u8.contiguous()
+        if self._x_sets and self._x_free[self._x_par] is not None and not torch.cuda.is_current_stream_capturing():
+            # a pipelined step's neck (nh stream) may still be reading the c1..c4 set this backbone is about to overwrite
+            torch.cuda.current_stream().wait_event(self._x_free[self._x_par])
         n = self._n_chains()
-        if n == 1:
-            for _ in self._backbone_blocks(images_u8):
+        first, last = self.bb_chain_stages if n > 1 else (0, 3)
+        # the stages outside [first, last] run as ONE chain over the whole batch on the caller's stream
+        if n == 1 or first > 0:
+            for _ in self._backbone_blocks(images_u8, 0, 3 if n == 1 else first - 1):
                 pass
-            return self.x
-        # n image chains: chain 0 on the caller's stream, chain h on side stream h - 1; launches are issued phase by phase in
-        # turn so that no stream's queue runs dry while the host is busy with another's
+        if n > 1:
+            self._backbone_chains(images_u8, n, first, last)
+            if last < 3:
+                for _ in self._backbone_blocks(None, last + 1, 3):
+                    pass
+        return self.x
+
+    def _backbone_chains(self, images_u8: torch.Tensor, n: int, first: int, last: int) -> None:
+        """Stages ``first`` .. ``last`` (with the stem when first == 0) as ``n`` image chains: chain 0 on the caller's stream,
+        chain h on its own stream; launches are issued phase by phase in turn so that no stream's queue runs dry while the host
+        is busy with another's; the caller's stream continues when all chains have arrived."""
         views = self._chain_views(n)
         while len(self._chain_streams) < n - 1:        # their own streams: the DAG lanes may be running the previous step's neck
             self._chain_streams.append(torch.cuda.Stream(device=self.dev))
@@ -700,8 +715,8 @@ class ImageTower:
         gens, pending = [], []
         for h, v in enumerate(views):
             if h:
-                streams[h].wait_event(done[0])          # everything issued before this step (the previous neck reads c1..c4)
-            gens.append(ImageTower._backbone_blocks(v, images_u8[h * v.B: (h + 1) * v.B]))
+                streams[h].wait_event(done[0])          # everything issued before (the previous neck reads c1..c4; the stages before ``first``)
+            gens.append(ImageTower._backbone_blocks(v, images_u8[h * v.B: (h + 1) * v.B], first, last))
             pending.append(next(gens[h]))               # the phase the chain issues next
         order = self.bb_chain_order
         rec_dw, rec_mlp = [False] * n, [False] * n
@@ -710,8 +725,9 @@ class ImageTower:
             for h in list(alive):
                 tag, before = pending[h], (h - 1) % n
                 with (torch.cuda.stream(streams[h]) if h else contextlib.nullcontext()):
-                    # phase order ACROSS chains ($WEDETECT_BB_CHAIN_ORDER): "dw" = the depthwise phases take turns (a chain's
-                    # HBM-bound phase then always runs beside another chain's GEMMs), "gemm" = the block MLPs take turns
+                    # phase order ACROSS chains ($WEDETECT_BB_CHAIN_ORDER; measured, profiles/r06_pipeline.txt: "free" wins): "dw" =
+                    # the depthwise phases take turns (a chain's HBM-bound phase then always runs beside another chain's GEMMs),
+                    # "gemm" = the block MLPs take turns
                     if tag == "dw" and order in ("dw", "both") and rec_dw[before]:
                         streams[h].wait_event(ev_dw[before])
                     if tag == "mlp" and order in ("gemm", "both") and rec_mlp[before]:
@@ -730,14 +746,20 @@ class ImageTower:
                         rec_mlp[h] = True
         for h in range(1, n):
             main.wait_event(done[h])
-        return self.x
 
-    def _backbone_blocks(self, images_u8: torch.Tensor):
+    def _backbone_blocks(self, images_u8: Optional[torch.Tensor], first: int = 0, last: int = 3):
         """The backbone's launches on the current stream as a generator: yields the name of the phase it issues NEXT — "stem",
         "down" (downsample LayerNorm + conv), "dw" (depthwise 7 x 7 with its LayerNorm / statistics), "mlp" (the block MLP) —
         ``backbone`` interleaves the image chains' launches at these points."""
         a, B = self.a, self.B
-        yield "stem"
+        if first == 0:
+            yield "stem"
+            self._stem(images_u8)
+        for i in range(first, last + 1):
+            yield from self._stage(i)
+
+    def _stem(self, images_u8: torch.Tensor) -> None:
+        a = self.a
         if self.fuse_stem and a.dims[0] in L.STEM_FUSED_WIDTHS:
             # patchify + conv + LayerNorm in one fp32 kernel: the image is read once, the rows written once
             L.stem_fused(images_u8, self.P["stem.w"], self.P["stem.b"], self.P["stem.ln_w"], self.P["stem.ln_b"], self.x[0])
@@ -747,78 +769,81 @@ class ImageTower:
             self._conv(self.patches, "stem.w", "stem.b", self.x[0], hin=h0, win=w0, cin=48, lda=48, n=a.dims[0],
                        ldc=a.dims[0])
             L.layernorm_rows(self.x[0], self.x[0], self.P["stem.ln_w"], self.P["stem.ln_b"], self.M[0], a.dims[0])
-        for i in range(4):
-            c = a.dims[i]
-            h, w = self.hw[i]
-            # fp16x3: LayerNorm and pwconv1 write their outputs as fp16 hi/lo groups, so the GEMMs that
-            # consume them copy both operands (no per-column-tile conversion of the same rows)
-            pre = self.precision == "fp16x3" and c % 8 == 0 and (i == 0 or a.dims[i - 1] % 8 == 0)
-            fa = L.SPLIT_A if pre else 0
-            if i > 0:
-                yield "down"
-                cp = a.dims[i - 1]
-                hp, wp = self.hw[i - 1]
-                if pre and hp % 2 == 0 and wp % 2 == 0 and self.s2d_down:
-                    # LayerNorm writes the 2 x 2 / stride-2 convolution's GEMM rows directly (space-to-depth, (kh, kw, cin)
-                    # column order = the packed weight's): the downsample runs as a plain pre-split GEMM with K = 4 cp on
-                    # the DMA-fed kernels instead of the register-staged conv loader.  Same K order, same bits.
-                    g_, b_ = self._ln_params(f"down{i}.ln_w", f"down{i}.ln_b", f"down{i}.ln")
-                    L.layernorm_rows_split_s2d(self.x[i - 1], self.tmp, g_, b_, B, hp, wp, cp)
-                    self._gemm(self.tmp, f"down{i}.w", f"down{i}.b", self.x[i], hin=h, win=w, cin=4 * cp, lda=4 * cp, n=c,
-                               ldc=c, split_flags=fa, a_key=f"down{i}.ln")
-                else:
-                    g_, b_ = self._ln_params(f"down{i}.ln_w", f"down{i}.ln_b", f"down{i}.ln" if pre else None)
-                    L.layernorm_rows(self.x[i - 1], self.tmp, g_, b_, self.M[i - 1], cp, split=pre)
-                    self._record(f"down{i}.ln", self.tmp[: self.M[i - 1] * cp])
-                    self._gemm(self.tmp, f"down{i}.w", f"down{i}.b", self.x[i], hin=hp, win=wp, cin=cp, lda=cp, kh=2, kw=2,
-                               stride=2, pad=0, n=c, ldc=c, split_flags=fa, a_key=f"down{i}.ln" if pre else None)
-            for j in range(a.depths[i]):
-                q = f"s{i}.{j}."
-                yield "dw"
-                if self._fold_ok(i, pre) and not self.sscale.get(q + "fold_off"):
-                    # LayerNorm folded into pwconv1: dwconv -> (split d, block statistics) -> row statistics -> GEMM
-                    self._prepare_fold()            # buffers and folded weights exist since __init__; a switch flipped later lands here
-                    self._fold_weights(q)
-                    L.dwconv7_stats(self.x[i], self.P[q + "dw_w"], self.P[q + "dw_b"], self.tmp, self.ln_part, B, h, w, c,
-                                    scale=self.sscale.get(q + "dw", 1.0))
-                    L.ln_stats_finalize(self.ln_part, self.ln_stats, self.M[i], c)
-                    yield "mlp"
-                    if c in self.fuse_mlp_wide and L.mlp_wide_supported(self.M[i], c, 4 * c):
-                        self._mlp_fused_fold(q, i)
-                        continue
-                    self._conv(self.tmp, q + "w1g", q + "v", self.hid, hin=h, win=w, cin=c, lda=c, n=4 * c, ldc=4 * c,
-                               act=L.ACT_GELU, split_flags=L.SPLIT_A | L.SPLIT_C, a_key=q + "dw", c_key=q + "hid",
-                               ln_stats=self.ln_stats, ln_u=self.P[q + "u"])
-                    self._conv(self.hid, q + "w2", q + "b2", self.x[i], hin=h, win=w, cin=4 * c, lda=4 * c, n=c, ldc=c,
-                               res=self.x[i], ldres=c, split_flags=fa, a_key=q + "hid")
-                    continue
-                g_, b_ = self._ln_params(q + "ln_w", q + "ln_b", q + "ln" if pre else None)
-                if c % 32 == 0 and (self.fuse_dwln == "1" or (self.fuse_dwln == "auto" and (c <= 128 or c in self.fuse_dwln_wide))):   # bit-identical to the pair
-                    L.dwconv7_ln(self.x[i], self.P[q + "dw_w"], self.P[q + "dw_b"], self.tmp, g_, b_, B, h, w, c, split=pre)
-                else:
-                    L.dwconv7(self.x[i], self.P[q + "dw_w"], self.P[q + "dw_b"], self.tmp, B, h, w, c)
-                    if self._calib is not None and self.ln_fold:
-                        self._record(q + "dw", self.tmp[: self.M[i] * c])      # the folded path splits the pre-norm tensor itself
-                        # and centres AFTER the contraction: rstd (W'd - mean u) loses |mean| / std x 2^-22 of the output to
-                        # cancellation.  Record the worst row's |mean| / std; calibrate() keeps the LayerNorm kernel for a block
-                        # where it exceeds FOLD_MAX_MEAN_OVER_STD
-                        d = self.tmp[: self.M[i] * c].view(self.M[i], c)
-                        self._calib[q + "dw.mr"] = (d.mean(dim=1).abs() / d.std(dim=1, unbiased=False).clamp_min(1e-30)).max()
-                    L.layernorm_rows(self.tmp, self.tmp, g_, b_, self.M[i], c, split=pre)
-                self._record(q + "ln", self.tmp[: self.M[i] * c])
+
+    def _stage(self, i: int):
+        """Stage ``i`` of the backbone (downsample, then its blocks) as a generator, see ``_backbone_blocks``."""
+        a, B = self.a, self.B
+        c = a.dims[i]
+        h, w = self.hw[i]
+        # fp16x3: LayerNorm and pwconv1 write their outputs as fp16 hi/lo groups, so the GEMMs that
+        # consume them copy both operands (no per-column-tile conversion of the same rows)
+        pre = self.precision == "fp16x3" and c % 8 == 0 and (i == 0 or a.dims[i - 1] % 8 == 0)
+        fa = L.SPLIT_A if pre else 0
+        if i > 0:
+            yield "down"
+            cp = a.dims[i - 1]
+            hp, wp = self.hw[i - 1]
+            if pre and hp % 2 == 0 and wp % 2 == 0 and self.s2d_down:
+                # LayerNorm writes the 2 x 2 / stride-2 convolution's GEMM rows directly (space-to-depth, (kh, kw, cin)
+                # column order = the packed weight's): the downsample runs as a plain pre-split GEMM with K = 4 cp on
+                # the DMA-fed kernels instead of the register-staged conv loader.  Same K order, same bits.
+                g_, b_ = self._ln_params(f"down{i}.ln_w", f"down{i}.ln_b", f"down{i}.ln")
+                L.layernorm_rows_split_s2d(self.x[i - 1], self.tmp, g_, b_, B, hp, wp, cp)
+                self._gemm(self.tmp, f"down{i}.w", f"down{i}.b", self.x[i], hin=h, win=w, cin=4 * cp, lda=4 * cp, n=c,
+                           ldc=c, split_flags=fa, a_key=f"down{i}.ln")
+            else:
+                g_, b_ = self._ln_params(f"down{i}.ln_w", f"down{i}.ln_b", f"down{i}.ln" if pre else None)
+                L.layernorm_rows(self.x[i - 1], self.tmp, g_, b_, self.M[i - 1], cp, split=pre)
+                self._record(f"down{i}.ln", self.tmp[: self.M[i - 1] * cp])
+                self._gemm(self.tmp, f"down{i}.w", f"down{i}.b", self.x[i], hin=hp, win=wp, cin=cp, lda=cp, kh=2, kw=2,
+                           stride=2, pad=0, n=c, ldc=c, split_flags=fa, a_key=f"down{i}.ln" if pre else None)
+        for j in range(a.depths[i]):
+            q = f"s{i}.{j}."
+            yield "dw"
+            if self._fold_ok(i, pre) and not self.sscale.get(q + "fold_off"):
+                # LayerNorm folded into pwconv1: dwconv -> (split d, block statistics) -> row statistics -> GEMM
+                self._prepare_fold()            # buffers and folded weights exist since __init__; a switch flipped later lands here
+                self._fold_weights(q)
+                L.dwconv7_stats(self.x[i], self.P[q + "dw_w"], self.P[q + "dw_b"], self.tmp, self.ln_part, B, h, w, c,
+                                scale=self.sscale.get(q + "dw", 1.0))
+                L.ln_stats_finalize(self.ln_part, self.ln_stats, self.M[i], c)
                 yield "mlp"
-                if pre and self.fuse_mlp and L.mlp_fused_supported(self.M[i], c, 4 * c):
-                    self._mlp_fused(q, i)       # pwconv1 -> GELU -> pwconv2 -> residual in one kernel: same bits
+                if c in self.fuse_mlp_wide and L.mlp_wide_supported(self.M[i], c, 4 * c):
+                    self._mlp_fused_fold(q, i)
                     continue
-                if pre and c in self.fuse_mlp_wide and L.mlp_wide_supported(self.M[i], c, 4 * c):
-                    self._mlp_fused(q, i, wide=True)
-                    continue
-                self._conv(self.tmp, q + "w1", q + "b1", self.hid, hin=h, win=w, cin=c, lda=c, n=4 * c, ldc=4 * c,
-                           act=L.ACT_GELU, split_flags=(L.SPLIT_A | L.SPLIT_C) if pre else 0,
-                           a_key=q + "ln" if pre else None, c_key=q + "hid")
-                # x <- x + (gamma*W2) hid + gamma*b2   (in place: each element is read then written by one lane)
+                self._conv(self.tmp, q + "w1g", q + "v", self.hid, hin=h, win=w, cin=c, lda=c, n=4 * c, ldc=4 * c,
+                           act=L.ACT_GELU, split_flags=L.SPLIT_A | L.SPLIT_C, a_key=q + "dw", c_key=q + "hid",
+                           ln_stats=self.ln_stats, ln_u=self.P[q + "u"])
                 self._conv(self.hid, q + "w2", q + "b2", self.x[i], hin=h, win=w, cin=4 * c, lda=4 * c, n=c, ldc=c,
-                           res=self.x[i], ldres=c, split_flags=fa, a_key=q + "hid" if pre else None)
+                           res=self.x[i], ldres=c, split_flags=fa, a_key=q + "hid")
+                continue
+            g_, b_ = self._ln_params(q + "ln_w", q + "ln_b", q + "ln" if pre else None)
+            if c % 32 == 0 and (self.fuse_dwln == "1" or (self.fuse_dwln == "auto" and (c <= 128 or c in self.fuse_dwln_wide))):   # bit-identical to the pair
+                L.dwconv7_ln(self.x[i], self.P[q + "dw_w"], self.P[q + "dw_b"], self.tmp, g_, b_, B, h, w, c, split=pre)
+            else:
+                L.dwconv7(self.x[i], self.P[q + "dw_w"], self.P[q + "dw_b"], self.tmp, B, h, w, c)
+                if self._calib is not None and self.ln_fold:
+                    self._record(q + "dw", self.tmp[: self.M[i] * c])      # the folded path splits the pre-norm tensor itself
+                    # and centres AFTER the contraction: rstd (W'd - mean u) loses |mean| / std x 2^-22 of the output to
+                    # cancellation.  Record the worst row's |mean| / std; calibrate() keeps the LayerNorm kernel for a block
+                    # where it exceeds FOLD_MAX_MEAN_OVER_STD (ADVICE r5)
+                    d = self.tmp[: self.M[i] * c].view(self.M[i], c)
+                    self._calib[q + "dw.mr"] = (d.mean(dim=1).abs() / d.std(dim=1, unbiased=False).clamp_min(1e-30)).max()
+                L.layernorm_rows(self.tmp, self.tmp, g_, b_, self.M[i], c, split=pre)
+            self._record(q + "ln", self.tmp[: self.M[i] * c])
+            yield "mlp"
+            if pre and self.fuse_mlp and L.mlp_fused_supported(self.M[i], c, 4 * c):
+                self._mlp_fused(q, i)       # pwconv1 -> GELU -> pwconv2 -> residual in one kernel: same bits
+                continue
+            if pre and c in self.fuse_mlp_wide and L.mlp_wide_supported(self.M[i], c, 4 * c):
+                self._mlp_fused(q, i, wide=True)
+                continue
+            self._conv(self.tmp, q + "w1", q + "b1", self.hid, hin=h, win=w, cin=c, lda=c, n=4 * c, ldc=4 * c,
+                       act=L.ACT_GELU, split_flags=(L.SPLIT_A | L.SPLIT_C) if pre else 0,
+                       a_key=q + "ln" if pre else None, c_key=q + "hid")
+            # x <- x + (gamma*W2) hid + gamma*b2   (in place: each element is read then written by one lane)
+            self._conv(self.hid, q + "w2", q + "b2", self.x[i], hin=h, win=w, cin=4 * c, lda=4 * c, n=c, ldc=c,
+                       res=self.x[i], ldres=c, split_flags=fa, a_key=q + "hid" if pre else None)
 
     # ------------------------------------------------------------------ neck
     def _bepc3(self, name: str, x, ldx: int, cin: int, hw: Tuple[int, int], out, cout: int, xkey: str, okey: str):
@@ -1257,9 +1282,7 @@ class ImageTower:
                 self._nh_stream = torch.cuda.Stream(device=self.dev)
                 self._bb_done = torch.cuda.Event()
             self._x_par ^= 1
-            self.x = self._x_sets[self._x_par]
-            if self._x_free[self._x_par] is not None:
-                main.wait_event(self._x_free[self._x_par])
+            self.x = self._x_sets[self._x_par]        # backbone() waits for the neck that last read this set
         self.backbone(images_u8)
         nh = self._nh_stream if pipe else main
         if pipe:
