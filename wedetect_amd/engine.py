@@ -1247,6 +1247,7 @@ class ImageTower:
         return self.embed, self.boxes
 
     def features(self, images_u8: torch.Tensor, num_classes: Optional[int] = None):
+        self.wait_post()                          # a pipelined step may still be reading the buffers the head is about to write
         self.backbone(images_u8)
         return self.neck_head(num_classes)
 
@@ -1262,7 +1263,11 @@ class ImageTower:
         instead of behind it.  Same kernels, same buffers, same results; what changes is the contract: the returned
         tensors are produced on ``self.post_stream`` — call ``wait_post()`` (or synchronise the device) before reading them
         from another stream — and they are overwritten by the next call's post-process, as ever.  The next call's head
-        waits for this post-process before it overwrites the boxes / embeddings / scores it reads."""
+        waits for this post-process before it overwrites the boxes / embeddings / scores it reads.
+        Round 6: in this mode the neck, head and similarity GEMM of the step are issued on the tower's ``nh`` stream (``_pipe_neck_on``),
+        so that they run beside the NEXT call's backbone too; ``self.x`` alternates between two c1..c4 sets.  The contract is the
+        same — everything a step produces (``embed``, ``boxes``, ``scores`` included) is complete once ``wait_post()`` has been
+        honoured; a later in-line call, ``backbone()`` or ``features()`` orders itself behind the pending work by itself."""
         if nms is None:
             nms = "mmcv" if normalize_text else "torchvision"
         if not overlap_post:
