@@ -324,7 +324,9 @@ def timed_region_record(summ, dom_tag, peak, n_inst, tower):
     command shows) and the family's flops over the time at least one of its launches was running."""
     d = summ.get(dom_tag) or max(summ.values(), key=lambda v: v["flops_total"])
     fl, busy, n, ms = d["flops_total"], d.get("busy_ms", d["ms_total"]), d["launches"], d["ms_total"]
-    return {"image_chains": tower._n_chains(), "neck_head_on_nh_stream": bool(tower._pipe_neck_on()),
+    pipe = bool(tower._pipe_neck_on())
+    return {"backbones_in_flight": tower._bb_depth() if pipe else 1, "image_chains": 1 if pipe and tower._bb_depth() == 2 and tower.bb_chains == "auto" else tower._n_chains(),
+            "neck_head_on_nh_stream": pipe,
             "launches_per_step": n // n_inst, "avg_launch_us_raw": round(1e3 * ms / max(1, n), 2),
             "algorithmic_gflop_per_launch": round(fl / max(1, n) / 1e9, 3),
             "busy_ms_per_step": round(busy / n_inst, 3),
@@ -559,7 +561,7 @@ def fp32_sim_reference(tower, L, text, normalize, reps=5):
             "peak": F32_MFMA_PEAK_TFLOPS, "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4)}
 
 
-def detect_leg(timer, L, arch, B, K, uni, steps=5, warmup=2):
+def detect_leg(timer, L, arch, B, K, uni, steps=12, warmup=3):
     """A short run of ANOTHER BASELINE configuration inside the default invocation (configs[2] / [3] were
     builder-run files only): same protocol as the headline — calibration, ``warmup`` untimed steps, ``steps`` timed steps
     issued back to back with the post-process on the second stream, wall clock around a full drain — and the per-launch
@@ -1043,7 +1045,8 @@ def main():
                        "pipelining": (("neck + head + similarity of step i on the tower's nh stream and its top-k / NMS on the post stream beside "
                                        "the backbone of step i + 1" if tower._pipe_neck_on() else
                                        "top-k / NMS of step i on a second stream beside the backbone of step i + 1")
-                                      + f"; backbone as {tower._n_chains()} image chain(s)"
+                                      + (f"; two backbones in flight (steps alternate between two backbone streams)" if tower._pipe_neck_on() and tower._bb_depth() == 2
+                                         else f"; backbone as {tower._n_chains()} image chain(s)")
                                       + " (same kernels, bit-identical results; every step completes inside the timed bracket); "
                                         "--no-overlap-post issues a step's kernels in line"
                                       if overlap else "none: every kernel of a step on one stream"),
@@ -1101,7 +1104,7 @@ def main():
             out["collective_backend"] = backend_name
         if (world == 1 and split and not args.no_other_configs
                 and (B, S, K, args.arch, args.mode) == (32, 640, 80, "base", "detect")):
-            # configs[2], [3] (one rank's share) and [4] (per-GPU form, whole bank) in the driver's one line: five timed steps
+            # configs[2], [3] (one rank's share) and [4] (per-GPU form, whole bank) in the driver's one line: twelve timed steps (configs[4]: five)
             # each after two warm-ups, same protocol as the headline
             other = {}
             other["configs[2] large_b16_k1203"] = detect_leg(timer, L, "large", 16, 1203, uni=False)

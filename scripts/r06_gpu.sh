@@ -16,6 +16,36 @@ for f in sys.argv[1:]:
 PY
 }
 case $STEP in
+depth32)
+  for i in 1 2 3 4; do
+    WEDETECT_BB_DEPTH=1 WEDETECT_BB_CHAINS=2 python bench.py $Q > $OUT/bench_d1c2_$i.json 2> $OUT/bench_d1c2_$i.err
+    WEDETECT_BB_DEPTH=2 WEDETECT_BB_CHAINS=1 python bench.py $Q > $OUT/bench_d2c1_$i.json 2> $OUT/bench_d2c1_$i.err
+  done
+  line $OUT/bench_*.json; cat $OUT/*.err | grep -v amdgpu.ids | tail -n 20
+  ;;
+depthcfg)
+  for i in 1 2; do
+    for cfg in "base64:--batch 64" "base2:--batch 2" "large16:--arch large --batch 16 --classes 1203" "tiny32:--arch tiny" "large1280:--arch large --size 1280 --batch 4 --classes 1203"; do
+      name=${cfg%%:*}; fl=${cfg#*:}
+      WEDETECT_BB_DEPTH=1 python bench.py $Q $fl > $OUT/bench_${name}_d1_$i.json 2> $OUT/bench_${name}_d1_$i.err
+      WEDETECT_BB_DEPTH=2 WEDETECT_BB_CHAINS=1 python bench.py $Q $fl > $OUT/bench_${name}_d2c1_$i.json 2> $OUT/bench_${name}_d2c1_$i.err
+    done
+  done
+  line $OUT/bench_*.json; cat $OUT/*.err | grep -v amdgpu.ids | tail -n 20
+  ;;
+depth)
+  # two backbones in flight (steps alternate between two backbone streams): identity tests, sweep over the batch
+  ( timeout 1200 python -m pytest tests/test_gpu_network.py -q -m gpu -k "pipelined" -x 2>&1 | tail -8 ) > $OUT/tests.log
+  for i in 1 2; do
+    for b in ${BATCHES:-1 4 8 16 32}; do
+      for dp in 1 2; do
+        WEDETECT_BB_DEPTH=$dp python bench.py $Q --batch $b > $OUT/bench_b${b}_d${dp}_$i.json 2> $OUT/bench_b${b}_d${dp}_$i.err
+      done
+    done
+    WEDETECT_BB_DEPTH=2 WEDETECT_BB_CHAINS=1 python bench.py $Q > $OUT/bench_b32_d2c1_$i.json 2> $OUT/bench_b32_d2c1_$i.err
+  done
+  cat $OUT/tests.log; line $OUT/bench_*.json; cat $OUT/*.err | grep -v amdgpu.ids | tail -n 20
+  ;;
 chainstages)
   ( timeout 1200 python -m pytest tests/test_gpu_network.py -q -m gpu -k "image_chains or pipelined" -x 2>&1 | tail -8 ) > $OUT/tests.log
   for i in 1 2; do

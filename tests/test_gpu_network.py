@@ -328,9 +328,10 @@ def test_pipelined_post_process_equals_the_in_line_step():
         assert torch.equal(ref[0][k], r[k]), f"in-line step behind a pipelined one: {k} differs"
 
 
-@pytest.mark.parametrize("arch,b,hw,chains,dag,split_k", [("base", 2, 320, 1, True, False), ("tiny", 4, 128, 2, True, False),
-                                                           ("tiny", 3, 128, 1, False, False), ("base", 1, 320, 1, True, True)])
-def test_neck_head_pipelined_behind_the_next_backbone_equals_the_in_line_step(arch, b, hw, chains, dag, split_k):
+@pytest.mark.parametrize("arch,b,hw,chains,dag,split_k,depth", [("base", 2, 320, 1, True, False, 1), ("tiny", 4, 128, 2, True, False, 1),
+                                                                 ("tiny", 3, 128, 1, False, False, 1), ("base", 1, 320, 1, True, True, 1),
+                                                                 ("base", 2, 320, 1, True, False, 2), ("base", 1, 320, 1, True, True, 2)])
+def test_neck_head_pipelined_behind_the_next_backbone_equals_the_in_line_step(arch, b, hw, chains, dag, split_k, depth):
     """Round 6: in a stream of batches (detect(overlap_post=True)) the neck + head + similarity of step i run on the tower's nh
     stream beside the BACKBONE of step i + 1 (c1..c4 double-buffered), the post-process behind them on the post stream.  Six
     DIFFERENT batches issued back to back with no host synchronisation must give exactly the tensors of the in-line steps — with
@@ -349,8 +350,8 @@ def test_neck_head_pipelined_behind_the_next_backbone_equals_the_in_line_step(ar
         r = t.detect(x, t.P["prompts"], meta, **kw)
         torch.cuda.synchronize()
         ref.append({k: v.clone() for k, v in r.items()})
-    t.bb_chains, t.pipe_neck, t.dag = str(chains), "1", dag
-    assert t._pipe_neck_on() and t._n_chains() == chains
+    t.bb_chains, t.pipe_neck, t.dag, t.bb_depth = str(chains), "1", dag, str(depth)     # depth 2: two backbones in flight, on two streams
+    assert t._pipe_neck_on() and t._n_chains() == chains and t._bb_depth() == depth
     got = []
     for x in batches:                                   # no synchronisation between the calls
         r = t.detect(x, t.P["prompts"], meta, overlap_post=True, **kw)
@@ -359,7 +360,7 @@ def test_neck_head_pipelined_behind_the_next_backbone_equals_the_in_line_step(ar
     r = t.detect(batches[0], t.P["prompts"], meta, **kw)     # in line, right behind a pipelined call
     t.wait_post()
     torch.cuda.synchronize()
-    assert t._nh_stream is not None and len(t._x_sets) == 2
+    assert t._nh_stream is not None and len(t._x_sets) == depth + 1 and (depth == 1 or t._slot1 is not None)
     for i, (a_, b_) in enumerate(zip(ref, got)):
         for k in a_:
             assert torch.equal(a_[k], b_[k]), f"batch {i}: {k} differs between the pipelined neck / head and the in-line step"

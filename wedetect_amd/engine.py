@@ -158,8 +158,12 @@ class ImageTower:
         self._nh_issue = False                    # neck / head launches are being issued on the nh stream (never lend them self.park)
         self._x_sets: List[List[torch.Tensor]] = []
         self._x_par = 0
-        self._x_free: List[Optional[torch.cuda.Event]] = [None, None]
-        self._bb_done: Optional[torch.cuda.Event] = None
+        self._x_free: List[Optional[torch.cuda.Event]] = [None]
+        self._bb_done: List[torch.cuda.Event] = []
+        self.bb_depth = os.environ.get("WEDETECT_BB_DEPTH", "auto")
+        self._depth2_issue = False                # a backbone of the two-in-flight schedule is being issued: no image chains by default
+        self._bb_slot = 0
+        self._slot1: Optional[dict] = None
         self._chain_parks: Dict[int, torch.Tensor] = {}
         self._chain_evs: List[torch.cuda.Event] = []
         self.s2d_down = os.environ.get("WEDETECT_S2D_DOWN", "1") != "0"     # downsample convs as plain GEMMs on space-to-depth LayerNorm rows
@@ -643,6 +647,8 @@ class ImageTower:
         if torch.cuda.is_current_stream_capturing() and not self._dag_in_capture:
             return 1
         n = 2 if self.bb_chains == "auto" else int(self.bb_chains)
+        if self.bb_chains == "auto" and self._depth2_issue:
+            return 1                # two whole backbones are in flight instead (detect(overlap_post=True), _bb_depth)
         if self.bb_chains == "auto" and not (self.BB_CHAINS_MIN_PIXELS <= self.B * self.H * self.W < 2 * self.BB_CHAINS_MIN_PIXELS):
             return 1                # measured window (profiles/r06_pipeline.txt): pays at 32 x 640 x 640, loses at 16 x and 64 x
         while n > 1 and (self.B % n or any(t.numel() % (64 * n) for t in (self.tmp, self.hid))):
@@ -1280,21 +1286,40 @@ class ImageTower:
             self._post_ready = torch.cuda.Event()
         main = torch.cuda.current_stream()
         pipe = self._pipe_neck_on()
+        depth = self._bb_depth() if pipe else 1
+        bb_stream = main
         if pipe:
-            # c1..c4 double-buffered: this backbone writes the set the neck of step i - 2 read
+            # c1..c4 in depth + 1 sets: this backbone writes the set the neck of step i - depth - 1 read
             if not self._x_sets:
-                self._x_sets = [self.x, [torch.empty_like(t) for t in self.x]]
+                self._x_sets = [self.x]
                 self._nh_stream = torch.cuda.Stream(device=self.dev)
-                self._bb_done = torch.cuda.Event()
-            self._x_par ^= 1
+                self._bb_done = [torch.cuda.Event(), torch.cuda.Event()]
+            while len(self._x_sets) < depth + 1:
+                self._x_sets.append([torch.empty_like(t) for t in self.x])
+                self._x_free.append(None)
+            self._x_par = (self._x_par + 1) % len(self._x_sets)
             self.x = self._x_sets[self._x_par]        # backbone() waits for the neck that last read this set
-        self.backbone(images_u8)
-        nh = self._nh_stream if pipe else main
+        if depth == 2:
+            # TWO backbones in flight: steps alternate between the caller's stream (slot 0: the tower's own scratch buffers) and
+            # the tower's second backbone stream (slot 1: scratch, park workspace and an input staging buffer of its own)
+            self._bb_slot ^= 1
+            self._depth2_issue = True
+            try:
+                if self._bb_slot:
+                    bb_stream = self._slot1_backbone(images_u8, main)
+                else:
+                    self.backbone(images_u8)
+            finally:
+                self._depth2_issue = False
+        else:
+            self._bb_slot = 0
+            self.backbone(images_u8)
         if pipe:
-            self._bb_done.record(main)
+            self._bb_done[self._bb_slot].record(bb_stream)
+        nh = self._nh_stream if pipe else main
         with (torch.cuda.stream(nh) if pipe else contextlib.nullcontext()):
             if pipe:
-                nh.wait_event(self._bb_done)
+                nh.wait_event(self._bb_done[self._bb_slot])
                 self._nh_issue = True
             try:
                 if self._dag_on():
@@ -1326,6 +1351,37 @@ class ImageTower:
                 self._post_done = torch.cuda.Event()
             self._post_done.record(self.post_stream)
         return res
+
+    def _bb_depth(self) -> int:
+        """Backbones in flight in a stream of batches (``$WEDETECT_BB_DEPTH``: "auto" = 2, "1", "2"): 2 = steps alternate between two
+        backbone streams, so that the backbone of step i + 1 runs beside the backbone of step i (and the neck / head of step
+        i - 1).  Whole-batch launches on both — unlike the image chains, which it replaces in a stream of batches (caller, second
+        backbone, nh, post = the four hardware queues; the chains stay for the in-line step): Base B = 8 712 -> 780 images/s,
+        B = 16 893 -> 933, B = 4 575 -> 612, Tiny B = 32 1 925 -> 1 987; at Base B = 32 equal to the chains (972.7 / 971.3)."""
+        return 1 if self.bb_depth == "1" else 2      # "auto" = 2: measured at every size (profiles/r06_pipeline.txt)
+
+    def _slot1_backbone(self, images_u8: torch.Tensor, main) -> torch.cuda.Stream:
+        """The backbone of this step on the tower's SECOND backbone stream, over scratch buffers of its own; the batch is
+        staged into a tower-owned buffer on the caller's stream first, so that the caller may reuse its tensor at once."""
+        if self._slot1 is None:
+            z = lambda t: None if t is None else torch.empty_like(t)
+            self._slot1 = dict(stream=torch.cuda.Stream(device=self.dev), ready=torch.cuda.Event(), img=torch.empty_like(images_u8),
+                               tmp=z(self.tmp), hid=z(self.hid), ln_part=z(self.ln_part), ln_stats=z(self.ln_stats), patches=z(self.patches),
+                               park=torch.zeros(max(1, L.p8_workspace_bytes() // 4), dtype=torch.float32, device=self.dev))
+        s1 = self._slot1
+        main.wait_event(self._bb_done[1])             # the slot's previous backbone (two steps ago) has read the staging buffer
+        s1["img"].copy_(images_u8, non_blocking=True)
+        s1["ready"].record(main)
+        v = copy.copy(self)
+        v.tmp, v.hid, v.ln_part, v.ln_stats, v.patches = s1["tmp"], s1["hid"], s1["ln_part"], s1["ln_stats"], s1["patches"]
+        v.park = s1["park"] if self.park is not None else None
+        v._park_mlp = s1["park"]
+        if v.bb_chains != "auto":
+            v.bb_chains = "1"                         # forced image chains run on slot 0 only (one set of chain workspaces)
+        with torch.cuda.stream(s1["stream"]):
+            s1["stream"].wait_event(s1["ready"])
+            v.backbone(s1["img"])
+        return s1["stream"]
 
     def _pipe_neck_on(self) -> bool:
         """Neck / head of a pipelined step on the nh stream?  Never inside the calibration pass or stream capture."""
