@@ -459,9 +459,10 @@ def fp32_reference_run(args, tower, images, text, meta, uni, steps=5):
 
 def host_fed_run(tower, images, text, meta, uni, steps):
     """The same step with the batch coming from (and the results going back to) pinned host memory every step.
-    Two device input buffers; uploads and result downloads run on a copy stream and overlap compute:
+    Two device input buffers; uploads and result downloads run on a copy stream and overlap compute, the steps themselves
+    are the pipelined ones of the headline (detect(overlap_post=True): results staged out on the tower's post stream):
         copy stream :  H2D batch i+1 | D2H results i-1
-        main stream :  step i
+        tower       :  step i (backbone | neck + head | post-process on their streams)
     Measured over ``steps`` steps after 2 warm-ups, wall clock around a full drain."""
     dev = images.device
     B = images.shape[0]
@@ -492,13 +493,14 @@ def host_fed_run(tower, images, text, meta, uni, steps):
                     d_in[nxt].copy_(h_img, non_blocking=True)
                     up[nxt].record(cs)
             main.wait_event(up[cur])
-            r = tower.detect(d_in[cur], text, meta, **kw)
-            free_in[cur].record(main)
-            if i >= 2:
-                main.wait_event(drained[cur])                  # the D2H of step i-2 has left this staging set
-            for k in keys:
-                d_out[cur][k].copy_(r[k], non_blocking=True)
-            done[cur].record(main)
+            r = tower.detect(d_in[cur], text, meta, overlap_post=True, **kw)
+            free_in[cur].record(main)                          # the backbone (or its staging copy) is ordered on the caller's stream
+            with torch.cuda.stream(tower.post_stream):         # the results are produced there
+                if i >= 2:
+                    tower.post_stream.wait_event(drained[cur])     # the D2H of step i-2 has left this staging set
+                for k in keys:
+                    d_out[cur][k].copy_(r[k], non_blocking=True)
+                done[cur].record(tower.post_stream)
             with torch.cuda.stream(cs):
                 cs.wait_event(done[cur])
                 for k in keys:
