@@ -1353,12 +1353,14 @@ class ImageTower:
         return res
 
     def _bb_depth(self) -> int:
-        """Backbones in flight in a stream of batches (``$WEDETECT_BB_DEPTH``: "auto" = 2, "1", "2"): 2 = steps alternate between two
+        """Backbones in flight in a stream of batches (``$WEDETECT_BB_DEPTH``: "auto" = 2 from two 640 x 640 images per batch, "1", "2"): 2 = steps alternate between two
         backbone streams, so that the backbone of step i + 1 runs beside the backbone of step i (and the neck / head of step
         i - 1).  Whole-batch launches on both — unlike the image chains, which it replaces in a stream of batches (caller, second
         backbone, nh, post = the four hardware queues; the chains stay for the in-line step): Base B = 8 712 -> 780 images/s,
         B = 16 893 -> 933, B = 4 575 -> 612, Tiny B = 32 1 925 -> 1 987; at Base B = 32 equal to the chains (972.7 / 971.3)."""
-        return 1 if self.bb_depth == "1" else 2      # "auto" = 2: measured at every size (profiles/r06_pipeline.txt)
+        if self.bb_depth == "auto":                  # measured (profiles/r06_pipeline.txt): pays from two 640 x 640 images per batch;
+            return 2 if self.B * self.H * self.W >= 2 * 640 * 640 else 1      # a single image is bound by the host's launch rate
+        return 2 if self.bb_depth == "2" else 1
 
     def _slot1_backbone(self, images_u8: torch.Tensor, main) -> torch.cuda.Stream:
         """The backbone of this step on the tower's SECOND backbone stream, over scratch buffers of its own; the batch is
