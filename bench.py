@@ -563,7 +563,7 @@ def fp32_sim_reference(tower, L, text, normalize, reps=5):
             "peak": F32_MFMA_PEAK_TFLOPS, "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4)}
 
 
-def detect_leg(timer, L, arch, B, K, uni, steps=12, warmup=3):
+def detect_leg(timer, L, arch, B, K, uni, steps=20, warmup=3):
     """A short run of ANOTHER BASELINE configuration inside the default invocation (configs[2] / [3] were
     builder-run files only): same protocol as the headline — calibration, ``warmup`` untimed steps, ``steps`` timed steps
     issued back to back with the post-process on the second stream, wall clock around a full drain — and the per-launch
@@ -1106,7 +1106,7 @@ def main():
             out["collective_backend"] = backend_name
         if (world == 1 and split and not args.no_other_configs
                 and (B, S, K, args.arch, args.mode) == (32, 640, 80, "base", "detect")):
-            # configs[2], [3] (one rank's share) and [4] (per-GPU form, whole bank) in the driver's one line: twelve timed steps (configs[4]: five)
+            # configs[2], [3] (one rank's share) and [4] (per-GPU form, whole bank) in the driver's one line: twenty timed steps (configs[4]: five)
             # each after two warm-ups, same protocol as the headline
             other = {}
             other["configs[2] large_b16_k1203"] = detect_leg(timer, L, "large", 16, 1203, uni=False)
