@@ -46,6 +46,27 @@ def fold_layernorm_into_linear(w1: torch.Tensor, b1: torch.Tensor, gamma: torch.
     return w1g, u, v
 
 
+_DEVICE_STREAMS: Dict[str, Dict[str, list]] = {}
+
+
+def device_streams(dev: torch.device, role: str, n: int = 1) -> List[torch.cuda.Stream]:
+    """The ``n`` streams of a ROLE on a device, shared by every tower of the process.  The HIP runtime multiplexes streams onto four
+    hardware queues in the order they are created: a stream of batches wants caller, post, nh and the second backbone stream
+    on four DIFFERENT queues (ImageTower.detect), so the roles are created once, in that order, the first time any tower pipelines —
+    a tower built later (another architecture or batch size in the same process) then gets the very mapping the first one had
+    instead of whatever the creation order of ITS streams would have landed on (a Large tower built after a Base tower in one
+    process ran 9 % slower than alone: its nh and second backbone streams shared a queue).  Sharing is only a matter of order:
+    towers used one after another, as the detectors use them, never wait for each other on it."""
+    pool = _DEVICE_STREAMS.setdefault(str(dev), {})
+    if not pool:                                   # fixed creation order of the pipeline roles
+        for r in ("post", "nh", "bb2"):
+            pool[r] = [torch.cuda.Stream(device=dev)]
+    lst = pool.setdefault(role, [])
+    while len(lst) < n:
+        lst.append(torch.cuda.Stream(device=dev))
+    return lst[:n]
+
+
 class ImageTower:
     PRECISIONS = ("fp32", "fp16x3")
     SPLIT_K_AUTO_PIXELS = 4 * 640 * 640
@@ -614,8 +635,8 @@ class ImageTower:
             self.t._lane_i = self.prev
 
     def _lane(self, i: int) -> "ImageTower._Lane":
-        while len(self._side) < self.N_LANES - 1:
-            self._side.append(torch.cuda.Stream(device=self.dev))
+        if len(self._side) < self.N_LANES - 1:
+            self._side = device_streams(self.dev, "lanes", self.N_LANES - 1)
         return ImageTower._Lane(self, i)
 
     def _mark(self) -> torch.cuda.Event:
@@ -710,8 +731,8 @@ class ImageTower:
         chain h on its own stream; launches are issued phase by phase in turn so that no stream's queue runs dry while the host
         is busy with another's; the caller's stream continues when all chains have arrived."""
         views = self._chain_views(n)
-        while len(self._chain_streams) < n - 1:        # their own streams: the DAG lanes may be running the previous step's neck
-            self._chain_streams.append(torch.cuda.Stream(device=self.dev))
+        if len(self._chain_streams) < n - 1:           # their own streams: the DAG lanes may be running the previous step's neck
+            self._chain_streams = device_streams(self.dev, "chains", n - 1)
         while len(self._chain_evs) < 3 * n:
             self._chain_evs.append(torch.cuda.Event())
         done, ev_dw, ev_mlp = self._chain_evs[:n], self._chain_evs[n:2 * n], self._chain_evs[2 * n:3 * n]
@@ -1282,7 +1303,7 @@ class ImageTower:
             scores = self.similarity(text, normalize=normalize_text)
             return self.postprocess(scores, score_thr, meta, iou_thr, with_embed, nms, nms_param, nms_device)
         if self.post_stream is None:
-            self.post_stream = torch.cuda.Stream(device=self.dev)
+            self.post_stream = device_streams(self.dev, "post")[0]
             self._post_ready = torch.cuda.Event()
         main = torch.cuda.current_stream()
         pipe = self._pipe_neck_on()
@@ -1292,7 +1313,7 @@ class ImageTower:
             # c1..c4 in depth + 1 sets: this backbone writes the set the neck of step i - depth - 1 read
             if not self._x_sets:
                 self._x_sets = [self.x]
-                self._nh_stream = torch.cuda.Stream(device=self.dev)
+                self._nh_stream = device_streams(self.dev, "nh")[0]
                 self._bb_done = [torch.cuda.Event(), torch.cuda.Event()]
             while len(self._x_sets) < depth + 1:
                 self._x_sets.append([torch.empty_like(t) for t in self.x])
@@ -1367,7 +1388,7 @@ class ImageTower:
         staged into a tower-owned buffer on the caller's stream first, so that the caller may reuse its tensor at once."""
         if self._slot1 is None:
             z = lambda t: None if t is None else torch.empty_like(t)
-            self._slot1 = dict(stream=torch.cuda.Stream(device=self.dev), ready=torch.cuda.Event(), img=torch.empty_like(images_u8),
+            self._slot1 = dict(stream=device_streams(self.dev, "bb2")[0], ready=torch.cuda.Event(), img=torch.empty_like(images_u8),
                                tmp=z(self.tmp), hid=z(self.hid), ln_part=z(self.ln_part), ln_stats=z(self.ln_stats), patches=z(self.patches),
                                park=torch.zeros(max(1, L.p8_workspace_bytes() // 4), dtype=torch.float32, device=self.dev))
         s1 = self._slot1
