@@ -161,19 +161,24 @@ class ImageTower:
         # all have arrived: one group's depthwise / LayerNorm launches then run beside another's GEMMs and the tail of one
         # launch is filled by the next group's head.  Same kernels on the same rows (every kernel form gives a row the same
         # bits whatever batch it arrives in): bit-identical to the one-chain step
-        # (tests/test_gpu_network.py::test_backbone_image_chains_equal_the_single_chain).  "auto": two chains for large towers
-        # (no latency split-K: that class splits K by the batch's reference geometry) of at least BB_CHAINS_MIN_PIXELS per batch.
+        # (tests/test_gpu_network.py::test_backbone_image_chains_equal_the_single_chain).  "auto": two chains for the IN-LINE step of
+        # towers without latency split-K (that class splits K by the batch's reference geometry) in the window in which they were
+        # measured to pay (_n_chains: 32 to 63 x 640 x 640 pixels per batch, + 2.9 % at Base B = 32); a stream of batches keeps two
+        # whole backbones in flight instead (bb_depth below).  $WEDETECT_BB_CHAIN_ORDER / _STAGES: the cross-chain phase orders and
+        # stage ranges that were measured and lost (profiles/r06_pipeline.txt), kept for A/B runs.
         self.bb_chains = os.environ.get("WEDETECT_BB_CHAINS", "auto")
         self.bb_chain_order = os.environ.get("WEDETECT_BB_CHAIN_ORDER", "free")
         st = os.environ.get("WEDETECT_BB_CHAIN_STAGES", "0-3").split("-")       # the stages (0-based, inclusive) that run as chains
         self.bb_chain_stages = (max(0, int(st[0])), min(3, int(st[-1])))
         self._chain_streams: List[torch.cuda.Stream] = []
         # A stream of batches (detect(overlap_post=True)), round 6, late: neck + head + similarity of step i on the tower's own
-        # "nh" stream beside the BACKBONE of step i + 1 ($WEDETECT_PIPE_NECK = "auto" (default: the towers that run image chains),
-        # "1", "0").  The neck / head launches fill 50 - 200 of 256 CUs at 0.15 - 0.45 of the MFMA roof; the next batch's
-        # backbone — which touches none of their buffers once c1..c4 are double-buffered (0.8 GB for Base, B = 32) — runs in
-        # the gaps.  Same kernels, same arguments: bit-identical results
+        # "nh" stream beside the BACKBONE of step i + 1 ($WEDETECT_PIPE_NECK = "auto" (default: on, every size gains), "1", "0").
+        # The neck / head launches fill 50 - 200 of 256 CUs at 0.15 - 0.45 of the MFMA roof; the next batch's backbone — which
+        # touches none of their buffers once c1..c4 exist in bb_depth + 1 sets (0.8 GB each for Base, B = 32) — runs in the
+        # gaps.  Same kernels, same arguments: bit-identical results
         # (tests/test_gpu_network.py::test_neck_head_pipelined_behind_the_next_backbone_equals_the_in_line_step).
+        # $WEDETECT_BB_DEPTH ("auto" = 2 from two 640 x 640 images per batch): TWO backbones in flight — the steps of the stream
+        # alternate between the caller's stream and a second backbone stream (_slot1_backbone).
         self.pipe_neck = os.environ.get("WEDETECT_PIPE_NECK", "auto")
         self._nh_stream: Optional[torch.cuda.Stream] = None
         self._nh_issue = False                    # neck / head launches are being issued on the nh stream (never lend them self.park)
