@@ -598,7 +598,7 @@ def detect_leg(timer, L, arch, B, K, uni, steps=20, warmup=3):
     if tower._n_chains() > 1 or tower._pipe_neck_on():
         # per-kernel figures from a serial step (see main(): in the pipelined steps launches of several streams share the chip)
         timer.rec.clear()
-        tower.bb_chains, tower.pipe_neck = "1", "0"
+        tower.bb_chains, tower.pipe_neck, tower.force_tile_forms = "1", "0", True
         tower.detect(images, text, meta, **kw)
         torch.cuda.synchronize()
         timer.prepare(timer.count // max(1, warmup))
@@ -996,8 +996,8 @@ def main():
     if concurrent:
         dog.phase("serial leg (per-kernel timing)")
         timed_summ = timer.summary(busy=True) if rank == 0 else None
-        saved_modes = (tower.bb_chains, tower.pipe_neck)
-        tower.bb_chains, tower.pipe_neck = "1", "0"
+        saved_modes = (tower.bb_chains, tower.pipe_neck, tower.force_tile_forms)
+        tower.bb_chains, tower.pipe_neck, tower.force_tile_forms = "1", "0", True      # the kernel forms of the pipelined step
         for _ in range(2):
             step()
         sync()
@@ -1008,7 +1008,7 @@ def main():
             step()
         sync()
         timer.mode = "off"
-        tower.bb_chains, tower.pipe_neck = saved_modes
+        tower.bb_chains, tower.pipe_neck, tower.force_tile_forms = saved_modes
 
     if rank == 0:
         summ = timer.summary()
@@ -1082,7 +1082,7 @@ def main():
                          "launches_per_step": dom["launches"] // n_inst, "avg_launch_us": round(dom["avg_us"], 2),
                          "algorithmic_gflop_per_launch": round(dom["flops_total"] / dom["launches"] / 1e9, 3),
                          **({"measured_in": f"serial leg: {n_inst} instrumented steps after two warm-ups, right after the timed region, "
-                                            "with WEDETECT_BB_CHAINS=1 WEDETECT_PIPE_NECK=0 semantics (one backbone chain, neck / head in line) — "
+                                            "with WEDETECT_BB_CHAINS=1 WEDETECT_PIPE_NECK=0 WEDETECT_FORCE_TILE=1 semantics (one backbone chain, neck / head in line, the tile forms the pipelined backbone runs) — "
                                             "in the timed region launches of several streams share the chip (timed_region below)",
                              "timed_region": timed_region_record(timed_summ, dom_tag, dom_peak, n_inst, tower)} if concurrent else {})},
             "gemm_kernels": {k: {"launches_per_step": v["launches"] // n_inst, "avg_us": round(v["avg_us"], 2),

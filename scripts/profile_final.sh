@@ -8,10 +8,10 @@ TAG=${1:-final}; shift
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 # Round 6: per-kernel evidence (trace averages, SQ counters, per-launch HBM bytes) is taken on the SERIAL form of the step — one
-# backbone chain, neck / head in line: what bench.py's serial leg measures (roofline.measured_in) — because in the default,
+# backbone chain, neck / head in line, the tile kernel forms of the pipelined backbone: what bench.py's serial leg measures (roofline.measured_in) — because in the default,
 # pipelined form launches of several streams share the chip and a launch's duration / counters are not its own.  The default
 # command gets a kernel trace of its own (summary_pipelined.txt): the whole picture, half-batch launches of the two image chains.
-export WEDETECT_BB_CHAINS=1 WEDETECT_PIPE_NECK=0
+export WEDETECT_BB_CHAINS=1 WEDETECT_PIPE_NECK=0 WEDETECT_FORCE_TILE=1
 CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fp32-reference --no-host-fed --no-other-configs --no-calibrate $*"
 timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace -o p -- $CMD > $OUT/trace_bench.json 2> $OUT/trace.err
 if [ -n "$TRACE_ONLY" ]; then     # kernel trace only (TRACE_ONLY=1): no counter passes
@@ -24,7 +24,7 @@ timeout 900 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o p -- $CMD > /dev/nul
 T=$(ls $OUT/trace/*.db | head -1); S=$(ls $OUT/pmc_sq/*.db | head -1); F=$(ls $OUT/pmc_fetch/*.db | head -1); W=$(ls $OUT/pmc_write/*.db | head -1)
 python scripts/rocpd_summary.py $T --pmc $S > $OUT/summary.txt 2>&1
 python scripts/traffic_json.py $F $W > $OUT/traffic.json 2> $OUT/traffic.err
-unset WEDETECT_BB_CHAINS WEDETECT_PIPE_NECK
+unset WEDETECT_BB_CHAINS WEDETECT_PIPE_NECK WEDETECT_FORCE_TILE
 timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace_pipe -o p -- $CMD > $OUT/trace_pipe_bench.json 2> $OUT/trace_pipe.err
 python scripts/rocpd_summary.py $(ls $OUT/trace_pipe/*.db | head -1) > $OUT/summary_pipelined.txt 2>&1
 rm -f $OUT/*/*.db            # keep the merge-back small: summaries only

@@ -16,6 +16,66 @@ for f in sys.argv[1:]:
 PY
 }
 case $STEP in
+persist)
+  # which persistent forms to keep while a pipelined backbone is issued: none (0) / the 256 x 256 kernel's (p8) / the wide MLP's (mlp) / both (1)
+  ( timeout 1200 python -m pytest tests/test_gpu_network.py -q -m gpu -k "pipelined or image_chains" -x 2>&1 | tail -4 ) > $OUT/tests.log
+  for i in 1 2; do
+    for m in 0 p8 mlp 1; do
+      WEDETECT_PIPE_PERSIST=$m python bench.py $Q > $OUT/bench_b32_pp${m}_$i.json 2> $OUT/bench_b32_pp${m}_$i.err
+      WEDETECT_PIPE_PERSIST=$m python bench.py $Q --batch 64 > $OUT/bench_b64_pp${m}_$i.json 2> $OUT/bench_b64_pp${m}_$i.err
+      WEDETECT_PIPE_PERSIST=$m python bench.py $Q --batch 16 > $OUT/bench_b16_pp${m}_$i.json 2> $OUT/bench_b16_pp${m}_$i.err
+    done
+  done
+  cat $OUT/tests.log; line $OUT/bench_*.json; cat $OUT/*.err | grep -v amdgpu.ids | tail -n 20
+  ;;
+p8tile)
+  # persistent (stream-K gangs) against tile form of the 256 x 256 kernel under the stream pipeline, in line, other towers / batches
+  for i in 1 2; do
+    for m in persist tile; do
+      WEDETECT_P8=$m python bench.py $Q > $OUT/bench_b32_${m}_$i.json 2> $OUT/bench_b32_${m}_$i.err
+      WEDETECT_P8=$m python bench.py $Q --no-overlap-post > $OUT/bench_inline_${m}_$i.json 2> $OUT/bench_inline_${m}_$i.err
+      WEDETECT_P8=$m python bench.py $Q --batch 16 > $OUT/bench_b16_${m}_$i.json 2> $OUT/bench_b16_${m}_$i.err
+      WEDETECT_P8=$m python bench.py $Q --batch 64 > $OUT/bench_b64_${m}_$i.json 2> $OUT/bench_b64_${m}_$i.err
+      WEDETECT_P8=$m python bench.py $Q --arch large --batch 16 --classes 1203 > $OUT/bench_large16_${m}_$i.json 2> $OUT/bench_large16_${m}_$i.err
+      WEDETECT_P8=$m python bench.py $Q --arch tiny > $OUT/bench_tiny32_${m}_$i.json 2> $OUT/bench_tiny32_${m}_$i.err
+    done
+  done
+  line $OUT/bench_*.json; cat $OUT/*.err | grep -v amdgpu.ids | tail -n 20
+  ;;
+wide512)
+  # the 512-channel one-kernel block MLP as default?  in-line steps (no pipeline), other batches
+  for i in 1 2; do
+    for w in "256" "256,512"; do
+      n=${w//,/_}
+      WEDETECT_FUSE_MLP_WIDE=$w python bench.py $Q --no-overlap-post > $OUT/bench_inline_w${n}_$i.json 2> $OUT/bench_inline_w${n}_$i.err
+      WEDETECT_FUSE_MLP_WIDE=$w python bench.py $Q --batch 16 > $OUT/bench_b16_w${n}_$i.json 2> $OUT/bench_b16_w${n}_$i.err
+      WEDETECT_FUSE_MLP_WIDE=$w python bench.py $Q --batch 64 > $OUT/bench_b64_w${n}_$i.json 2> $OUT/bench_b64_w${n}_$i.err
+      WEDETECT_FUSE_MLP_WIDE=$w python bench.py $Q --batch 24 > $OUT/bench_b24_w${n}_$i.json 2> $OUT/bench_b24_w${n}_$i.err
+    done
+  done
+  line $OUT/bench_*.json; cat $OUT/*.err | grep -v amdgpu.ids | tail -n 20
+  ;;
+energy2)
+  for i in 1 2 3; do
+    python bench.py $Q > $OUT/bench_default_$i.json 2> $OUT/bench_default_$i.err
+    WEDETECT_FUSE_MLP_WIDE=256,512 python bench.py $Q > $OUT/bench_wide512_$i.json 2> $OUT/bench_wide512_$i.err
+    WEDETECT_FUSE_MLP_WIDE=256,512 WEDETECT_P8=tile python bench.py $Q > $OUT/bench_wide512_p8tile_$i.json 2> $OUT/bench_wide512_p8tile_$i.err
+    WEDETECT_FUSE_MLP_WIDE=256,512 WEDETECT_LN_FOLD=0 python bench.py $Q > $OUT/bench_wide512_nofold_$i.json 2> $OUT/bench_wide512_nofold_$i.err
+    WEDETECT_FUSE_MLP_WIDE= python bench.py $Q > $OUT/bench_nowide_$i.json 2> $OUT/bench_nowide_$i.err
+  done
+  line $OUT/bench_*.json; cat $OUT/*.err | grep -v amdgpu.ids | tail -n 20
+  ;;
+energy)
+  # under the power cap a form that moves fewer bytes may win although it is slower alone: the 512-channel one-kernel block MLP
+  # (hidden tensor never leaves the CU), the similarity on the fp16x3 kernel at K = 80, the LayerNorm kernel instead of the fold
+  for i in 1 2 3; do
+    python bench.py $Q > $OUT/bench_default_$i.json 2> $OUT/bench_default_$i.err
+    WEDETECT_FUSE_MLP_WIDE=256,512 python bench.py $Q > $OUT/bench_wide512_$i.json 2> $OUT/bench_wide512_$i.err
+    WEDETECT_SIM_SPLIT=1 python bench.py $Q > $OUT/bench_simsplit_$i.json 2> $OUT/bench_simsplit_$i.err
+    WEDETECT_P8=tile python bench.py $Q > $OUT/bench_p8tile_$i.json 2> $OUT/bench_p8tile_$i.err
+  done
+  line $OUT/bench_*.json; cat $OUT/*.err | grep -v amdgpu.ids | tail -n 20
+  ;;
 depth32)
   for i in 1 2 3 4; do
     WEDETECT_BB_DEPTH=1 WEDETECT_BB_CHAINS=2 python bench.py $Q > $OUT/bench_d1c2_$i.json 2> $OUT/bench_d1c2_$i.err

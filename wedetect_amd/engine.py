@@ -188,6 +188,17 @@ class ImageTower:
         self._bb_done: List[torch.cuda.Event] = []
         self.bb_depth = os.environ.get("WEDETECT_BB_DEPTH", "auto")
         self._depth2_issue = False                # a backbone of the two-in-flight schedule is being issued: no image chains by default
+        # The persistent (stream-K) forms of the 256 x 256 kernel and of the wide block MLP hold every CU for the whole launch: the
+        # fastest form of a launch that has the chip to itself (+ 0.4 - 0.8 % on the one-stream step, round 4), the wrong one where
+        # launches of other streams are meant to run in its gaps — under the stream pipeline the TILE form wins at every size
+        # (Base B = 16 / 32 / 64: + 0.5 / 1.0 / 1.4 %, profiles/r06_pipeline.txt) although the launch itself is slower alone.  Same
+        # MFMA chain per output, bit-identical.  $WEDETECT_PIPE_PERSIST: "0" (default) = tile forms while a pipelined step's
+        # backbone is issued, "p8" / "mlp" / "1" = keep the persistent form of that family / of both (A/B).
+        self.pipe_persist = os.environ.get("WEDETECT_PIPE_PERSIST", "0")
+        self._pipe_issue = False                  # the backbone of a pipelined step (detect(overlap_post=True)) is being issued
+        # $WEDETECT_FORCE_TILE=1: the tile forms in EVERY step — what a pipelined step's backbone runs, for measuring those
+        # kernels one at a time (bench.py's serial leg, scripts/profile_final.sh)
+        self.force_tile_forms = os.environ.get("WEDETECT_FORCE_TILE", "0") == "1"
         self._bb_slot = 0
         self._slot1: Optional[dict] = None
         self._chain_parks: Dict[int, torch.Tensor] = {}
@@ -394,7 +405,7 @@ class ImageTower:
         if ws is not None and (kw.get("split_flags", 0) & L.SPLIT_A):
             plain = kw.get("kh", 1) == 1 and kw.get("kw", 1) == 1 and kw.get("stride", 1) == 1 and kw.get("pad", 0) == 0
             m = self.B * kw["hin"] * kw["win"]
-            if plain and self.park is not None and self._lane_i == 0 and not self._nh_issue and L.gemm_config(m, kw["n"], kw["cin"], split=True, presplit=True,
+            if plain and self.park is not None and self._lane_i == 0 and not self._nh_issue and self._persist_ok("p8") and L.gemm_config(m, kw["n"], kw["cin"], split=True, presplit=True,
                                                                                        park=True).endswith("/p8s"):
                 work = self.park
             elif plain and self.p8_mode == "0" and kw["cin"] % 16 == 0:
@@ -459,6 +470,11 @@ class ImageTower:
             return 1
         return max(1, min(512 // tiles, nk // 8, 16))
 
+    def _persist_ok(self, family: str) -> bool:
+        """May a launch of ``family`` ("p8" / "mlp") take its persistent form now?  Not while a pipelined step's backbone is issued
+        (see __init__: pipe_persist)."""
+        return not (self._pipe_issue or self.force_tile_forms) or self.pipe_persist in ("1", family)
+
     def _fold_weights(self, q: str) -> None:
         """W', u, v of one block (fold_layernorm_into_linear), on the device, once (shared through the packed set)."""
         if q + "w1g" in self.P.t:
@@ -517,7 +533,7 @@ class ImageTower:
                 max(1, L.p8_workspace_bytes() // 4), dtype=torch.float32, device=self.dev)
         L.mlp_fused_wide_ln(self.tmp, self.M[i], c, 4 * c, (ws[0][0], ws[0][1] / sa), self.P[q + "v"], self.P[q + "u"], self.ln_stats,
                             (ws[1][0], ws[1][1] / sh), self.P[q + "b2"], self.x[i], hid_scale=sh, range_flag=self.range_flag,
-                            workspace=self._park_mlp)
+                            workspace=self._park_mlp if self._persist_ok("mlp") else None)
 
     def _mlp_fused(self, q: str, i: int, wide: bool = False) -> None:
         """One ConvNeXt block MLP as a single launch: the 4c hidden activation never leaves the CU (wd_mlp_fused_split for the
@@ -544,7 +560,7 @@ class ImageTower:
             if self._park_mlp is None:
                 self._park_mlp = self.park if self.park is not None else torch.zeros(
                     max(1, L.p8_workspace_bytes() // 4), dtype=torch.float32, device=self.dev)
-            kw["workspace"] = self._park_mlp
+            kw["workspace"] = self._park_mlp if self._persist_ok("mlp") else None
         fn = L.mlp_fused_wide if wide else L.mlp_fused
         fn(self.tmp, self.M[i], c, 4 * c, (ws[0][0], ws[0][1] / sa), self.P[q + "b1"], (ws[1][0], ws[1][1] / sh),
            self.P[q + "b2"], self.x[i], hid_scale=sh, range_flag=self.range_flag, **kw)
@@ -1325,21 +1341,12 @@ class ImageTower:
                 self._x_free.append(None)
             self._x_par = (self._x_par + 1) % len(self._x_sets)
             self.x = self._x_sets[self._x_par]        # backbone() waits for the neck that last read this set
-        if depth == 2:
-            # TWO backbones in flight: steps alternate between the caller's stream (slot 0: the tower's own scratch buffers) and
-            # the tower's second backbone stream (slot 1: scratch, park workspace and an input staging buffer of its own)
-            self._bb_slot ^= 1
-            self._depth2_issue = True
-            try:
-                if self._bb_slot:
-                    bb_stream = self._slot1_backbone(images_u8, main)
-                else:
-                    self.backbone(images_u8)
-            finally:
-                self._depth2_issue = False
-        else:
-            self._bb_slot = 0
-            self.backbone(images_u8)
+        self._pipe_issue = pipe
+        try:
+            self._issue_pipelined_backbone(images_u8, main, depth)
+        finally:
+            self._pipe_issue = False
+        bb_stream = self._slot1["stream"] if (depth == 2 and self._bb_slot) else main
         if pipe:
             self._bb_done[self._bb_slot].record(bb_stream)
         nh = self._nh_stream if pipe else main
@@ -1377,6 +1384,23 @@ class ImageTower:
                 self._post_done = torch.cuda.Event()
             self._post_done.record(self.post_stream)
         return res
+
+    def _issue_pipelined_backbone(self, images_u8: torch.Tensor, main, depth: int) -> None:
+        if depth == 2:
+            # TWO backbones in flight: steps alternate between the caller's stream (slot 0: the tower's own scratch buffers) and
+            # the tower's second backbone stream (slot 1: scratch, park workspace and an input staging buffer of its own)
+            self._bb_slot ^= 1
+            self._depth2_issue = True
+            try:
+                if self._bb_slot:
+                    self._slot1_backbone(images_u8, main)
+                else:
+                    self.backbone(images_u8)
+            finally:
+                self._depth2_issue = False
+        else:
+            self._bb_slot = 0
+            self.backbone(images_u8)
 
     def _bb_depth(self) -> int:
         """Backbones in flight in a stream of batches (``$WEDETECT_BB_DEPTH``: "auto" = 2 from two 640 x 640 images per batch, "1", "2"): 2 = steps alternate between two
