@@ -16,6 +16,16 @@ for f in sys.argv[1:]:
 PY
 }
 case $STEP in
+forms2)
+  for i in 1 2; do
+    python bench.py $Q > $OUT/bench_default_$i.json 2> $OUT/bench_default_$i.err
+    WEDETECT_CONV3_WS=0 python bench.py $Q > $OUT/bench_conv3ws0_$i.json 2> $OUT/bench_conv3ws0_$i.err
+    WEDETECT_FUSE_MLP_WIDE=256,512 python bench.py $Q > $OUT/bench_wide512_$i.json 2> $OUT/bench_wide512_$i.err
+    WEDETECT_DWCONV_DMA=0 python bench.py $Q > $OUT/bench_dwdma0_$i.json 2> $OUT/bench_dwdma0_$i.err
+    WEDETECT_FIXED_SPLITK=0 python bench.py $Q > $OUT/bench_fsk0_$i.json 2> $OUT/bench_fsk0_$i.err
+  done
+  line $OUT/bench_*.json; cat $OUT/*.err | grep -v amdgpu.ids | tail -n 20
+  ;;
 persist)
   # which persistent forms to keep while a pipelined backbone is issued: none (0) / the 256 x 256 kernel's (p8) / the wide MLP's (mlp) / both (1)
   ( timeout 1200 python -m pytest tests/test_gpu_network.py -q -m gpu -k "pipelined or image_chains" -x 2>&1 | tail -4 ) > $OUT/tests.log
