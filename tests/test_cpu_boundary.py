@@ -596,7 +596,7 @@ def test_image_chain_and_pipeline_rules_are_host_logic(monkeypatch):
     from wedetect_amd.engine import ImageTower
     monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)        # no device here
     t = types.SimpleNamespace(bb_chains="auto", _calib=None, kws=None, B=32, H=640, W=640, _dag_in_capture=True, _depth2_issue=False,
-                              tmp=torch.empty(3 << 12), hid=torch.empty(3 << 14), BB_CHAINS_MIN_PIXELS=ImageTower.BB_CHAINS_MIN_PIXELS)
+                              tmp=torch.empty(3 << 12), hid=torch.empty(3 << 14), ln_part=None, ln_stats=torch.empty(3 << 10), BB_CHAINS_MIN_PIXELS=ImageTower.BB_CHAINS_MIN_PIXELS)
     n = lambda: ImageTower._n_chains(t)
     assert n() == 2
     t._depth2_issue = True

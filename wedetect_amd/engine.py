@@ -693,7 +693,7 @@ class ImageTower:
             return 1                # two whole backbones are in flight instead (detect(overlap_post=True), _bb_depth)
         if self.bb_chains == "auto" and not (self.BB_CHAINS_MIN_PIXELS <= self.B * self.H * self.W < 2 * self.BB_CHAINS_MIN_PIXELS):
             return 1                # measured window (profiles/r06_pipeline.txt): pays at 32 x 640 x 640, loses at 16 x and 64 x
-        while n > 1 and (self.B % n or any(t.numel() % (64 * n) for t in (self.tmp, self.hid))):
+        while n > 1 and (self.B % n or any(t.numel() % (64 * n) for t in (self.tmp, self.hid, self.ln_part, self.ln_stats) if t is not None)):
             n -= 1
         return max(1, n)
 
