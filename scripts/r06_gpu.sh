@@ -16,6 +16,18 @@ for f in sys.argv[1:]:
 PY
 }
 case $STEP in
+dwfin)
+  # statistics finalize inside the depthwise kernel: identity tests, step A/B at B = 32 and on single images
+  ( timeout 1500 python -m pytest tests/test_gpu_split.py tests/test_gpu_network.py -q -m gpu -k "finalize_inside or layernorm or fold or image_chains or pipelined or goldens or batch_invariant" -x 2>&1 | tail -4 ) > $OUT/tests.log
+  for i in 1 2 3; do
+    for f in 0 1; do
+      WEDETECT_DW_FIN=$f python bench.py $Q > $OUT/bench_b32_fin${f}_$i.json 2> $OUT/bench_b32_fin${f}_$i.err
+      WEDETECT_DW_FIN=$f python bench.py $Q --batch 1 --no-overlap-post > $OUT/bench_b1inline_fin${f}_$i.json 2> $OUT/bench_b1inline_fin${f}_$i.err
+      WEDETECT_DW_FIN=$f python bench.py $Q --batch 8 > $OUT/bench_b8_fin${f}_$i.json 2> $OUT/bench_b8_fin${f}_$i.err
+    done
+  done
+  cat $OUT/tests.log; line $OUT/bench_*.json; cat $OUT/*.err | grep -v amdgpu.ids | tail -n 20
+  ;;
 forms2)
   for i in 1 2; do
     python bench.py $Q > $OUT/bench_default_$i.json 2> $OUT/bench_default_$i.err
