@@ -17,7 +17,8 @@ PY
 }
 case $STEP in
 dwfin)
-  # statistics finalize inside the depthwise kernel: identity tests, step A/B at B = 32 and on single images
+  # statistics finalize inside the depthwise kernel: identity tests, step A/B at B = 32 and on single images (the code behind $WEDETECT_DW_FIN was
+  # measured 1.8 x slower and removed: profiles/r06_dwfin.txt; the step is kept as the record of what was run)
   ( timeout 1500 python -m pytest tests/test_gpu_split.py tests/test_gpu_network.py -q -m gpu -k "finalize_inside or layernorm or fold or image_chains or pipelined or goldens or batch_invariant" -x 2>&1 | tail -4 ) > $OUT/tests.log
   for i in 1 2 3; do
     for f in 0 1; do
